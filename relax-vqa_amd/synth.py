@@ -1,0 +1,112 @@
+"""Deterministic synthetic weights and clips (no network: no checkpoints, no videos).
+
+Weights follow the reference's state-dict key names so a real torchvision
+``resnet50`` / DINO ``vitbase16`` checkpoint drops into the same loader:
+  ResNet-50 keys: torchvision (reference: src/extractor/visualise_resnet.py:21)
+  ViT keys:       DINO checkpoint loaded at src/extractor/visualise_vit_layer.py:326-328
+Everything is drawn from numpy PCG64 so host, oracle and GPU box regenerate
+bit-identical tensors without shipping ~440 MB.
+"""
+import numpy as np
+
+RESNET_STAGES = [(1, 3, 64, 1), (2, 4, 128, 2), (3, 6, 256, 2), (4, 3, 512, 2)]
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def resnet50_state_dict(seed=7):
+    """fp32 numpy state dict with torchvision resnet50 key names (fc omitted:
+    the reference computes fc but never reads it)."""
+    g = _rng(seed)
+    sd = {}
+
+    def conv(name, cout, cin, k):
+        fan_out = cout * k * k
+        sd[name + ".weight"] = (g.standard_normal((cout, cin, k, k), dtype=np.float32)
+                                * np.float32(np.sqrt(2.0 / fan_out)))
+
+    def bn(name, c, gamma_scale=1.0):
+        sd[name + ".weight"] = (g.uniform(0.5, 1.5, c) * gamma_scale).astype(np.float32)
+        sd[name + ".bias"] = (g.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_mean"] = (g.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_var"] = g.uniform(0.5, 1.5, c).astype(np.float32)
+
+    conv("conv1", 64, 3, 7)
+    bn("bn1", 64)
+    cin = 64
+    for layer, blocks, width, _stride in RESNET_STAGES:
+        for b in range(blocks):
+            p = f"layer{layer}.{b}"
+            conv(p + ".conv1", width, cin, 1)
+            bn(p + ".bn1", width)
+            conv(p + ".conv2", width, width, 3)
+            bn(p + ".bn2", width)
+            conv(p + ".conv3", width * 4, width, 1)
+            bn(p + ".bn3", width * 4, gamma_scale=0.5)   # keeps the residual sum from growing 2x per block
+            if b == 0:
+                conv(p + ".downsample.0", width * 4, cin, 1)
+                bn(p + ".downsample.1", width * 4)
+            cin = width * 4
+    return sd
+
+
+def vit_state_dict(name_model="vit_base", patch=16, seed=11):
+    """fp32 numpy state dict with DINO ViT key names.  Biases / LN affine are
+    non-trivial on purpose so a missing bias add cannot pass parity."""
+    cfg = {"vit_tiny": (192, 12, 3), "vit_small": (384, 12, 6), "vit_base": (768, 12, 12)}[name_model]
+    dim, depth, _heads = cfg
+    g = _rng(seed)
+
+    def nrm(shape, std):
+        return (g.standard_normal(shape, dtype=np.float32) * np.float32(std))
+
+    sd = {
+        "cls_token": nrm((1, 1, dim), 0.02),
+        "pos_embed": nrm((1, 197, dim), 0.02),
+        "patch_embed.proj.weight": nrm((dim, 3, patch, patch), 0.02),
+        "patch_embed.proj.bias": nrm((dim,), 0.02),
+    }
+    for i in range(depth):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"] = g.uniform(0.5, 1.5, dim).astype(np.float32)
+        sd[p + "norm1.bias"] = nrm((dim,), 0.1)
+        sd[p + "attn.qkv.weight"] = nrm((3 * dim, dim), 0.05)
+        sd[p + "attn.qkv.bias"] = nrm((3 * dim,), 0.02)
+        sd[p + "attn.proj.weight"] = nrm((dim, dim), 0.02)
+        sd[p + "attn.proj.bias"] = nrm((dim,), 0.02)
+        sd[p + "norm2.weight"] = g.uniform(0.5, 1.5, dim).astype(np.float32)
+        sd[p + "norm2.bias"] = nrm((dim,), 0.1)
+        sd[p + "mlp.fc1.weight"] = nrm((4 * dim, dim), 0.02)
+        sd[p + "mlp.fc1.bias"] = nrm((4 * dim,), 0.02)
+        sd[p + "mlp.fc2.weight"] = nrm((dim, 4 * dim), 0.02)
+        sd[p + "mlp.fc2.bias"] = nrm((dim,), 0.02)
+    sd["norm.weight"] = g.uniform(0.5, 1.5, dim).astype(np.float32)
+    sd["norm.bias"] = nrm((dim,), 0.1)
+    return sd
+
+
+def synthetic_pair(height, width, seed, patch=16, max_amp=64):
+    """One (orig, next) pair, uint8 [H,W,3] BGR each.  next = clip(orig + noise)
+    with a per-16x16-patch noise amplitude in {0..max_amp}, so patch scores are
+    spread the way sparse motion spreads them."""
+    g = _rng(seed)
+    orig = g.integers(0, 256, (height, width, 3), dtype=np.uint8)
+    ph, pw = -(-height // patch), -(-width // patch)
+    amp = g.integers(0, max_amp + 1, (ph, pw), dtype=np.int16)
+    amp_px = np.repeat(np.repeat(amp, patch, axis=0), patch, axis=1)[:height, :width, None]
+    noise = g.integers(-max_amp, max_amp + 1, (height, width, 3), dtype=np.int16)
+    noise = np.sign(noise) * np.minimum(np.abs(noise), amp_px)
+    nxt = np.clip(orig.astype(np.int16) + noise, 0, 255).astype(np.uint8)
+    return orig, nxt
+
+
+def synthetic_clip(n_pairs, height, width, clip_id=0):
+    """uint8 [T,2,H,W,3]: frames[t,0]=sampled frame, frames[t,1]=the frame after
+    it (the pairing of src/video_frames_extract.py:51-69)."""
+    out = np.empty((n_pairs, 2, height, width, 3), dtype=np.uint8)
+    for t in range(n_pairs):
+        o, n = synthetic_pair(height, width, seed=1000 + clip_id * 4096 + t)
+        out[t, 0], out[t, 1] = o, n
+    return out
