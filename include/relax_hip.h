@@ -1,0 +1,164 @@
+/*
+ * relax_hip.h — C-ABI of librelax_hip.so, the MI355X (gfx950) engine for the
+ * ReLaX-VQA feature-extraction hot path.
+ *
+ * The reference (xinyiW915/ReLaX-VQA) has no FFI: its de-facto operator API for
+ * this path is a set of module-level Python functions that pass PNG paths and
+ * numpy arrays.  Each entry point below names the reference interface it
+ * replaces (file:line relative to the reference repo).  The Python host layer
+ * (relax-vqa_amd/) keeps those function names and binds this header through
+ * ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative relax_status otherwise;
+ *     relax_last_error() gives the message (Python raises RuntimeError).
+ *   - caller allocates: every in/out buffer is a DEVICE pointer (e.g.
+ *     torch.Tensor.data_ptr() under PyTorch-ROCm) unless the name says host.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All work
+ *     is enqueued on it; no hidden synchronisation.
+ *   - a handle owns only weights + workspace; it is NOT thread-safe; one handle
+ *     per (process, device).
+ *   - images are uint8 HWC **BGR** exactly as cv2.imread holds them
+ *     (src/main_fragment_layerstack.py:295-296); fragments are 224x224x3.
+ */
+#ifndef RELAX_HIP_H
+#define RELAX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RELAX_ABI_VERSION 1
+
+#define RELAX_PATCH 16           /* patch_size  (main_fragment_layerstack.py:298) */
+#define RELAX_TARGET 224         /* target_size (main_fragment_layerstack.py:297) */
+#define RELAX_TOP_N 196          /* top_n = (224/16)^2 (main_fragment_layerstack.py:299) */
+#define RELAX_FRAG_BYTES (224 * 224 * 3)
+#define RELAX_RN50_LAYER_STACK_DIM 13120 /* 64+3*256+4*512+4*1024+3*2048 */
+#define RELAX_RN50_POOL_DIM 2051         /* 2048 + mean,max,std */
+#define RELAX_RN50_NUM_TAPS 15
+
+typedef enum relax_status {
+    RELAX_OK = 0,
+    RELAX_ERR_INVALID = -1,   /* bad argument */
+    RELAX_ERR_HIP = -2,       /* a HIP runtime call failed */
+    RELAX_ERR_STATE = -3,     /* weights not loaded / workspace too small */
+    RELAX_ERR_NOMEM = -4
+} relax_status;
+
+typedef struct relax_handle relax_handle;
+typedef void* relax_stream;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int relax_abi_version(void);
+int relax_create(int device, relax_handle** out);
+int relax_destroy(relax_handle* h);
+/* message of the last failing call on this handle (h may be NULL: last create error) */
+const char* relax_last_error(const relax_handle* h);
+
+/* Size the activation workspace for batches of up to max_images fragments
+ * (ResNet-50 and ViT share one arena).  Called implicitly (growing) by the
+ * backbone entry points; call it up front to keep allocation out of timed code. */
+int relax_reserve(relax_handle* h, int max_images);
+
+/* ---- weights ------------------------------------------------------------------------------- */
+/* Replaces `models.resnet50(pretrained=True)` (src/extractor/visualise_resnet.py:21,
+ * visualise_resnet_layer.py:20).  names[i] are torchvision state-dict keys
+ * ("conv1.weight", "layer1.0.bn1.running_var", ...); tensors[i] are HOST fp32
+ * pointers in PyTorch layout (OIHW for convs); numels[i] their element counts.
+ * BatchNorm (eps 1e-5, eval) is folded into the following conv's weights/bias,
+ * except bn1 which is applied after the raw `conv1` tap. "fc.*" is ignored. */
+int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char* const* names,
+                        const int64_t* numels, int n);
+
+/* Replaces VitGenerator(name_model, patch_size=16, ...) + load_state_dict
+ * (src/extractor/visualise_vit_layer.py:263-329).  DINO state-dict keys
+ * ("cls_token", "blocks.0.attn.qkv.weight", ...).  dim/depth/heads: 768/12/12
+ * for vit_base (:287-289); head_dim must be 64, input is always 224x224 (197 tokens). */
+int relax_load_vit(relax_handle* h, const float* const* tensors, const char* const* names,
+                   const int64_t* numels, int n, int dim, int depth, int heads);
+
+/* ---- stage A: residual -> patch score -> top-n -> fragments (bit-exact integer path) -------- */
+/* Replaces, per (frame, next) pair: cv2.absdiff (main_fragment_layerstack.py:302),
+ * process_patches('frame_diff') = get_patch_diff + extract_important_patches (:232-240,
+ * :177-210) and get_original_frame_patches (:212-230).
+ *   orig, next : uint8 [H,W,3] per pair; pair t starts at orig + t*pair_stride (bytes)
+ *   positions  : int32 [T,196,2] (y,x) patch coordinates in raster order, (-1,-1) past counts[t]
+ *   counts     : int32 [T]  = min(top_n, (H/16)*(W/16))
+ *   ori_frag   : uint8 [T,224,224,3] patches of `orig`   (may be NULL)
+ *   diff_frag  : uint8 [T,224,224,3] patches of |next-orig| (may be NULL)
+ *   scores     : uint32 [T,(H/16)*(W/16)] patch sums (may be NULL -> internal scratch)
+ * Tie rule: higher score first, then lower flat patch index. */
+int relax_fragment_pairs(relax_handle* h, const uint8_t* orig, const uint8_t* next, int64_t pair_stride,
+                         int T, int H, int W, int top_n, int32_t* positions, int32_t* counts,
+                         uint8_t* ori_frag, uint8_t* diff_frag, uint32_t* scores, relax_stream stream);
+
+/* Same selection on an already-computed residual image (the optical-flow image of
+ * process_patches('optical_flow'), main_fragment_layerstack.py:319; main_residual_fragment.py:206-214).
+ *   image: uint8 [H,W,3] per item, item t at image + t*item_stride. */
+int relax_fragment_image(relax_handle* h, const uint8_t* image, int64_t item_stride, int T, int H, int W,
+                         int top_n, int32_t* positions, int32_t* counts, uint8_t* frag, uint32_t* scores,
+                         relax_stream stream);
+
+/* get_original_frame_patches (main_fragment_layerstack.py:212-230) with given positions. */
+int relax_gather_patches(relax_handle* h, const uint8_t* image, int64_t item_stride, int T, int H, int W,
+                         const int32_t* positions, const int32_t* counts, uint8_t* frag, relax_stream stream);
+
+/* merge_fragments = cv2.addWeighted(a,.5,b,.5,0) (main_fragment_layerstack.py:242-245):
+ * round-half-to-even(0.5a+0.5b) on uint8. n_bytes elements. */
+int relax_merge_fragments(relax_handle* h, const uint8_t* a, const uint8_t* b, uint8_t* out, int64_t n_bytes,
+                          relax_stream stream);
+
+/* ---- stage B: backbones ---------------------------------------------------------------------- */
+/* ResNet-50 on N fragments (uint8 [N,224,224,3] BGR).  One forward per image yields everything
+ * the reference gets from 15 hooked forwards + 1 avgpool forward:
+ *   layer_stack : fp32 [N,13120] = get_deep_feature(..,'layer_stack') + process_video_feature(..,'layer_stack')
+ *                 (main_fragment_layerstack.py:91-96,134-140; extractor/visualise_resnet.py:62-109)   (may be NULL)
+ *   pool        : fp32 [N,2051]  = get_deep_feature(..,'pool') + process_video_feature(..,'pool')
+ *                 (main_fragment_layerstack.py:97-99,141-149; extractor/visualise_resnet_layer.py:62-102) (may be NULL)
+ *   taps_nchw   : NULL, or RELAX_RN50_NUM_TAPS device pointers (each NULL or fp32 [N,C,H,W]) receiving the
+ *                 hooked activations themselves (visualise_resnet.process_video_frame's dict values). */
+int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float* layer_stack, float* pool,
+                            float* const* taps_nchw, relax_stream stream);
+
+/* ViT on N fragments.  tokens: fp32 [N,196,dim] final-norm patch tokens
+ * (visualise_vit_layer.process_video_frame, :447-500) (may be NULL);
+ * pooled: fp32 [N,3*dim] mean|max|std over tokens (main_fragment_pool.py:124-133) (may be NULL). */
+int relax_vit_features(relax_handle* h, const uint8_t* frags, int N, float* tokens, float* pooled,
+                       relax_stream stream);
+
+/* ---- operator level (what the backbones are built from; parity-tested one by one) ------------ */
+/* out[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + residual[M,N]);  act: 0 none, 1 relu, 2 gelu(erf).
+ * fp32 in, fp32 MFMA accumulate.  K % 32 == 0, N % 64 == 0.  bias/residual may be NULL. */
+int relax_op_gemm(relax_handle* h, const float* A, const float* W, const float* bias, const float* residual,
+                  float* out, int M, int N, int K, int act, relax_stream stream);
+/* NHWC conv as implicit GEMM: in [Nimg,H,W,Cin], w [Cout, KH*KW*Cin (padded to %32)] (k = (dy*KW+dx)*Cin+c),
+ * out [Nimg,Ho,Wo,Cout].  Cin a power of two >= 4 when KH*KW > 1. */
+int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const float* bias,
+                         const float* residual, float* out, int Nimg, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad, int act, relax_stream stream);
+/* rows of `dim` floats: y = (x-mean)/sqrt(var+eps)*gamma+beta */
+int relax_op_layernorm(relax_handle* h, const float* x, const float* gamma, const float* beta, float* y,
+                       int rows, int dim, float eps, relax_stream stream);
+/* qkv [Nimg*197, 3*heads*64] -> out [Nimg*197, heads*64]; softmax(q k^T / 8) v per (image, head) */
+int relax_op_attention(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, relax_stream stream);
+/* relu(x*scale[c]+shift[c]) then 3x3/s2/p1 max-pool: [Nimg,H,W,C] -> [Nimg,H/2,W/2,C] */
+int relax_op_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
+                             int Nimg, int H, int W, int C, relax_stream stream);
+/* spatial mean: x [Nimg,HW,C] -> out[n*out_stride + c] */
+int relax_op_gap(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,
+                 relax_stream stream);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* While enabled, every launch of the contraction kernel (GEMM / implicit-GEMM conv) and of the patch-score
+ * kernel is bracketed by HIP events on the caller's stream.  relax_profile_read synchronises those events and
+ * returns totals since the last enable: kind 0 = contraction (work = FLOPs), kind 1 = patch score (work = bytes). */
+int relax_profile_enable(relax_handle* h, int on);
+int relax_profile_read(relax_handle* h, int kind, double* total_ms, double* total_work, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELAX_HIP_H */

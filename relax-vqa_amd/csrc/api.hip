@@ -1,0 +1,200 @@
+// Handle lifetime, error reporting, workspace and event profiling of librelax_hip.so.
+#include <cstdarg>
+
+#include "relax_internal.h"
+
+namespace relax {
+
+static thread_local std::string g_create_error;
+
+void set_error(relax_handle* h, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->last_error = buf;
+    else g_create_error = buf;
+}
+
+int ensure_buf(relax_handle* h, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return RELAX_OK;
+    if (b.p) {
+        RELAX_HIP_CHECK(h, hipDeviceSynchronize());
+        RELAX_HIP_CHECK(h, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        set_error(h, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        b.p = nullptr;
+        return RELAX_ERR_NOMEM;
+    }
+    b.bytes = bytes;
+    return RELAX_OK;
+}
+
+int upload(relax_handle* h, const float* host, size_t n, float** dev, std::vector<void*>& allocs) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, n * sizeof(float));
+    if (e != hipSuccess) {
+        set_error(h, "hipMalloc(%zu floats) failed: %s", n, hipGetErrorString(e));
+        return RELAX_ERR_NOMEM;
+    }
+    allocs.push_back(p);
+    RELAX_HIP_CHECK(h, hipMemcpy(p, host, n * sizeof(float), hipMemcpyHostToDevice));
+    *dev = static_cast<float*>(p);
+    return RELAX_OK;
+}
+
+int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_idx) {
+    *span_idx = -1;
+    Profiler& p = h->prof;
+    if (!p.on) return RELAX_OK;
+    ProfSpan sp;
+    for (hipEvent_t* ev : {&sp.start, &sp.stop}) {
+        if (!p.pool.empty()) {
+            *ev = p.pool.back();
+            p.pool.pop_back();
+        } else {
+            RELAX_HIP_CHECK(h, hipEventCreate(ev));
+        }
+    }
+    sp.work = work;
+    sp.kind = kind;
+    RELAX_HIP_CHECK(h, hipEventRecord(sp.start, s));
+    p.spans.push_back(sp);
+    *span_idx = static_cast<int>(p.spans.size()) - 1;
+    return RELAX_OK;
+}
+
+int prof_end(relax_handle* h, hipStream_t s, int span_idx) {
+    if (span_idx < 0) return RELAX_OK;
+    RELAX_HIP_CHECK(h, hipEventRecord(h->prof.spans[span_idx].stop, s));
+    return RELAX_OK;
+}
+
+static int prof_drain(relax_handle* h) {
+    Profiler& p = h->prof;
+    for (ProfSpan& sp : p.spans) {
+        RELAX_HIP_CHECK(h, hipEventSynchronize(sp.stop));
+        float ms = 0.f;
+        RELAX_HIP_CHECK(h, hipEventElapsedTime(&ms, sp.start, sp.stop));
+        p.total_ms[sp.kind] += ms;
+        p.total_work[sp.kind] += sp.work;
+        p.launches[sp.kind] += 1;
+        p.pool.push_back(sp.start);
+        p.pool.push_back(sp.stop);
+    }
+    p.spans.clear();
+    return RELAX_OK;
+}
+
+}  // namespace relax
+
+using namespace relax;
+
+extern "C" {
+
+int relax_abi_version(void) { return RELAX_ABI_VERSION; }
+
+int relax_create(int device, relax_handle** out) {
+    if (!out) {
+        set_error(nullptr, "relax_create: out is NULL");
+        return RELAX_ERR_INVALID;
+    }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error(nullptr, "relax_create: no HIP device (%s)", hipGetErrorString(e));
+        return RELAX_ERR_HIP;
+    }
+    if (device < 0 || device >= count) {
+        set_error(nullptr, "relax_create: device %d out of range (have %d)", device, count);
+        return RELAX_ERR_INVALID;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        set_error(nullptr, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+        return RELAX_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        set_error(nullptr, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+        return RELAX_ERR_HIP;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(nullptr, "relax_create: device %d is %s; this library is built for gfx950 only", device,
+                  prop.gcnArchName);
+        return RELAX_ERR_HIP;
+    }
+    relax_handle* h = new relax_handle();
+    h->device = device;
+    *out = h;
+    return RELAX_OK;
+}
+
+int relax_destroy(relax_handle* h) {
+    if (!h) return RELAX_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    free_resnet(h);
+    free_vit(h);
+    if (h->arena.p) (void)hipFree(h->arena.p);
+    if (h->scratch.p) (void)hipFree(h->scratch.p);
+    for (auto& sp : h->prof.spans) {
+        (void)hipEventDestroy(sp.start);
+        (void)hipEventDestroy(sp.stop);
+    }
+    for (auto ev : h->prof.pool) (void)hipEventDestroy(ev);
+    delete h;
+    return RELAX_OK;
+}
+
+const char* relax_last_error(const relax_handle* h) {
+    return h ? h->last_error.c_str() : g_create_error.c_str();
+}
+
+int relax_reserve(relax_handle* h, int max_images) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, max_images > 0, "relax_reserve: max_images must be > 0");
+    if (max_images <= h->reserved_images) return RELAX_OK;
+    size_t need = resnet_arena_bytes(max_images);
+    if (h->vit.loaded) {
+        size_t v = vit_arena_bytes(h->vit, max_images);
+        if (v > need) need = v;
+    }
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    RELAX_TRY(ensure_buf(h, h->arena, need));
+    h->reserved_images = max_images;
+    return RELAX_OK;
+}
+
+int relax_profile_enable(relax_handle* h, int on) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_TRY(prof_drain(h));
+    h->prof.on = on != 0;
+    if (on) {
+        for (int k = 0; k < 2; ++k) {
+            h->prof.total_ms[k] = 0;
+            h->prof.total_work[k] = 0;
+            h->prof.launches[k] = 0;
+        }
+    }
+    return RELAX_OK;
+}
+
+int relax_profile_read(relax_handle* h, int kind, double* total_ms, double* total_work, int64_t* launches) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, kind == 0 || kind == 1, "relax_profile_read: kind must be 0 or 1");
+    RELAX_TRY(prof_drain(h));
+    if (total_ms) *total_ms = h->prof.total_ms[kind];
+    if (total_work) *total_work = h->prof.total_work[kind];
+    if (launches) *launches = h->prof.launches[kind];
+    return RELAX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,368 @@
+// The non-contraction kernels of the backbones: LayerNorm (wavefront reductions), fused
+// single-tile attention for 197 tokens x 64-d heads (fp32 MFMA, softmax in registers),
+// BN+ReLU+max-pool, deterministic global-average-pool, NHWC->NCHW tap export.
+#include "relax_internal.h"
+
+namespace relax {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- LayerNorm: one 64-lane wave per row, row held in registers (dim <= 768) ---------------------------
+__global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x, const float* __restrict__ g,
+                                                      const float* __restrict__ b, float* __restrict__ y, int rows,
+                                                      int dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;  // wave-uniform
+    const int nvec = dim >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * dim);
+    float4 v[3];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = i < nvec ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nvec) {
+            const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + eps);
+    float4* yr = reinterpret_cast<float4*>(y + (int64_t)row * dim);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nvec) {
+            const float4 gg = g4[i], bb = b4[i];
+            float4 o;
+            o.x = (v[j].x - mean) * rstd * gg.x + bb.x;
+            o.y = (v[j].y - mean) * rstd * gg.y + bb.y;
+            o.z = (v[j].z - mean) * rstd * gg.z + bb.z;
+            o.w = (v[j].w - mean) * rstd * gg.w + bb.w;
+            yr[i] = o;
+        }
+    }
+}
+
+int launch_layernorm(relax_handle* h, const float* x, const float* g, const float* b, float* y, int rows, int dim,
+                     float eps, hipStream_t s) {
+    RELAX_REQUIRE(h, dim % 4 == 0 && dim > 0 && dim <= 768, "layernorm: dim=%d must be a multiple of 4, <= 768", dim);
+    RELAX_REQUIRE(h, rows > 0, "layernorm: rows=%d", rows);
+    hipLaunchKernelGGL(layernorm_rows, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, dim, eps);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+// ---- attention: one workgroup per (image, head), 7 waves = 7 query tiles of 32 -----------------------------
+// S^T = K Q^T is computed with the KEY on the MFMA row (register) axis and the QUERY on the lane,
+// so each lane owns one query's scores: softmax is register-local plus one lane^32 exchange, and
+// the probabilities already sit in the A-operand layout of the P V product (no LDS round trip).
+constexpr int NTOK = 197;
+constexpr int KTILES = 7;         // 224 = 7 * 32 padded keys
+constexpr int KPAD = KTILES * 32;
+constexpr int KV_LD = 68;         // 64 + 4: conflict-free ds_read_b128 of K rows
+constexpr int ATT_THREADS = KTILES * 64;
+constexpr size_t ATT_LDS = sizeof(float) * (2 * KPAD * KV_LD + KTILES * 32);
+
+__global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __restrict__ qkv,
+                                                                 float* __restrict__ out, int heads) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = smem + KPAD * KV_LD;
+    float* rowsum = Vs + KPAD * KV_LD;
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x / heads, head = blockIdx.x % heads;
+    const int dim = heads * 64;
+    const int ld = 3 * dim;
+    const float* base = qkv + (int64_t)img * NTOK * ld + head * 64;
+
+    for (int idx = tid; idx < KPAD * 16; idx += ATT_THREADS) {
+        const int row = idx >> 4, c = idx & 15;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (row < NTOK) {
+            kv = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + dim + c * 4);
+            vv = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + 2 * dim + c * 4);
+        }
+        *reinterpret_cast<float4*>(Ks + row * KV_LD + c * 4) = kv;
+        *reinterpret_cast<float4*>(Vs + row * KV_LD + c * 4) = vv;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 31, half = lane >> 5;
+    const int qrow = wave * 32 + li;
+    const int qclamped = qrow < NTOK ? qrow : NTOK - 1;
+    const float* qp = base + (int64_t)qclamped * ld + 4 * half;
+    float4 qf[8];
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) {
+        float4 t = *reinterpret_cast<const float4*>(qp + 8 * q8);
+        qf[q8] = make_float4(t.x * 0.125f, t.y * 0.125f, t.z * 0.125f, t.w * 0.125f);  // head_dim^-0.5, exact
+    }
+
+    floatx16 sacc[KTILES];
+#pragma unroll
+    for (int kt = 0; kt < KTILES; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+        const float* kp = Ks + (kt * 32 + li) * KV_LD + 4 * half;
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) {
+            const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * q8);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[q8].x, sacc[kt], 0, 0, 0);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[q8].y, sacc[kt], 0, 0, 0);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[q8].z, sacc[kt], 0, 0, 0);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[q8].w, sacc[kt], 0, 0, 0);
+        }
+    }
+    // sacc[kt][r] = score(query li, key kt*32 + (r&3) + 8*(r>>2) + 4*half)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KTILES; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= NTOK) sacc[kt][r] = -INFINITY;
+            mx = fmaxf(mx, sacc[kt][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KTILES; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = expf(sacc[kt][r] - mx);
+            sacc[kt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32);
+    if (half == 0) rowsum[wave * 32 + li] = sum;
+    __syncthreads();
+
+    floatx16 oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < KTILES; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float v0 = Vs[key * KV_LD + li];
+            const float v1 = Vs[key * KV_LD + 32 + li];
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r], v0, oacc[0], 0, 0, 0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r], v1, oacc[1], 0, 0, 0);
+        }
+    // oacc[dt][r] = O(query wave*32 + (r&3)+8*(r>>2)+4*half, d = dt*32 + li)
+    float* ob = out + (int64_t)img * NTOK * dim + head * 64 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qt = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int q = wave * 32 + qt;
+        if (q < NTOK) {
+            const float inv = 1.0f / rowsum[wave * 32 + qt];
+            ob[(int64_t)q * dim] = oacc[0][r] * inv;
+            ob[(int64_t)q * dim + 32] = oacc[1][r] * inv;
+        }
+    }
+}
+
+int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s) {
+    RELAX_REQUIRE(h, Nimg > 0 && heads > 0, "attention: Nimg=%d heads=%d", Nimg, heads);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_197x64),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_197x64, dim3(Nimg * heads), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+// ---- relu(bn(x)) then 3x3 / stride 2 / pad 1 max-pool, NHWC, 4 channels per thread ---------------------------
+__global__ __launch_bounds__(256) void bn_relu_maxpool_nhwc(const float* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ y,
+                                                            int Nimg, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const int64_t total = (int64_t)Nimg * Ho * Wo * C4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    int64_t pix = i / C4;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const float4 sc = reinterpret_cast<const float4*>(scale)[c4];
+    const float4 sh = reinterpret_cast<const float4*>(shift)[c4];
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox * 2 - 1 + dx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const float4 v = reinterpret_cast<const float4*>(x + (((int64_t)n * H + iy) * W + ix) * C)[c4];
+            m.x = fmaxf(m.x, fmaxf(v.x * sc.x + sh.x, 0.f));
+            m.y = fmaxf(m.y, fmaxf(v.y * sc.y + sh.y, 0.f));
+            m.z = fmaxf(m.z, fmaxf(v.z * sc.z + sh.z, 0.f));
+            m.w = fmaxf(m.w, fmaxf(v.w * sc.w + sh.w, 0.f));
+        }
+    }
+    reinterpret_cast<float4*>(y + (((int64_t)n * Ho + oy) * Wo + ox) * C)[c4] = m;
+}
+
+int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
+                           int Nimg, int H, int W, int C, hipStream_t s) {
+    RELAX_REQUIRE(h, Nimg > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "bn_relu_maxpool: bad shape");
+    const int64_t total = (int64_t)Nimg * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, y,
+                       Nimg, H, W, C);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+// ---- global average pool, deterministic two-stage ---------------------------------------------------------------
+// stage 1: grid (C/64, Nimg, S); a workgroup owns 64 channels of one image and 1/S of the pixels;
+//          16 lanes x float4 cover the channels (256 B coalesced), 16 lane-groups stride the pixels;
+//          fixed-order LDS reduction -> partial[n][s][c].
+// stage 2: sums the S partials in order and divides by HW.
+__global__ __launch_bounds__(256) void gap_partial(const float* __restrict__ x, float* __restrict__ partial, int HW,
+                                                   int C, int S) {
+    __shared__ float4 red[256];
+    const int cc = blockIdx.x, n = blockIdx.y, sp = blockIdx.z;
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int per = (HW + S - 1) / S;
+    const int lo = sp * per;
+    const int hi = lo + per < HW ? lo + per : HW;
+    const float* xb = x + (int64_t)n * HW * C + cc * 64 + l16 * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = lo + grp; p < hi; p += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)p * C);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float4 t = red[threadIdx.x];
+        for (int g = 1; g < 16; ++g) {
+            const float4 u = red[g * 16 + threadIdx.x];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        reinterpret_cast<float4*>(partial + ((int64_t)n * S + sp) * C + cc * 64)[threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void gap_finish(const float* __restrict__ partial, float* __restrict__ out, int Nimg,
+                                                  int HW, int C, int S, int64_t out_stride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Nimg * C) return;
+    const int n = (int)(i / C), c = (int)(i % C);
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += partial[((int64_t)n * S + s) * C + c];
+    out[(int64_t)n * out_stride + c] = t / (float)HW;
+}
+
+constexpr int GAP_MAX_SPLIT = 16;
+
+int launch_gap_ws(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,
+                  float* partial_ws, hipStream_t s) {
+    RELAX_REQUIRE(h, C % 64 == 0 && HW > 0 && Nimg > 0, "gap: bad shape HW=%d C=%d", HW, C);
+    const int blocks = (C / 64) * Nimg;
+    int S = (1024 + blocks - 1) / blocks;
+    if (S > GAP_MAX_SPLIT) S = GAP_MAX_SPLIT;
+    if (S > (HW + 15) / 16) S = (HW + 15) / 16;
+    if (S < 1) S = 1;
+    hipLaunchKernelGGL(gap_partial, dim3(C / 64, Nimg, S), dim3(256), 0, s, x, partial_ws, HW, C, S);
+    hipLaunchKernelGGL(gap_finish, dim3((unsigned)(((int64_t)Nimg * C + 255) / 256)), dim3(256), 0, s, partial_ws, out,
+                       Nimg, HW, C, S, out_stride);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+int launch_gap(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,
+               hipStream_t s) {
+    // stand-alone form: partial sums live in the stage-A scratch buffer
+    RELAX_TRY(ensure_buf(h, h->scratch, sizeof(float) * (size_t)Nimg * GAP_MAX_SPLIT * C));
+    return launch_gap_ws(h, x, out, Nimg, HW, C, out_stride, static_cast<float*>(h->scratch.p), s);
+}
+
+// ---- [N,HW,C] -> [N,C,HW] (tap export for the process_video_frame dict) -----------------------------------------
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int HW,
+                                                           int C) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        if (p < HW && c < C) tile[j][tx] = x[((int64_t)n * HW + p) * C + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        if (p < HW && c < C) y[((int64_t)n * C + c) * HW + p] = tile[tx][j];
+    }
+}
+
+int launch_nhwc_to_nchw(relax_handle* h, const float* x, float* y, int Nimg, int HW, int C, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, Nimg), dim3(256), 0, s, x, y, HW, C);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+}  // namespace relax
+
+using namespace relax;
+
+extern "C" {
+
+int relax_op_layernorm(relax_handle* h, const float* x, const float* gamma, const float* beta, float* y, int rows,
+                       int dim, float eps, relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, x && gamma && beta && y, "relax_op_layernorm: NULL operand");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    return launch_layernorm(h, x, gamma, beta, y, rows, dim, eps, static_cast<hipStream_t>(stream));
+}
+
+int relax_op_attention(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, qkv && out, "relax_op_attention: NULL operand");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    return launch_attention(h, qkv, out, Nimg, heads, static_cast<hipStream_t>(stream));
+}
+
+int relax_op_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
+                             int Nimg, int H, int W, int C, relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, x && scale && shift && y, "relax_op_bn_relu_maxpool: NULL operand");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    return launch_bn_relu_maxpool(h, x, scale, shift, y, Nimg, H, W, C, static_cast<hipStream_t>(stream));
+}
+
+int relax_op_gap(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,
+                 relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, x && out, "relax_op_gap: NULL operand");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    return launch_gap(h, x, out, Nimg, HW, C, out_stride, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

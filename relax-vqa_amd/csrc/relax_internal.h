@@ -1,0 +1,174 @@
+// Internal declarations shared by the translation units of librelax_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "relax_hip.h"
+
+namespace relax {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(relax_handle* h, const char* fmt, ...);
+
+#define RELAX_HIP_CHECK(h, expr)                                                             \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            relax::set_error((h), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RELAX_ERR_HIP;                                                            \
+        }                                                                                    \
+    } while (0)
+
+#define RELAX_REQUIRE(h, cond, ...)                                                          \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            relax::set_error((h), __VA_ARGS__);                                              \
+            return RELAX_ERR_INVALID;                                                        \
+        }                                                                                    \
+    } while (0)
+
+#define RELAX_TRY(expr)                                                                      \
+    do {                                                                                     \
+        int rc_ = (expr);                                                                    \
+        if (rc_ != RELAX_OK) return rc_;                                                     \
+    } while (0)
+
+// ---- device buffers -------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+// ---- contraction kernel description -----------------------------------------------------------
+struct ConvDesc {
+    // A operand: NHWC activation, gathered on the fly (implicit GEMM)
+    const float* in;
+    int Nimg, H, W, Cin;
+    int Ho, Wo;
+    int KH, KW, stride, pad;
+    // B operand: weights [Cout][Kpad], k = (dy*KW+dx)*Cin + c, zero padded to Kpad (% 32 == 0)
+    const float* w;
+    int Cout, Kpad;
+    // epilogue
+    const float* bias;      // [Cout] or null
+    const float* residual;  // [M, Cout] or null
+    float* out;             // [M, Cout]
+    int act;                // 0 none, 1 relu, 2 gelu(erf)
+    double flops;           // algorithmic FLOPs for the profiler (0 = 2*M*N*KH*KW*Cin)
+};
+
+// ---- model weights ------------------------------------------------------------------------------
+struct ConvW {          // one folded conv (+BN) of ResNet-50
+    float* w = nullptr;     // device [Cout][Kpad]
+    float* bias = nullptr;  // device [Cout] (null for the raw conv1)
+    int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, Kpad = 0;
+};
+
+struct Bottleneck {
+    ConvW c1, c2, c3, down;
+    bool has_down = false;
+    int tap = -1;  // layer-stack tap index, -1 if not tapped
+};
+
+struct ResNet50W {
+    bool loaded = false;
+    ConvW conv1;                 // Cin padded 3 -> 4, K 196 -> 224, no bias (raw tap precedes bn1)
+    float* bn1_scale = nullptr;  // [64]
+    float* bn1_shift = nullptr;  // [64]
+    std::vector<Bottleneck> blocks;  // 16
+    std::vector<void*> allocs;
+};
+
+struct LinearW {
+    float* w = nullptr;  // device [out][in]
+    float* b = nullptr;  // device [out]
+    int in = 0, out = 0;
+};
+
+struct VitBlockW {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    LinearW qkv, proj, fc1, fc2;
+};
+
+struct VitW {
+    bool loaded = false;
+    int dim = 0, depth = 0, heads = 0;
+    float* cls = nullptr;   // [dim]
+    float* pos = nullptr;   // [197][dim]
+    LinearW patch;          // [dim][3*16*16], k = c*256 + py*16 + px (c in RGB order)
+    std::vector<VitBlockW> blocks;
+    float *norm_g = nullptr, *norm_b = nullptr;
+    std::vector<void*> allocs;
+};
+
+// ---- event profiling ----------------------------------------------------------------------------
+struct ProfSpan {
+    hipEvent_t start, stop;
+    double work;
+    int kind;
+};
+
+struct Profiler {
+    bool on = false;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> pool;
+    double total_ms[2] = {0, 0};
+    double total_work[2] = {0, 0};
+    int64_t launches[2] = {0, 0};
+};
+
+}  // namespace relax
+
+struct relax_handle {
+    int device = 0;
+    std::string last_error;
+    relax::DevBuf arena;        // activation workspace shared by both backbones
+    int reserved_images = 0;
+    relax::DevBuf scratch;      // stage-A scratch (scores)
+    relax::ResNet50W rn;
+    relax::VitW vit;
+    relax::Profiler prof;
+};
+
+namespace relax {
+
+int ensure_buf(relax_handle* h, DevBuf& b, size_t bytes);
+int upload(relax_handle* h, const float* host, size_t n, float** dev, std::vector<void*>& allocs);
+
+// profiling helpers: call around a launch; no-ops when profiling is off
+int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_idx);
+int prof_end(relax_handle* h, hipStream_t s, int span_idx);
+
+// contraction kernel launcher (gemm.hip)
+int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s);
+inline int launch_gemm(relax_handle* h, const float* A, const float* W, const float* bias, const float* residual,
+                       float* out, int M, int N, int K, int act, hipStream_t s) {
+    ConvDesc d{};
+    d.in = A; d.Nimg = 1; d.H = 1; d.W = M; d.Cin = K; d.Ho = 1; d.Wo = M;
+    d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+    d.w = W; d.Cout = N; d.Kpad = K; d.bias = bias; d.residual = residual; d.out = out; d.act = act;
+    return launch_conv(h, d, s);
+}
+
+// small kernels (layers.hip)
+int launch_layernorm(relax_handle* h, const float* x, const float* g, const float* b, float* y, int rows, int dim,
+                     float eps, hipStream_t s);
+int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s);
+int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
+                           int Nimg, int H, int W, int C, hipStream_t s);
+int launch_gap(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,
+               hipStream_t s);
+int launch_nhwc_to_nchw(relax_handle* h, const float* x, float* y, int Nimg, int HW, int C, hipStream_t s);
+
+// model drivers
+void free_resnet(relax_handle* h);
+void free_vit(relax_handle* h);
+size_t resnet_arena_bytes(int n_images);
+size_t vit_arena_bytes(const VitW& v, int n_images);
+
+}  // namespace relax

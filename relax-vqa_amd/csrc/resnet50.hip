@@ -1,0 +1,308 @@
+// ResNet-50 (torchvision v1.5 layout) feature extractor on gfx950: one forward per fragment yields the
+// 15 layer-stack taps' spatial means (13120-d) and the avgpool vector + stats (2051-d).
+//
+// Reference semantics (file:line in xinyiW915/ReLaX-VQA):
+//   src/extractor/visualise_resnet.py:40-50      preprocess: PNG(BGR->RGB), ToTensor (/255), Normalize(mean,std)
+//   src/extractor/visualise_resnet.py:21,83-106  resnet50, one hooked forward per tap
+//   src/main_fragment_layerstack.py:91-99        tap list; 'resnet50.conv1' is the RAW conv output (before bn1)
+//   src/main_fragment_layerstack.py:134-149      spatial mean per tap / avgpool + (mean,max,std)
+// Layout: activations NHWC fp32 (channel = GEMM N axis, contiguous), weights [Cout][KH*KW*Cin] with
+// eval-mode BatchNorm folded in (scale into the weights, shift as bias); bn1 stays separate because
+// the conv1 tap is taken before it.
+#include <cmath>
+
+#include "relax_internal.h"
+
+namespace relax {
+
+int launch_gap_ws(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,
+                  float* partial_ws, hipStream_t s);
+
+static const int kTapChannels[RELAX_RN50_NUM_TAPS] = {64, 256, 256, 256, 512, 512, 512, 512,
+                                                      1024, 1024, 1024, 1024, 2048, 2048, 2048};
+static const int kTapHW[RELAX_RN50_NUM_TAPS] = {112, 56, 56, 56, 28, 28, 28, 28, 14, 14, 14, 14, 7, 7, 7};
+
+// ---- kernels ---------------------------------------------------------------------------------------
+// uint8 BGR [N,224,224,3] -> fp32 NHWC4 RGB0, ((x/255) - mean) / std   (ToTensor + Normalize)
+__global__ __launch_bounds__(256) void rn_preprocess(const uint8_t* __restrict__ frag, float* __restrict__ x,
+                                                     int64_t npix) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint8_t* p = frag + i * 3;
+    const float b = (float)p[0] / 255.0f, g = (float)p[1] / 255.0f, r = (float)p[2] / 255.0f;
+    float4 o;
+    o.x = (r - 0.485f) / 0.229f;
+    o.y = (g - 0.456f) / 0.224f;
+    o.z = (b - 0.406f) / 0.225f;
+    o.w = 0.f;
+    reinterpret_cast<float4*>(x)[i] = o;
+}
+
+// avgpool vector v[2048] -> out[0:2048] = v, out[2048..2050] = mean, max, population std
+__global__ __launch_bounds__(256) void rn_pool_stats(const float* __restrict__ avg, int64_t avg_stride,
+                                                     float* __restrict__ out) {
+    __shared__ float red[256];
+    __shared__ float s_mean;
+    const int n = blockIdx.x, t = threadIdx.x;
+    const float* v = avg + (int64_t)n * avg_stride;
+    float* o = out + (int64_t)n * RELAX_RN50_POOL_DIM;
+    float vals[8];
+    float s = 0.f, m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        vals[j] = v[t + 256 * j];
+        o[t + 256 * j] = vals[j];
+        s += vals[j];
+        m = fmaxf(m, vals[j]);
+    }
+    red[t] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) s_mean = red[0] / 2048.0f;
+    __syncthreads();
+    const float mean = s_mean;
+    __syncthreads();
+    red[t] = m;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (t < w) red[t] = fmaxf(red[t], red[t + w]);
+        __syncthreads();
+    }
+    const float mx = red[0];
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q += (vals[j] - mean) * (vals[j] - mean);
+    red[t] = q;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) {
+        o[2048] = mean;
+        o[2049] = mx;
+        o[2050] = sqrtf(red[0] / 2048.0f);
+    }
+}
+
+// ---- weights ---------------------------------------------------------------------------------------
+struct HostSD {
+    std::map<std::string, std::pair<const float*, int64_t>> t;
+    const float* get(relax_handle* h, const std::string& k, int64_t numel) const {
+        auto it = t.find(k);
+        if (it == t.end()) {
+            set_error(h, "state dict: missing key '%s'", k.c_str());
+            return nullptr;
+        }
+        if (it->second.second != numel) {
+            set_error(h, "state dict: key '%s' has %lld elements, expected %lld", k.c_str(),
+                      (long long)it->second.second, (long long)numel);
+            return nullptr;
+        }
+        return it->second.first;
+    }
+};
+
+static constexpr float kBnEps = 1e-5f;
+
+// conv (OIHW) [+ BN] -> device [Cout][Kpad] (+ bias).  cin_pad >= cin (conv1: 3 -> 4).
+static int make_conv(relax_handle* h, const HostSD& sd, const std::string& conv, const std::string& bn, int cout,
+                     int cin, int cin_pad, int k, int stride, int pad, ConvW* out, std::vector<void*>& allocs) {
+    const float* w = sd.get(h, conv + ".weight", (int64_t)cout * cin * k * k);
+    if (!w) return RELAX_ERR_INVALID;
+    std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
+    if (!bn.empty()) {
+        const float* g = sd.get(h, bn + ".weight", cout);
+        const float* b = sd.get(h, bn + ".bias", cout);
+        const float* mu = sd.get(h, bn + ".running_mean", cout);
+        const float* var = sd.get(h, bn + ".running_var", cout);
+        if (!g || !b || !mu || !var) return RELAX_ERR_INVALID;
+        for (int o = 0; o < cout; ++o) {
+            scale[o] = g[o] / std::sqrt(var[o] + kBnEps);
+            shift[o] = b[o] - mu[o] * scale[o];
+        }
+    }
+    const int kreal = k * k * cin_pad;
+    const int kpad = ((kreal + 31) / 32) * 32;
+    std::vector<float> packed((size_t)cout * kpad, 0.f);
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+            for (int dy = 0; dy < k; ++dy)
+                for (int dx = 0; dx < k; ++dx)
+                    packed[(size_t)o * kpad + (size_t)(dy * k + dx) * cin_pad + c] =
+                        w[(((size_t)o * cin + c) * k + dy) * k + dx] * scale[o];
+    out->Cin = cin_pad; out->Cout = cout; out->KH = k; out->KW = k; out->stride = stride; out->pad = pad;
+    out->Kpad = kpad;
+    RELAX_TRY(upload(h, packed.data(), packed.size(), &out->w, allocs));
+    if (!bn.empty()) RELAX_TRY(upload(h, shift.data(), shift.size(), &out->bias, allocs));
+    else out->bias = nullptr;
+    return RELAX_OK;
+}
+
+void free_resnet(relax_handle* h) {
+    for (void* p : h->rn.allocs) (void)hipFree(p);
+    h->rn = ResNet50W();
+}
+
+// floats per image of the activation arena (see relax_resnet50_features)
+static constexpr size_t kX0 = 224 * 224 * 4;        // preprocessed input, NHWC4
+static constexpr size_t kBig = 112 * 112 * 64;      // == 56*56*256: largest block in/out and conv1 raw
+static constexpr size_t kT1 = 56 * 56 * 128;        // largest conv1-of-block output (layer2.0 before the stride)
+static constexpr size_t kT2 = 56 * 56 * 64;         // largest conv2 output
+static constexpr size_t kGapWs = 16 * 2048;         // GAP partial sums
+static constexpr size_t kAvg = 2048;
+static constexpr size_t kRnFloatsPerImage = kX0 + 3 * kBig + kT1 + kT2 + kGapWs + kAvg;
+
+size_t resnet_arena_bytes(int n) { return sizeof(float) * kRnFloatsPerImage * (size_t)n; }
+
+static int run_conv(relax_handle* h, const ConvW& c, const float* in, int Nimg, int H, int W, const float* residual,
+                    float* out, int act, hipStream_t s, double flops = 0) {
+    ConvDesc d{};
+    d.in = in; d.Nimg = Nimg; d.H = H; d.W = W; d.Cin = c.Cin;
+    d.Ho = (H + 2 * c.pad - c.KH) / c.stride + 1;
+    d.Wo = (W + 2 * c.pad - c.KW) / c.stride + 1;
+    d.KH = c.KH; d.KW = c.KW; d.stride = c.stride; d.pad = c.pad;
+    d.w = c.w; d.Cout = c.Cout; d.Kpad = c.Kpad;
+    d.bias = c.bias; d.residual = residual; d.out = out; d.act = act; d.flops = flops;
+    return launch_conv(h, d, s);
+}
+
+}  // namespace relax
+
+using namespace relax;
+
+extern "C" {
+
+int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char* const* names,
+                        const int64_t* numels, int n) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, tensors && names && numels && n > 0, "relax_load_resnet50: bad arguments");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    free_resnet(h);
+    HostSD sd;
+    for (int i = 0; i < n; ++i) sd.t[names[i]] = {tensors[i], numels[i]};
+    ResNet50W& rn = h->rn;
+    int rc = make_conv(h, sd, "conv1", "", 64, 3, 4, 7, 2, 3, &rn.conv1, rn.allocs);
+    if (rc != RELAX_OK) { free_resnet(h); return rc; }
+    {
+        const float* g = sd.get(h, "bn1.weight", 64);
+        const float* b = sd.get(h, "bn1.bias", 64);
+        const float* mu = sd.get(h, "bn1.running_mean", 64);
+        const float* var = sd.get(h, "bn1.running_var", 64);
+        if (!g || !b || !mu || !var) { free_resnet(h); return RELAX_ERR_INVALID; }
+        std::vector<float> sc(64), sh(64);
+        for (int o = 0; o < 64; ++o) {
+            sc[o] = g[o] / std::sqrt(var[o] + kBnEps);
+            sh[o] = b[o] - mu[o] * sc[o];
+        }
+        rc = upload(h, sc.data(), 64, &rn.bn1_scale, rn.allocs);
+        if (rc == RELAX_OK) rc = upload(h, sh.data(), 64, &rn.bn1_shift, rn.allocs);
+        if (rc != RELAX_OK) { free_resnet(h); return rc; }
+    }
+    const int stage_blocks[4] = {3, 4, 6, 3};
+    const int stage_width[4] = {64, 128, 256, 512};
+    const int stage_taps[4] = {3, 4, 4, 3};  // layer3 blocks 4,5 are not tapped
+    int cin = 64, tap = 1;
+    for (int st = 0; st < 4; ++st) {
+        for (int b = 0; b < stage_blocks[st]; ++b) {
+            Bottleneck blk;
+            const int width = stage_width[st];
+            const int stride = (b == 0 && st > 0) ? 2 : 1;
+            char pfx[64];
+            snprintf(pfx, sizeof(pfx), "layer%d.%d", st + 1, b);
+            const std::string p(pfx);
+            rc = make_conv(h, sd, p + ".conv1", p + ".bn1", width, cin, cin, 1, 1, 0, &blk.c1, rn.allocs);
+            if (rc == RELAX_OK)
+                rc = make_conv(h, sd, p + ".conv2", p + ".bn2", width, width, width, 3, stride, 1, &blk.c2, rn.allocs);
+            if (rc == RELAX_OK)
+                rc = make_conv(h, sd, p + ".conv3", p + ".bn3", width * 4, width, width, 1, 1, 0, &blk.c3, rn.allocs);
+            blk.has_down = (b == 0);
+            if (rc == RELAX_OK && blk.has_down)
+                rc = make_conv(h, sd, p + ".downsample.0", p + ".downsample.1", width * 4, cin, cin, 1, stride, 0,
+                               &blk.down, rn.allocs);
+            if (rc != RELAX_OK) { free_resnet(h); return rc; }
+            blk.tap = b < stage_taps[st] ? tap++ : -1;
+            rn.blocks.push_back(blk);
+            cin = width * 4;
+        }
+    }
+    rn.loaded = true;
+    return RELAX_OK;
+}
+
+int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float* layer_stack, float* pool,
+                            float* const* taps_nchw, relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, h->rn.loaded, "relax_resnet50_features: call relax_load_resnet50 first");
+    RELAX_REQUIRE(h, frags && N > 0, "relax_resnet50_features: bad arguments");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    RELAX_TRY(ensure_buf(h, h->arena, resnet_arena_bytes(N)));
+    float* base = static_cast<float*>(h->arena.p);
+    const size_t n = (size_t)N;
+    float* X0 = base;
+    float* bufA = X0 + kX0 * n;
+    float* bufB = bufA + kBig * n;
+    float* bufD = bufB + kBig * n;
+    float* T1 = bufD + kBig * n;
+    float* T2 = T1 + kT1 * n;
+    float* gapws = T2 + kT2 * n;
+    float* avg = gapws + kGapWs * n;
+    const ResNet50W& rn = h->rn;
+
+    auto emit_tap = [&](int tap, const float* act) -> int {
+        const int C = kTapChannels[tap], HW = kTapHW[tap] * kTapHW[tap];
+        int off = 0;
+        for (int t = 0; t < tap; ++t) off += kTapChannels[t];
+        if (layer_stack)
+            RELAX_TRY(launch_gap_ws(h, act, layer_stack + off, N, HW, C, RELAX_RN50_LAYER_STACK_DIM, gapws, s));
+        if (taps_nchw && taps_nchw[tap]) RELAX_TRY(launch_nhwc_to_nchw(h, act, taps_nchw[tap], N, HW, C, s));
+        return RELAX_OK;
+    };
+
+    const int64_t npix = (int64_t)N * 224 * 224;
+    hipLaunchKernelGGL(rn_preprocess, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, frags, X0, npix);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    // conv1 7x7/2 (raw), algorithmic FLOPs use the real 3 input channels
+    RELAX_TRY(run_conv(h, rn.conv1, X0, N, 224, 224, nullptr, bufA, 0, s, 2.0 * N * 112.0 * 112.0 * 64.0 * 147.0));
+    RELAX_TRY(emit_tap(0, bufA));
+    RELAX_TRY(launch_bn_relu_maxpool(h, bufA, rn.bn1_scale, rn.bn1_shift, bufB, N, 112, 112, 64, s));
+    float* cur = bufB;
+    float* other = bufA;
+    int H = 56;
+    for (const Bottleneck& blk : rn.blocks) {
+        const int Ho = H / blk.c2.stride;
+        RELAX_TRY(run_conv(h, blk.c1, cur, N, H, H, nullptr, T1, 1, s));
+        RELAX_TRY(run_conv(h, blk.c2, T1, N, H, H, nullptr, T2, 1, s));
+        const float* identity = cur;
+        if (blk.has_down) {
+            RELAX_TRY(run_conv(h, blk.down, cur, N, H, H, nullptr, bufD, 0, s));
+            identity = bufD;
+        }
+        RELAX_TRY(run_conv(h, blk.c3, T2, N, Ho, Ho, identity, other, 1, s));
+        float* t = cur; cur = other; other = t;
+        H = Ho;
+        if (blk.tap >= 0) RELAX_TRY(emit_tap(blk.tap, cur));
+    }
+    if (pool) {
+        const float* avg_src;
+        int64_t avg_stride;
+        if (layer_stack) {
+            avg_src = layer_stack + (RELAX_RN50_LAYER_STACK_DIM - 2048);
+            avg_stride = RELAX_RN50_LAYER_STACK_DIM;
+        } else {
+            RELAX_TRY(launch_gap_ws(h, cur, avg, N, 49, 2048, 2048, gapws, s));
+            avg_src = avg;
+            avg_stride = 2048;
+        }
+        hipLaunchKernelGGL(rn_pool_stats, dim3(N), dim3(256), 0, s, avg_src, avg_stride, pool);
+        RELAX_HIP_CHECK(h, hipGetLastError());
+    }
+    return RELAX_OK;
+}
+
+}  // extern "C"

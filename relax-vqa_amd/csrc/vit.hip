@@ -1,0 +1,229 @@
+// DINO ViT (patch 16, 224x224 input -> 197 tokens, 64-d heads) feature extractor on gfx950.
+//
+// Reference semantics (file:line in xinyiW915/ReLaX-VQA, src/extractor/visualise_vit_layer.py):
+//   :466-470,339-342,492-494  input: PIL RGB, /255, no mean/std normalisation
+//   :132-149  PatchEmbed conv 16x16/16            -> patchify kernel + GEMM (K = 3*16*16 = 768)
+//   :221-232  cls token prepend, + pos_embed       -> vit_assemble
+//   :93-129   pre-LN blocks: qkv, softmax(q k^T/8) v, proj, MLP with exact-erf GELU
+//   :234-239  final LayerNorm (eps 1e-6, :287-289), patch tokens x[:,1:]
+//   src/main_fragment_pool.py:124-133  mean / max / population-std over the 196 tokens
+#include "relax_internal.h"
+
+namespace relax {
+
+constexpr int NTOK = 197;
+constexpr int NPATCH = 196;
+constexpr int PATCH_K = 3 * 16 * 16;
+constexpr float kLnEps = 1e-6f;
+
+// uint8 BGR [N,224,224,3] -> fp32 [N*196, 768], k = c*256 + py*16 + px with c in RGB order, value/255
+__global__ __launch_bounds__(256) void vit_patchify(const uint8_t* __restrict__ frag, float* __restrict__ P,
+                                                    int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % PATCH_K);
+    const int64_t row = i / PATCH_K;
+    const int p = (int)(row % NPATCH);
+    const int64_t n = row / NPATCH;
+    const int c = k >> 8, py = (k >> 4) & 15, px = k & 15;
+    const int y = (p / 14) * 16 + py, x = (p % 14) * 16 + px;
+    P[i] = (float)frag[((n * 224 + y) * 224 + x) * 3 + (2 - c)] / 255.0f;
+}
+
+// X[n,0,:] = cls + pos[0];  X[n,1+p,:] = PE[n*196+p,:] + pos[1+p]
+__global__ __launch_bounds__(256) void vit_assemble(const float* __restrict__ PE, const float* __restrict__ cls,
+                                                    const float* __restrict__ pos, float* __restrict__ X, int dim4,
+                                                    int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int d = (int)(i % dim4);
+    const int64_t row = i / dim4;
+    const int tok = (int)(row % NTOK);
+    const int64_t n = row / NTOK;
+    const float4 pp = reinterpret_cast<const float4*>(pos)[(int64_t)tok * dim4 + d];
+    const float4 v = tok == 0 ? reinterpret_cast<const float4*>(cls)[d]
+                              : reinterpret_cast<const float4*>(PE)[(n * NPATCH + (tok - 1)) * dim4 + d];
+    reinterpret_cast<float4*>(X)[i] = make_float4(v.x + pp.x, v.y + pp.y, v.z + pp.z, v.w + pp.w);
+}
+
+// Y [N,197,dim] -> tokens [N,196,dim] (drop cls)
+__global__ __launch_bounds__(256) void vit_drop_cls(const float* __restrict__ Y, float* __restrict__ T, int dim4,
+                                                    int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int d = (int)(i % dim4);
+    const int64_t row = i / dim4;
+    const int p = (int)(row % NPATCH);
+    const int64_t n = row / NPATCH;
+    reinterpret_cast<float4*>(T)[i] = reinterpret_cast<const float4*>(Y)[(n * NTOK + 1 + p) * dim4 + d];
+}
+
+// per (image, channel): mean, max, population std over tokens 1..196 -> out[n, 0:dim | dim:2dim | 2dim:3dim]
+__global__ __launch_bounds__(256) void vit_token_stats(const float* __restrict__ Y, float* __restrict__ out, int dim) {
+    __shared__ float red[4][64];
+    __shared__ float s_mean[64];
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int grp = threadIdx.x >> 6;  // 4 groups stride the tokens
+    const float* yb = Y + ((int64_t)n * NTOK + 1) * dim + c;
+    float s = 0.f, m = -INFINITY;
+    for (int p = grp; p < NPATCH; p += 4) {
+        const float v = yb[(int64_t)p * dim];
+        s += v;
+        m = fmaxf(m, v);
+    }
+    red[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0) s_mean[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)NPATCH;
+    __syncthreads();
+    const float mean = s_mean[threadIdx.x & 63];
+    __syncthreads();
+    red[grp][threadIdx.x & 63] = m;
+    __syncthreads();
+    float mx = 0.f;
+    if (grp == 0) mx = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+    __syncthreads();
+    float q = 0.f;
+    for (int p = grp; p < NPATCH; p += 4) {
+        const float dv = yb[(int64_t)p * dim] - mean;
+        q += dv * dv;
+    }
+    red[grp][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (grp == 0) {
+        const float var = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)NPATCH;
+        float* o = out + (int64_t)n * 3 * dim;
+        o[c] = mean;
+        o[dim + c] = mx;
+        o[2 * dim + c] = sqrtf(var);
+    }
+}
+
+void free_vit(relax_handle* h) {
+    for (void* p : h->vit.allocs) (void)hipFree(p);
+    h->vit = VitW();
+}
+
+static size_t vit_floats_per_image(int dim) {
+    return (size_t)NPATCH * PATCH_K        // P   patches
+           + (size_t)NPATCH * dim          // PE  patch-embed output
+           + (size_t)NTOK * dim * 2        // X, Y
+           + (size_t)NTOK * dim * 3        // QKV
+           + (size_t)NTOK * dim * 4;       // Hid
+}
+
+size_t vit_arena_bytes(const VitW& v, int n) { return sizeof(float) * vit_floats_per_image(v.dim) * (size_t)n; }
+
+}  // namespace relax
+
+using namespace relax;
+
+extern "C" {
+
+int relax_load_vit(relax_handle* h, const float* const* tensors, const char* const* names, const int64_t* numels,
+                   int n, int dim, int depth, int heads) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, tensors && names && numels && n > 0, "relax_load_vit: bad arguments");
+    RELAX_REQUIRE(h, heads > 0 && dim == heads * 64, "relax_load_vit: dim=%d must be heads*64 (heads=%d)", dim, heads);
+    RELAX_REQUIRE(h, dim <= 768 && depth > 0, "relax_load_vit: dim=%d depth=%d unsupported", dim, depth);
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    free_vit(h);
+    std::map<std::string, std::pair<const float*, int64_t>> sd;
+    for (int i = 0; i < n; ++i) sd[names[i]] = {tensors[i], numels[i]};
+    VitW& v = h->vit;
+    int rc = RELAX_OK;
+    auto up = [&](const std::string& key, int64_t numel, float** dst) {
+        if (rc != RELAX_OK) return;
+        auto it = sd.find(key);
+        if (it == sd.end()) {
+            set_error(h, "vit state dict: missing key '%s'", key.c_str());
+            rc = RELAX_ERR_INVALID;
+            return;
+        }
+        if (it->second.second != numel) {
+            set_error(h, "vit state dict: key '%s' has %lld elements, expected %lld", key.c_str(),
+                      (long long)it->second.second, (long long)numel);
+            rc = RELAX_ERR_INVALID;
+            return;
+        }
+        rc = upload(h, it->second.first, (size_t)numel, dst, v.allocs);
+    };
+    auto lin = [&](const std::string& p, int in, int out, LinearW* l) {
+        l->in = in;
+        l->out = out;
+        up(p + ".weight", (int64_t)in * out, &l->w);
+        up(p + ".bias", out, &l->b);
+    };
+    v.dim = dim; v.depth = depth; v.heads = heads;
+    up("cls_token", dim, &v.cls);
+    up("pos_embed", (int64_t)NTOK * dim, &v.pos);
+    lin("patch_embed.proj", PATCH_K, dim, &v.patch);  // OIHW [dim][3][16][16] is already [dim][c*256+py*16+px]
+    v.blocks.resize(depth);
+    for (int i = 0; i < depth; ++i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        VitBlockW& b = v.blocks[i];
+        up(p + "norm1.weight", dim, &b.ln1_g);
+        up(p + "norm1.bias", dim, &b.ln1_b);
+        lin(p + "attn.qkv", dim, 3 * dim, &b.qkv);
+        lin(p + "attn.proj", dim, dim, &b.proj);
+        up(p + "norm2.weight", dim, &b.ln2_g);
+        up(p + "norm2.bias", dim, &b.ln2_b);
+        lin(p + "mlp.fc1", dim, 4 * dim, &b.fc1);
+        lin(p + "mlp.fc2", 4 * dim, dim, &b.fc2);
+    }
+    up("norm.weight", dim, &v.norm_g);
+    up("norm.bias", dim, &v.norm_b);
+    if (rc != RELAX_OK) {
+        free_vit(h);
+        return rc;
+    }
+    v.loaded = true;
+    return RELAX_OK;
+}
+
+int relax_vit_features(relax_handle* h, const uint8_t* frags, int N, float* tokens, float* pooled,
+                       relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, h->vit.loaded, "relax_vit_features: call relax_load_vit first");
+    RELAX_REQUIRE(h, frags && N > 0, "relax_vit_features: bad arguments");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const VitW& v = h->vit;
+    const int dim = v.dim;
+    RELAX_TRY(ensure_buf(h, h->arena, vit_arena_bytes(v, N)));
+    const size_t n = (size_t)N;
+    float* P = static_cast<float*>(h->arena.p);
+    float* PE = P + n * NPATCH * PATCH_K;
+    float* X = PE + n * NPATCH * dim;
+    float* Y = X + n * NTOK * dim;
+    float* QKV = Y + n * NTOK * dim;
+    float* Hid = QKV + n * NTOK * dim * 3;
+    const int rows = N * NTOK;
+
+    const int64_t ptotal = (int64_t)N * NPATCH * PATCH_K;
+    hipLaunchKernelGGL(vit_patchify, dim3((unsigned)((ptotal + 255) / 256)), dim3(256), 0, s, frags, P, ptotal);
+    RELAX_TRY(launch_gemm(h, P, v.patch.w, v.patch.b, nullptr, PE, N * NPATCH, dim, PATCH_K, 0, s));
+    const int64_t atotal = (int64_t)rows * (dim / 4);
+    hipLaunchKernelGGL(vit_assemble, dim3((unsigned)((atotal + 255) / 256)), dim3(256), 0, s, PE, v.cls, v.pos, X,
+                       dim / 4, atotal);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    for (const VitBlockW& b : v.blocks) {
+        RELAX_TRY(launch_layernorm(h, X, b.ln1_g, b.ln1_b, Y, rows, dim, kLnEps, s));
+        RELAX_TRY(launch_gemm(h, Y, b.qkv.w, b.qkv.b, nullptr, QKV, rows, 3 * dim, dim, 0, s));
+        RELAX_TRY(launch_attention(h, QKV, Y, N, v.heads, s));
+        RELAX_TRY(launch_gemm(h, Y, b.proj.w, b.proj.b, X, X, rows, dim, dim, 0, s));       // x += proj(attn)
+        RELAX_TRY(launch_layernorm(h, X, b.ln2_g, b.ln2_b, Y, rows, dim, kLnEps, s));
+        RELAX_TRY(launch_gemm(h, Y, b.fc1.w, b.fc1.b, nullptr, Hid, rows, 4 * dim, dim, 2, s));   // GELU(erf)
+        RELAX_TRY(launch_gemm(h, Hid, b.fc2.w, b.fc2.b, X, X, rows, dim, 4 * dim, 0, s));   // x += mlp
+    }
+    RELAX_TRY(launch_layernorm(h, X, v.norm_g, v.norm_b, Y, rows, dim, kLnEps, s));
+    if (tokens) {
+        const int64_t t = (int64_t)N * NPATCH * (dim / 4);
+        hipLaunchKernelGGL(vit_drop_cls, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, Y, tokens, dim / 4, t);
+    }
+    if (pooled) hipLaunchKernelGGL(vit_token_stats, dim3(dim / 64, N), dim3(256), 0, s, Y, pooled, dim);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+}  // extern "C"

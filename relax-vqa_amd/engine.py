@@ -1,0 +1,318 @@
+"""Host side of the MI355X feature-extraction engine.
+
+PyTorch-ROCm is plumbing only (device memory, streams, torch.distributed); all
+compute goes through the C-ABI of librelax_hip.so (include/relax_hip.h).
+Array-in / array-out counterparts of the reference's path-based functions:
+
+  fragment_pairs      <- cv2.absdiff + process_patches('frame_diff') + get_original_frame_patches
+                         (src/main_fragment_layerstack.py:302-310)
+  fragment_image      <- process_patches('optical_flow', flow_rgb) (src/main_fragment_layerstack.py:319)
+  merge_fragments     <- merge_fragments (src/main_fragment_layerstack.py:242-245)
+  resnet50_features   <- get_deep_feature('resnet50', .., 'layer_stack'|'pool') + process_video_feature
+                         (src/main_fragment_layerstack.py:83-99,124-160)
+  vit_features        <- get_deep_feature('vit', ..) + process_video_feature (src/main_fragment_pool.py:114-143)
+  extract_clip        <- the per-video loop body of src/main_fragment_layerstack.py:293-344 plus the ViT
+                         branch of src/demo_test.py:137-161 (config 3 of BASELINE.json)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+LAYER_STACK_DIM = 13120
+RN50_POOL_DIM = 2051
+TOP_N = 196
+TARGET = 224
+RN50_TAP_SHAPES = [(64, 112)] + [(256, 56)] * 3 + [(512, 28)] * 4 + [(1024, 14)] * 4 + [(2048, 7)] * 3
+VIT_CONFIGS = {"vit_tiny": (192, 12, 3), "vit_small": (384, 12, 6), "vit_base": (768, 12, 12)}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class RelaxEngine:
+    """One engine per (process, device).  Not thread-safe (mirrors the C handle)."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("RelaxEngine needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        torch.cuda.set_device(self.device)
+        torch.zeros(1, device=self.device)  # make sure the HIP context exists before the library touches it
+        h = C.c_void_p()
+        rc = self.lib.relax_create(self.device.index, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"relax_create failed ({rc}): {self.lib.relax_last_error(None).decode()}")
+        self.h = h
+        self.vit_dim = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.relax_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.relax_last_error(self.h).decode()}")
+
+    # ---- weights ------------------------------------------------------------------------------
+    def _marshal_state_dict(self, sd):
+        names, arrays = [], []
+        for k, v in sd.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            v = np.asarray(v)
+            if v.dtype.kind != "f":
+                continue  # num_batches_tracked etc.
+            names.append(k.encode())
+            arrays.append(np.ascontiguousarray(v, dtype=np.float32))
+        n = len(names)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrays])
+        cnames = (C.c_char_p * n)(*names)
+        numels = (C.c_int64 * n)(*[a.size for a in arrays])
+        return ptrs, cnames, numels, n, arrays
+
+    def load_resnet50(self, state_dict):
+        """state_dict: torchvision resnet50 key names -> fp32 arrays/tensors."""
+        ptrs, names, numels, n, keep = self._marshal_state_dict(state_dict)
+        self._check(self.lib.relax_load_resnet50(self.h, ptrs, names, numels, n), "relax_load_resnet50")
+        del keep
+
+    def load_vit(self, state_dict, name_model="vit_base"):
+        """state_dict: DINO ViT key names -> fp32 arrays/tensors."""
+        dim, depth, heads = VIT_CONFIGS[name_model]
+        ptrs, names, numels, n, keep = self._marshal_state_dict(state_dict)
+        self._check(self.lib.relax_load_vit(self.h, ptrs, names, numels, n, dim, depth, heads), "relax_load_vit")
+        self.vit_dim = dim
+        del keep
+
+    def reserve(self, max_images):
+        self._check(self.lib.relax_reserve(self.h, int(max_images)), "relax_reserve")
+
+    # ---- stage A ------------------------------------------------------------------------------
+    def _dev_u8(self, a):
+        if isinstance(a, np.ndarray):
+            a = torch.from_numpy(np.ascontiguousarray(a))
+        a = a.to(self.device, non_blocking=True)
+        if a.dtype != torch.uint8:
+            raise TypeError(f"expected uint8, got {a.dtype}")
+        return a.contiguous()
+
+    def fragment_pairs(self, frames, top_n=TOP_N, want_scores=False):
+        """frames: uint8 [T,2,H,W,3] BGR (frames[t,0] = sampled frame, frames[t,1] = the next one).
+        -> dict(positions int32 [T,196,2], counts int32 [T], ori_frag, diff_frag uint8 [T,224,224,3][, scores])"""
+        frames = self._dev_u8(frames)
+        if frames.dim() != 5 or frames.shape[1] != 2 or frames.shape[4] != 3:
+            raise ValueError(f"frames must be [T,2,H,W,3], got {tuple(frames.shape)}")
+        T, _, H, W, _ = frames.shape
+        dev = self.device
+        positions = torch.empty((T, TOP_N, 2), dtype=torch.int32, device=dev)
+        counts = torch.empty((T,), dtype=torch.int32, device=dev)
+        ori = torch.empty((T, TARGET, TARGET, 3), dtype=torch.uint8, device=dev)
+        diff = torch.empty((T, TARGET, TARGET, 3), dtype=torch.uint8, device=dev)
+        scores = torch.empty((T, (H // 16) * (W // 16)), dtype=torch.int32, device=dev) if want_scores else None
+        frame_bytes = H * W * 3
+        base = frames.data_ptr()
+        rc = self.lib.relax_fragment_pairs(self.h, C.c_void_p(base), C.c_void_p(base + frame_bytes), 2 * frame_bytes,
+                                           T, H, W, int(top_n), _ptr(positions), _ptr(counts), _ptr(ori), _ptr(diff),
+                                           _ptr(scores), _stream())
+        self._check(rc, "relax_fragment_pairs")
+        out = dict(positions=positions, counts=counts, ori_frag=ori, diff_frag=diff)
+        if want_scores:
+            out["scores"] = scores.view(T, H // 16, W // 16)
+        return out
+
+    def fragment_image(self, images, top_n=TOP_N, want_scores=False):
+        """images: uint8 [T,H,W,3] residual images (e.g. flow_to_rgb output). -> dict(positions, counts, frag[, scores])"""
+        images = self._dev_u8(images)
+        if images.dim() != 4 or images.shape[3] != 3:
+            raise ValueError(f"images must be [T,H,W,3], got {tuple(images.shape)}")
+        T, H, W, _ = images.shape
+        dev = self.device
+        positions = torch.empty((T, TOP_N, 2), dtype=torch.int32, device=dev)
+        counts = torch.empty((T,), dtype=torch.int32, device=dev)
+        frag = torch.empty((T, TARGET, TARGET, 3), dtype=torch.uint8, device=dev)
+        scores = torch.empty((T, (H // 16) * (W // 16)), dtype=torch.int32, device=dev) if want_scores else None
+        rc = self.lib.relax_fragment_image(self.h, _ptr(images), H * W * 3, T, H, W, int(top_n), _ptr(positions),
+                                           _ptr(counts), _ptr(frag), _ptr(scores), _stream())
+        self._check(rc, "relax_fragment_image")
+        out = dict(positions=positions, counts=counts, frag=frag)
+        if want_scores:
+            out["scores"] = scores.view(T, H // 16, W // 16)
+        return out
+
+    def gather_patches(self, images, positions, counts):
+        images = self._dev_u8(images)
+        T, H, W, _ = images.shape
+        positions = positions.to(self.device, torch.int32).contiguous()
+        counts = counts.to(self.device, torch.int32).contiguous()
+        frag = torch.empty((T, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device)
+        rc = self.lib.relax_gather_patches(self.h, _ptr(images), H * W * 3, T, H, W, _ptr(positions), _ptr(counts),
+                                           _ptr(frag), _stream())
+        self._check(rc, "relax_gather_patches")
+        return frag
+
+    def merge_fragments(self, a, b):
+        a, b = self._dev_u8(a), self._dev_u8(b)
+        if a.shape != b.shape:
+            raise ValueError("merge_fragments: shape mismatch")
+        out = torch.empty_like(a)
+        self._check(self.lib.relax_merge_fragments(self.h, _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()),
+                    "relax_merge_fragments")
+        return out
+
+    # ---- stage B ------------------------------------------------------------------------------
+    def _frags(self, frags):
+        frags = self._dev_u8(frags)
+        if frags.dim() == 3:
+            frags = frags.unsqueeze(0)
+        if tuple(frags.shape[1:]) != (TARGET, TARGET, 3):
+            raise ValueError(f"fragments must be [N,224,224,3], got {tuple(frags.shape)}")
+        return frags
+
+    def resnet50_features(self, frags, layer_stack=True, pool=True, taps=None):
+        """frags uint8 [N,224,224,3] BGR -> (layer_stack fp32 [N,13120] | None, pool fp32 [N,2051] | None[, taps]).
+        taps: optional iterable of tap indices (0..14) whose full activations [N,C,H,W] are returned too."""
+        frags = self._frags(frags)
+        N = frags.shape[0]
+        dev = self.device
+        ls = torch.empty((N, LAYER_STACK_DIM), dtype=torch.float32, device=dev) if layer_stack else None
+        pl = torch.empty((N, RN50_POOL_DIM), dtype=torch.float32, device=dev) if pool else None
+        tap_out, tap_ptrs = {}, None
+        if taps is not None:
+            arr = (C.c_void_p * 15)()
+            for t in taps:
+                c, s = RN50_TAP_SHAPES[t]
+                tap_out[t] = torch.empty((N, c, s, s), dtype=torch.float32, device=dev)
+                arr[t] = tap_out[t].data_ptr()
+            tap_ptrs = arr
+        rc = self.lib.relax_resnet50_features(self.h, _ptr(frags), N, _ptr(ls), _ptr(pl), tap_ptrs, _stream())
+        self._check(rc, "relax_resnet50_features")
+        return (ls, pl, tap_out) if taps is not None else (ls, pl)
+
+    def vit_features(self, frags, tokens=False, pooled=True):
+        """frags uint8 [N,224,224,3] BGR -> (tokens fp32 [N,196,dim] | None, pooled fp32 [N,3*dim] | None)"""
+        if self.vit_dim is None:
+            raise RuntimeError("load_vit first")
+        frags = self._frags(frags)
+        N = frags.shape[0]
+        dev = self.device
+        tk = torch.empty((N, 196, self.vit_dim), dtype=torch.float32, device=dev) if tokens else None
+        pl = torch.empty((N, 3 * self.vit_dim), dtype=torch.float32, device=dev) if pooled else None
+        self._check(self.lib.relax_vit_features(self.h, _ptr(frags), N, _ptr(tk), _ptr(pl), _stream()),
+                    "relax_vit_features")
+        return tk, pl
+
+    # ---- whole clip ---------------------------------------------------------------------------
+    def extract_clip(self, frames, resnet=True, vit=True, flow_images=None):
+        """frames uint8 [T,2,H,W,3] on the device -> per-frame features (all fp32, on the device):
+             resnet: [T,15171] = layer-stack of the original fragment | pool of the residual fragment
+             vit:    [T,4608]  = pool of the original fragment | pool of the residual fragment
+        The residual fragment is the frame-difference fragment, merged 50/50 with the optical-flow
+        fragment when flow_images (uint8 [T,H,W,3]) are supplied (src/main_fragment_layerstack.py:313-325)."""
+        fr = self.fragment_pairs(frames)
+        resid = fr["diff_frag"]
+        if flow_images is not None:
+            fl = self.fragment_image(flow_images)
+            resid = self.merge_fragments(resid, fl["frag"])
+        T = resid.shape[0]
+        both = torch.cat([fr["ori_frag"], resid], dim=0)
+        out = {"positions": fr["positions"], "counts": fr["counts"]}
+        if resnet:
+            ls, pool = self.resnet50_features(both, layer_stack=True, pool=True)
+            out["resnet"] = torch.cat([ls[:T], pool[T:]], dim=1)
+        if vit:
+            _, pooled = self.vit_features(both, tokens=False, pooled=True)
+            out["vit"] = torch.cat([pooled[:T], pooled[T:]], dim=1)
+        return out
+
+    def clip_vector(self, frames, **kw):
+        """Per-clip mean over frames of the concatenated features (src/demo_test.py:171-175)."""
+        f = self.extract_clip(frames, **kw)
+        parts = [f[k].mean(dim=0) for k in ("resnet", "vit") if k in f]
+        return torch.cat(parts)
+
+    # ---- operator level (tests / benches) -------------------------------------------------------
+    def op_gemm(self, A, W, bias=None, residual=None, act=0, out=None):
+        M, K = A.shape
+        N = W.shape[0]
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=self.device)
+        self._check(self.lib.relax_op_gemm(self.h, _ptr(A), _ptr(W), _ptr(bias), _ptr(residual), _ptr(out), M, N, K,
+                                           act, _stream()), "relax_op_gemm")
+        return out
+
+    def op_conv2d_nhwc(self, x, w_packed, bias, residual, Cout, KH, KW, stride, pad, act):
+        Nimg, H, W, Cin = x.shape
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W + 2 * pad - KW) // stride + 1
+        out = torch.empty((Nimg, Ho, Wo, Cout), dtype=torch.float32, device=self.device)
+        rc = self.lib.relax_op_conv2d_nhwc(self.h, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(out),
+                                           Nimg, H, W, Cin, Cout, KH, KW, stride, pad, act, _stream())
+        self._check(rc, "relax_op_conv2d_nhwc")
+        return out
+
+    def op_layernorm(self, x, g, b, eps):
+        rows, dim = x.shape
+        y = torch.empty_like(x)
+        self._check(self.lib.relax_op_layernorm(self.h, _ptr(x), _ptr(g), _ptr(b), _ptr(y), rows, dim, eps, _stream()),
+                    "relax_op_layernorm")
+        return y
+
+    def op_attention(self, qkv, n_img, heads):
+        out = torch.empty((qkv.shape[0], heads * 64), dtype=torch.float32, device=self.device)
+        self._check(self.lib.relax_op_attention(self.h, _ptr(qkv), _ptr(out), n_img, heads, _stream()),
+                    "relax_op_attention")
+        return out
+
+    def op_bn_relu_maxpool(self, x, scale, shift):
+        Nimg, H, W, Cc = x.shape
+        y = torch.empty((Nimg, H // 2, W // 2, Cc), dtype=torch.float32, device=self.device)
+        self._check(self.lib.relax_op_bn_relu_maxpool(self.h, _ptr(x), _ptr(scale), _ptr(shift), _ptr(y), Nimg, H, W,
+                                                      Cc, _stream()), "relax_op_bn_relu_maxpool")
+        return y
+
+    def op_gap(self, x):
+        Nimg, HW, Cc = x.shape
+        out = torch.empty((Nimg, Cc), dtype=torch.float32, device=self.device)
+        self._check(self.lib.relax_op_gap(self.h, _ptr(x), _ptr(out), Nimg, HW, Cc, Cc, _stream()), "relax_op_gap")
+        return out
+
+    # ---- measurement ----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.relax_profile_enable(self.h, int(bool(on))), "relax_profile_enable")
+
+    def profile_read(self, kind):
+        ms, work, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.relax_profile_read(self.h, kind, C.byref(ms), C.byref(work), C.byref(n)),
+                    "relax_profile_read")
+        return ms.value, work.value, n.value
+
+
+def pack_conv_weight(w_oihw, cin_pad=None):
+    """OIHW fp32 -> [Cout, Kpad] with k = (dy*KW+dx)*Cin_pad + c, zero padded to a multiple of 32
+    (the layout relax_op_conv2d_nhwc expects; the model loader does the same on the host in C++)."""
+    w = np.asarray(w_oihw, dtype=np.float32)
+    co, ci, kh, kw = w.shape
+    cp = cin_pad or ci
+    k = kh * kw * cp
+    kpad = -(-k // 32) * 32
+    out = np.zeros((co, kpad), dtype=np.float32)
+    t = np.zeros((co, kh, kw, cp), dtype=np.float32)
+    t[..., :ci] = w.transpose(0, 2, 3, 1)
+    out[:, :k] = t.reshape(co, k)
+    return out

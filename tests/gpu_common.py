@@ -1,0 +1,54 @@
+"""Shared helpers for the -m gpu parity tests (HIP path vs oracle through the C-ABI)."""
+import numpy as np
+import pytest
+import torch
+
+import relax_vqa_amd  # noqa: F401
+from relax_vqa_amd import synth
+from relax_vqa_amd.engine import RelaxEngine
+
+# north_star tolerance: features within 1e-3 relative fp32.  The engine computes in exact fp32 (fp32 MFMA), so
+# the element-wise check below uses rtol 1e-3 with an absolute floor of 1e-4 x the block's mean magnitude
+# (features that are exactly ~0 after ReLU have no meaningful relative error).
+RTOL = 1e-3
+ATOL_FRAC = 1e-4
+
+_engine = None
+_weights = {}
+
+
+def engine():
+    global _engine
+    if _engine is None:
+        _engine = RelaxEngine(0)
+    return _engine
+
+
+def rn50_weights():
+    if "rn" not in _weights:
+        _weights["rn"] = synth.resnet50_state_dict()
+        engine().load_resnet50(_weights["rn"])
+    return _weights["rn"]
+
+
+def vit_weights(name):
+    key = "vit:" + name
+    if _weights.get("vit_loaded") != name:
+        _weights[key] = _weights.get(key) or synth.vit_state_dict(name)
+        engine().load_vit(_weights[key], name)
+        _weights["vit_loaded"] = name
+    return _weights[key]
+
+
+def assert_close(got, want, what, rtol=RTOL, atol_frac=ATOL_FRAC):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    scale = float(np.abs(want).mean()) + 1e-30
+    err = np.abs(got - want)
+    bound = rtol * np.abs(want) + atol_frac * scale
+    worst = float((err / bound).max())
+    assert worst <= 1.0, (f"{what}: max err/bound {worst:.3g}; max abs err {err.max():.3e}, "
+                          f"mean |want| {scale:.3e}, norm-rel {np.linalg.norm(got - want) / np.linalg.norm(want):.3e}")
+    return float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))

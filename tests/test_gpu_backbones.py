@@ -1,0 +1,104 @@
+"""Backbone parity on the GPU: ResNet-50 layer-stack / pool and ViT tokens / pool against the oracle, plus the
+reference-derived ViT golden tokens and the whole-clip path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fragment_ref, pooling_ref, resnet50_ref, vit_ref
+from tests.gpu_common import assert_close, engine, rn50_weights, synth, vit_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _fragments(n, seed=0):
+    frs = []
+    for i in range(n):
+        o, nx = synth.synthetic_pair(240, 320, 500 + seed * 64 + i)
+        f = fragment_ref.fragment_pair(o, nx)
+        frs.append(f["ori_frag"] if i % 2 == 0 else f["diff_frag"])
+    return np.stack(frs)
+
+
+def test_resnet50_taps_and_features():
+    sd = rn50_weights()
+    frags = _fragments(3)
+    ls, pool, taps = engine().resnet50_features(torch.from_numpy(frags).cuda(), taps=range(15))
+    torch.cuda.synchronize()
+    tsd = resnet50_ref.to_torch_state_dict(sd)
+    ref_taps, ref_avg = resnet50_ref.forward_taps(tsd, resnet50_ref.preprocess_bgr_u8(frags))
+    for i, name in enumerate(pooling_ref.RESNET50_TAPS):      # every hooked activation, in tap order
+        assert_close(taps[i], ref_taps[name].numpy(), name)
+    want_ls = resnet50_ref.layer_stack_features(tsd, frags)
+    want_pool = resnet50_ref.pool_features(tsd, frags)
+    off = 0
+    for name, c in zip(pooling_ref.RESNET50_TAPS, pooling_ref.RESNET50_TAP_CHANNELS):
+        assert_close(ls[:, off:off + c], want_ls[:, off:off + c], f"layer-stack block {name}")
+        off += c
+    assert_close(pool[:, :2048], want_pool[:, :2048], "pool vector")
+    assert_close(pool[:, 2048:], want_pool[:, 2048:], "pool stats (mean,max,std)")
+
+
+def test_resnet50_pool_only_and_batch_independence():
+    rn50_weights()
+    frags = _fragments(5, seed=1)
+    ls_all, pool_all = engine().resnet50_features(torch.from_numpy(frags).cuda())
+    none_ls, pool_only = engine().resnet50_features(torch.from_numpy(frags).cuda(), layer_stack=False, pool=True)
+    assert none_ls is None
+    assert torch.equal(pool_only, pool_all)
+    ls_one, pool_one = engine().resnet50_features(torch.from_numpy(frags[3:4]).cuda())
+    assert torch.equal(ls_one[0], ls_all[3]) and torch.equal(pool_one[0], pool_all[3]), "result depends on batch"
+
+
+@pytest.mark.parametrize("name,heads", [("vit_tiny", 3), ("vit_base", 12)])
+def test_vit_matches_reference_golden_tokens(golden_dir, name, heads):
+    vit_weights(name)
+    z = np.load(os.path.join(golden_dir, f"{name}_tokens.npz"))
+    tokens, pooled = engine().vit_features(torch.from_numpy(z["frags"]).cuda(), tokens=True, pooled=True)
+    assert_close(tokens, z["tokens"], f"{name} tokens vs reference VisionTransformer")
+    want = np.stack([pooling_ref.vit_pool_vector(t) for t in z["tokens"]])
+    assert_close(pooled, want, f"{name} pooled vs reference process_video_feature")
+
+
+def test_vit_base_oracle_batch():
+    sd = vit_weights("vit_base")
+    frags = _fragments(3, seed=2)
+    tokens, pooled = engine().vit_features(torch.from_numpy(frags).cuda(), tokens=True, pooled=True)
+    tsd = vit_ref.to_torch_state_dict(sd)
+    assert_close(tokens, vit_ref.tokens(tsd, frags, 12), "vit_base tokens")
+    assert_close(pooled, vit_ref.pool_features(tsd, frags, 12), "vit_base pooled")
+
+
+def test_extract_clip_config2_shape_720p():
+    """BASELINE config 2 (720p, residual-fragment + RN50 layer-stack) on a short clip, against the oracle."""
+    sd = rn50_weights()
+    T = 3
+    clip = synth.synthetic_clip(T, 720, 1280, clip_id=2)
+    out = engine().extract_clip(torch.from_numpy(clip).cuda(), resnet=True, vit=False)
+    tsd = resnet50_ref.to_torch_state_dict(sd)
+    refs = [fragment_ref.fragment_pair(clip[t, 0], clip[t, 1]) for t in range(T)]
+    assert np.array_equal(out["positions"].cpu().numpy(), np.stack([r["positions"] for r in refs]))
+    want = np.concatenate([resnet50_ref.layer_stack_features(tsd, np.stack([r["ori_frag"] for r in refs])),
+                           resnet50_ref.pool_features(tsd, np.stack([r["diff_frag"] for r in refs]))], axis=1)
+    assert out["resnet"].shape == (T, 15171)
+    assert_close(out["resnet"][:, :13120], want[:, :13120], "clip layer-stack")
+    assert_close(out["resnet"][:, 13120:], want[:, 13120:], "clip residual pool")
+
+
+def test_extract_clip_config3_1080p_with_vit():
+    sd_r, sd_v = rn50_weights(), vit_weights("vit_base")
+    T = 2
+    clip = synth.synthetic_clip(T, 1080, 1920, clip_id=3)
+    out = engine().extract_clip(torch.from_numpy(clip).cuda())
+    refs = [fragment_ref.fragment_pair(clip[t, 0], clip[t, 1]) for t in range(T)]
+    assert np.array_equal(out["positions"].cpu().numpy(), np.stack([r["positions"] for r in refs]))
+    ori, res = np.stack([r["ori_frag"] for r in refs]), np.stack([r["diff_frag"] for r in refs])
+    tv = vit_ref.to_torch_state_dict(sd_v)
+    want_vit = np.concatenate([vit_ref.pool_features(tv, ori, 12), vit_ref.pool_features(tv, res, 12)], axis=1)
+    assert out["vit"].shape == (T, 4608) and out["resnet"].shape == (T, 15171)
+    assert_close(out["vit"], want_vit, "clip vit pooled")
+    tr = resnet50_ref.to_torch_state_dict(sd_r)
+    assert_close(out["resnet"][:, :13120], resnet50_ref.layer_stack_features(tr, ori), "clip layer-stack 1080p")
+    vec = engine().clip_vector(torch.from_numpy(clip).cuda())
+    assert vec.shape == (15171 + 4608,)
