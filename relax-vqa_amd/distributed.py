@@ -1,0 +1,61 @@
+"""Clip-sharded data parallelism: one process per GPU, clips are independent (the reference's outer loop
+`for i in range(len(videodata))`, src/main_fragment_layerstack.py:269, carries no state), weights replicated,
+and ONE collective: an all-gather of the per-clip feature vectors so that every rank holds the [n_clips, F]
+matrix the scaler/MLP consume (the matrix src/data_processing/extract_npy2mat.py:117-130 builds on disk).
+Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_clips(n_clips, rank, world):
+    """Contiguous block partition of clip indices; the first n_clips % world ranks get one extra."""
+    base, extra = divmod(n_clips, world)
+    lo = rank * base + min(rank, extra)
+    return list(range(lo, lo + base + (1 if rank < extra else 0)))
+
+
+def gather_clip_vectors(local, n_clips, rank, world, group=None):
+    """local: [len(shard_clips(n_clips, rank, world)), F] -> [n_clips, F] on every rank, rows in clip order.
+    Ragged shards are padded to ceil(n_clips / world) rows for a single fixed-size all-gather."""
+    if world == 1:
+        return local
+    per = -(-n_clips // world)
+    F = local.shape[1]
+    padded = torch.zeros((per, F), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    out = torch.empty((world * per, F), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    rows = []
+    for r in range(world):
+        n_r = len(shard_clips(n_clips, r, world))
+        rows.append(out[r * per: r * per + n_r])
+    return torch.cat(rows, dim=0)
+
+
+def extract_dataset(extract_fn, n_clips, rank, world, group=None):
+    """Run extract_fn(clip_index) -> [F] on this rank's shard and all-gather the per-clip vectors."""
+    mine = shard_clips(n_clips, rank, world)
+    vecs = [extract_fn(i) for i in mine]
+    if vecs:
+        local = torch.stack(vecs)
+    else:
+        raise ValueError("every rank needs at least one clip (n_clips >= world)")
+    return gather_clip_vectors(local, n_clips, rank, world, group)
