@@ -145,6 +145,7 @@ int relax_destroy(relax_handle* h) {
     free_vit(h);
     if (h->arena.p) (void)hipFree(h->arena.p);
     if (h->scratch.p) (void)hipFree(h->scratch.p);
+    if (h->splitk_ws.p) (void)hipFree(h->splitk_ws.p);
     for (auto& sp : h->prof.spans) {
         (void)hipEventDestroy(sp.start);
         (void)hipEventDestroy(sp.stop);

@@ -32,10 +32,13 @@ struct GemmParams {
     const float* bias;
     const float* residual;
     float* out;
+    float* partial;  // split-K partial tiles [split_tile][slice][BM*BN], or null
     int M, N, Kpad;
     int H, W, Cin, cin_log2, Ho, Wo, KW, stride, pad, ntaps;
     int act;
     int tiles_n, ntiles;
+    int full_tiles;  // tiles [0, full_tiles) run the whole K loop and the epilogue in-kernel
+    int nsplit;      // tiles [full_tiles, ntiles) are cut into nsplit K slices (raw partial sums)
 };
 
 __device__ inline int xcd_remap(int b, int nwg) {
@@ -52,23 +55,39 @@ __device__ inline float apply_act(float v, int act) {
 }
 
 template <int BM, int BN, int WM, int WN, bool TAPS>
-__global__ __launch_bounds__(256) void conv_gemm_f32(const GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_f32(const GemmParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int PASS = NT / 8;  // tile rows staged per pass (8 lanes x float4 = one 32-float K step of a row)
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
-    constexpr int A_LOADS = BM / 32;
-    constexpr int B_LOADS = BN / 32;
+    constexpr int A_LOADS = BM / PASS;
+    constexpr int B_LOADS = BN / PASS;
     constexpr int STAGE = (BM + BN) * LDK;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BM % PASS == 0 && BN % PASS == 0 && TM >= 1 && TN >= 1, "tile / wave layout mismatch");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int lrow = tid >> 3;  // 0..31: row within a 32-row staging pass
+    const int lrow = tid >> 3;  // row within a staging pass
     const int c4 = tid & 7;     // which float4 of the 32-float K step
 
-    const int tile = xcd_remap(blockIdx.x, p.ntiles);
+    // work unit -> (tile, K slice)
+    int tile, kt_begin, kt_end, slice = -1, split_tile = 0;
+    const int nk = p.Kpad / BK;
+    if ((int)blockIdx.x < p.full_tiles) {
+        tile = xcd_remap(blockIdx.x, p.full_tiles);
+        kt_begin = 0;
+        kt_end = nk;
+    } else {
+        const int u = blockIdx.x - p.full_tiles;
+        split_tile = u / p.nsplit;
+        slice = u - split_tile * p.nsplit;
+        tile = p.full_tiles + split_tile;
+        kt_begin = (int)((int64_t)nk * slice / p.nsplit);
+        kt_end = (int)((int64_t)nk * (slice + 1) / p.nsplit);
+    }
     const int m0 = (tile / p.tiles_n) * BM;
     const int n0 = (tile % p.tiles_n) * BN;
 
@@ -78,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(const GemmParams p) {
     bool a_ok[A_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-        const int m = m0 + i * 32 + lrow;
+        const int m = m0 + i * PASS + lrow;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
         if (TAPS || p.stride != 1) {
@@ -96,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(const GemmParams p) {
         }
     }
     const float* wrow0 = p.w + (int64_t)(n0 + lrow) * p.Kpad + c4 * 4;
-    const int64_t wpass = (int64_t)32 * p.Kpad;  // 32 weight rows per staging pass
+    const int64_t wpass = (int64_t)PASS * p.Kpad;  // weight rows per staging pass
 
     f32x4 ra[A_LOADS], rb[B_LOADS];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -132,9 +151,9 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(const GemmParams p) {
         float* As_ = smem + (buf_) * STAGE;                                                           \
         float* Bs_ = As_ + BM * LDK;                                                                  \
         _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                           \
-            *reinterpret_cast<f32x4*>(As_ + (i * 32 + lrow) * LDK + c4 * 4) = ra[i];                  \
+            *reinterpret_cast<f32x4*>(As_ + (i * PASS + lrow) * LDK + c4 * 4) = ra[i];                \
         _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                           \
-            *reinterpret_cast<f32x4*>(Bs_ + (i * 32 + lrow) * LDK + c4 * 4) = rb[i];                  \
+            *reinterpret_cast<f32x4*>(Bs_ + (i * PASS + lrow) * LDK + c4 * 4) = rb[i];                \
     }
 
     floatx16 acc[TM][TN];
@@ -145,15 +164,14 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.Kpad / BK;
-    RELAX_LOAD_TILE(0);
+    RELAX_LOAD_TILE(kt_begin * BK);
     RELAX_STORE_TILE(0);
     __syncthreads();
 
     const int frag_off = (lane & 31) * LDK + 4 * (lane >> 5);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
         const float* As = smem + cur * STAGE + (wm * TM * 32) * LDK + frag_off;
         const float* Bs = smem + cur * STAGE + BM * LDK + (wn * TN * 32) * LDK + frag_off;
 #pragma unroll
@@ -173,12 +191,27 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(const GemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) RELAX_STORE_TILE(cur ^ 1);
+        if (kt + 1 < kt_end) RELAX_STORE_TILE(cur ^ 1);
         __syncthreads();
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int half = lane >> 5;
+    if (slice >= 0) {
+        // K slice of a split tile: raw partial sums, tile-local row-major [BM][BN]; epilogue runs in splitk_finish
+        float* pt = p.partial + ((int64_t)split_tile * p.nsplit + slice) * (BM * BN);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = (wm * TM + i) * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+                    pt[lr * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
+                }
+        return;
+    }
+    const bool full_rows = m0 + BM <= p.M;  // workgroup-uniform: interior tiles skip the per-row guards
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -186,14 +219,30 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int rbase = m0 + (wm * TM + i) * 32 + 4 * half;
+            if (full_rows) {
+                float res[16];
+                if (p.residual) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < p.M) {
-                    const int64_t o = (int64_t)row * p.N + col;
-                    float v = acc[i][j][r] + bias;
-                    if (p.residual) v += p.residual[o];
-                    p.out[o] = apply_act(v, p.act);
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = p.residual[(int64_t)(rbase + (r & 3) + 8 * (r >> 2)) * p.N + col];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) res[r] = 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    p.out[(int64_t)(rbase + (r & 3) + 8 * (r >> 2)) * p.N + col] =
+                        apply_act(acc[i][j][r] + bias + res[r], p.act);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) {
+                        const int64_t o = (int64_t)row * p.N + col;
+                        float v = acc[i][j][r] + bias;
+                        if (p.residual) v += p.residual[o];
+                        p.out[o] = apply_act(v, p.act);
+                    }
                 }
             }
         }
@@ -203,10 +252,68 @@ __global__ __launch_bounds__(256) void conv_gemm_f32(const GemmParams p) {
 #undef RELAX_LOAD_TILE
 #undef RELAX_STORE_TILE
 
+// Sums the K slices of the split tiles in slice order (deterministic) and applies the epilogue.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void splitk_finish(const GemmParams p) {
+    const int split_tile = blockIdx.y;
+    const int tile = p.full_tiles + split_tile;
+    const int m0 = (tile / p.tiles_n) * BM;
+    const int n0 = (tile % p.tiles_n) * BN;
+    const int e4 = blockIdx.x * 256 + threadIdx.x;  // float4 index inside the tile
+    if (e4 >= BM * BN / 4) return;
+    const int lr = e4 / (BN / 4), lc = (e4 % (BN / 4)) * 4;
+    const int row = m0 + lr;
+    if (row >= p.M) return;
+    const float* pt = p.partial + (int64_t)split_tile * p.nsplit * (BM * BN) + lr * BN + lc;
+    f32x4 s = *reinterpret_cast<const f32x4*>(pt);
+    for (int k = 1; k < p.nsplit; ++k) s += *reinterpret_cast<const f32x4*>(pt + (int64_t)k * (BM * BN));
+    const int64_t o = (int64_t)row * p.N + n0 + lc;
+    if (p.bias) s += *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
+    if (p.residual) s += *reinterpret_cast<const f32x4*>(p.residual + o);
+    f32x4 v = {apply_act(s.x, p.act), apply_act(s.y, p.act), apply_act(s.z, p.act), apply_act(s.w, p.act)};
+    *reinterpret_cast<f32x4*>(p.out + o) = v;
+}
+
+struct TuneKnobs {
+    int force_variant = -1;  // RELAX_GEMM_VARIANT: pin one tile variant (experiments only)
+    int split = 1;           // RELAX_GEMM_SPLIT=0 disables tail split-K
+};
+
+static const TuneKnobs& knobs() {
+    static TuneKnobs k = [] {
+        TuneKnobs t;
+        if (const char* e = getenv("RELAX_GEMM_VARIANT")) t.force_variant = atoi(e);
+        if (const char* e = getenv("RELAX_GEMM_SPLIT")) t.split = atoi(e);
+        return t;
+    }();
+    return k;
+}
+
 template <int BM, int BN, int WM, int WN, bool TAPS>
-static int launch_variant(relax_handle* h, GemmParams& p, hipStream_t s) {
+static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hipStream_t s) {
+    constexpr int NT = WM * WN * 64;
     p.tiles_n = p.N / BN;
     p.ntiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+    p.full_tiles = p.ntiles;
+    p.nsplit = 1;
+    p.partial = nullptr;
+    // Tail split-K: the last partial round of tiles would leave most CUs idle; cut those tiles along K so
+    // that the tail fills the chip once with short work units (partials summed in order by splitk_finish).
+    const int slots = blocks_per_cu * 256;
+    const int nk = p.Kpad / BK;
+    const int rem = p.ntiles % slots;
+    if (knobs().split && rem > 0 && rem * 4 < slots * 3) {
+        int S = slots / rem;
+        if (S > nk / 4) S = nk / 4;
+        if (S > 16) S = 16;
+        if (S >= 2) {
+            const size_t need = sizeof(float) * (size_t)rem * S * BM * BN;
+            RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
+            p.partial = static_cast<float*>(h->splitk_ws.p);
+            p.full_tiles = p.ntiles - rem;
+            p.nsplit = S;
+        }
+    }
     constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;
     static bool attr_set = false;
     if (!attr_set) {
@@ -214,7 +321,10 @@ static int launch_variant(relax_handle* h, GemmParams& p, hipStream_t s) {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, TAPS>), dim3(p.ntiles), dim3(256), lds, s, p);
+    const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
+    hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, TAPS>), dim3(units), dim3(NT), lds, s, p);
+    if (p.nsplit > 1)
+        hipLaunchKernelGGL((splitk_finish<BM, BN>), dim3(BM * BN / 4 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }
@@ -224,6 +334,11 @@ static int ilog2_exact(int v) {
     while ((1 << l) < v) ++l;
     return (1 << l) == v ? l : -1;
 }
+
+// tile variants: id -> <BM, BN, WM, WN>, workgroups resident per CU (LDS / VGPR bound)
+#define RELAX_DISPATCH(BM_, BN_, WM_, WN_, BPC_)                                             \
+    (taps ? launch_variant<BM_, BN_, WM_, WN_, true>(h, p, BPC_, s)                          \
+          : launch_variant<BM_, BN_, WM_, WN_, false>(h, p, BPC_, s))
 
 int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     GemmParams p{};
@@ -239,7 +354,10 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     RELAX_REQUIRE(h, p.Kpad % BK == 0, "conv/gemm: K=%d must be a multiple of %d", p.Kpad, BK);
     RELAX_REQUIRE(h, p.N % 64 == 0, "conv/gemm: N=%d must be a multiple of 64", p.N);
     RELAX_REQUIRE(h, p.Cin % 4 == 0, "conv/gemm: Cin=%d must be a multiple of 4", p.Cin);
-    RELAX_REQUIRE(h, (reinterpret_cast<uintptr_t>(d.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.w) & 15) == 0,
+    RELAX_REQUIRE(h, (reinterpret_cast<uintptr_t>(d.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.w) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(d.out) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(d.residual) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0,
                   "conv/gemm: operands must be 16-byte aligned");
     if (taps) {
         p.cin_log2 = ilog2_exact(d.Cin);
@@ -252,21 +370,27 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)(d.KH * d.KW * d.Cin);
     int span;
     RELAX_TRY(prof_begin(h, s, 0, flops, &span));
-    // tile choice: the biggest tile that still gives every CU (256) at least ~2 workgroups
-    const long tiles128 = (p.N % 128 == 0) ? (long)((p.M + 127) / 128) * (p.N / 128) : 0;
-    const long tiles128x64 = (long)((p.M + 127) / 128) * (p.N / 64);
+    int variant = knobs().force_variant;
+    if (variant < 0 || (variant != 5 && variant != 6 && p.N % 128 != 0)) {
+        variant = (p.N % 128 == 0) ? 1 : 5;
+    }
     int rc;
-    if (tiles128 >= 512) {
-        rc = taps ? launch_variant<128, 128, 2, 2, true>(h, p, s) : launch_variant<128, 128, 2, 2, false>(h, p, s);
-    } else if (tiles128x64 >= 512) {
-        rc = taps ? launch_variant<128, 64, 2, 2, true>(h, p, s) : launch_variant<128, 64, 2, 2, false>(h, p, s);
-    } else {
-        rc = taps ? launch_variant<64, 64, 2, 2, true>(h, p, s) : launch_variant<64, 64, 2, 2, false>(h, p, s);
+    switch (variant) {
+        case 1: rc = RELAX_DISPATCH(128, 128, 2, 2, 2); break;   // 4 waves, 64x64 per wave
+        case 2: rc = RELAX_DISPATCH(128, 128, 2, 4, 2); break;   // 8 waves, 64x32 per wave
+        case 3: rc = RELAX_DISPATCH(128, 128, 4, 2, 2); break;   // 8 waves, 32x64 per wave
+        case 4: rc = RELAX_DISPATCH(256, 128, 4, 2, 1); break;   // 8 waves, 64x64 per wave, 1 workgroup / CU
+        case 5: rc = RELAX_DISPATCH(128, 64, 2, 2, 2); break;    // 4 waves, 64x32 per wave
+        case 6: rc = RELAX_DISPATCH(64, 64, 2, 2, 4); break;     // 4 waves, 32x32 per wave
+        default:
+            set_error(h, "conv/gemm: unknown tile variant %d", variant);
+            return RELAX_ERR_INVALID;
     }
     RELAX_TRY(rc);
     RELAX_TRY(prof_end(h, s, span));
     return RELAX_OK;
 }
+#undef RELAX_DISPATCH
 
 }  // namespace relax
 

@@ -130,6 +130,7 @@ struct relax_handle {
     relax::DevBuf arena;        // activation workspace shared by both backbones
     int reserved_images = 0;
     relax::DevBuf scratch;      // stage-A scratch (scores)
+    relax::DevBuf splitk_ws;    // split-K partial tiles of the contraction kernel
     relax::ResNet50W rn;
     relax::VitW vit;
     relax::Profiler prof;
