@@ -151,6 +151,11 @@ int relax_op_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale
 int relax_op_gap(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,
                  relax_stream stream);
 
+/* x [Nimg, tokens, dim] -> out [Nimg, 3*dim] = per-channel mean | max | population std over tokens
+ * (process_video_feature, vit branch: src/main_residual_fragment.py:128-136; src/main_fragment_pool.py:124-133) */
+int relax_op_token_stats(relax_handle* h, const float* x, float* out, int Nimg, int tokens, int dim,
+                         relax_stream stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* While enabled, every launch of the contraction kernel (GEMM / implicit-GEMM conv) and of the patch-score
  * kernel is bracketed by HIP events on the caller's stream.  relax_profile_read synchronises those events and

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "relax_op_attention": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, c_vp]),
     "relax_op_bn_relu_maxpool": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "relax_op_gap": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int64, c_vp]),
+    "relax_op_token_stats": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "relax_profile_enable": (C.c_int, [c_vp, C.c_int]),
     "relax_profile_read": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_int64)]),

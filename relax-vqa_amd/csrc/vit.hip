@@ -59,22 +59,23 @@ __global__ __launch_bounds__(256) void vit_drop_cls(const float* __restrict__ Y,
 }
 
 // per (image, channel): mean, max, population std over tokens 1..196 -> out[n, 0:dim | dim:2dim | 2dim:3dim]
-__global__ __launch_bounds__(256) void vit_token_stats(const float* __restrict__ Y, float* __restrict__ out, int dim) {
+__global__ __launch_bounds__(256) void vit_token_stats(const float* __restrict__ Y, float* __restrict__ out, int dim,
+                                                       int tok_per_img, int first, int count) {
     __shared__ float red[4][64];
     __shared__ float s_mean[64];
     const int n = blockIdx.y;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int grp = threadIdx.x >> 6;  // 4 groups stride the tokens
-    const float* yb = Y + ((int64_t)n * NTOK + 1) * dim + c;
+    const float* yb = Y + ((int64_t)n * tok_per_img + first) * dim + c;
     float s = 0.f, m = -INFINITY;
-    for (int p = grp; p < NPATCH; p += 4) {
+    for (int p = grp; p < count; p += 4) {
         const float v = yb[(int64_t)p * dim];
         s += v;
         m = fmaxf(m, v);
     }
     red[grp][threadIdx.x & 63] = s;
     __syncthreads();
-    if (grp == 0) s_mean[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)NPATCH;
+    if (grp == 0) s_mean[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)count;
     __syncthreads();
     const float mean = s_mean[threadIdx.x & 63];
     __syncthreads();
@@ -84,14 +85,14 @@ __global__ __launch_bounds__(256) void vit_token_stats(const float* __restrict__
     if (grp == 0) mx = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
     __syncthreads();
     float q = 0.f;
-    for (int p = grp; p < NPATCH; p += 4) {
+    for (int p = grp; p < count; p += 4) {
         const float dv = yb[(int64_t)p * dim] - mean;
         q += dv * dv;
     }
     red[grp][threadIdx.x & 63] = q;
     __syncthreads();
     if (grp == 0) {
-        const float var = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)NPATCH;
+        const float var = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)count;
         float* o = out + (int64_t)n * 3 * dim;
         o[c] = mean;
         o[dim + c] = mx;
@@ -221,7 +222,20 @@ int relax_vit_features(relax_handle* h, const uint8_t* frags, int N, float* toke
         const int64_t t = (int64_t)N * NPATCH * (dim / 4);
         hipLaunchKernelGGL(vit_drop_cls, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, Y, tokens, dim / 4, t);
     }
-    if (pooled) hipLaunchKernelGGL(vit_token_stats, dim3(dim / 64, N), dim3(256), 0, s, Y, pooled, dim);
+    if (pooled) hipLaunchKernelGGL(vit_token_stats, dim3(dim / 64, N), dim3(256), 0, s, Y, pooled, dim, NTOK, 1, NPATCH);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+
+int relax_op_token_stats(relax_handle* h, const float* x, float* out, int Nimg, int tokens, int dim,
+                         relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, x && out && Nimg > 0 && tokens > 0 && dim > 0 && dim % 64 == 0,
+                  "relax_op_token_stats: bad arguments (dim must be a multiple of 64)");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(vit_token_stats, dim3(dim / 64, Nimg), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, dim,
+                       tokens, 0, tokens);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }

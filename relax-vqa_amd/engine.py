@@ -292,6 +292,13 @@ class RelaxEngine:
         self._check(self.lib.relax_op_gap(self.h, _ptr(x), _ptr(out), Nimg, HW, Cc, Cc, _stream()), "relax_op_gap")
         return out
 
+    def op_token_stats(self, x):
+        Nimg, T, dim = x.shape
+        out = torch.empty((Nimg, 3 * dim), dtype=torch.float32, device=self.device)
+        self._check(self.lib.relax_op_token_stats(self.h, _ptr(x), _ptr(out), Nimg, T, dim, _stream()),
+                    "relax_op_token_stats")
+        return out
+
     # ---- measurement ----------------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self.lib.relax_profile_enable(self.h, int(bool(on))), "relax_profile_enable")

@@ -1,0 +1,85 @@
+"""Process-wide engine + weights, the counterpart of the reference's import-time globals
+(`resnet50 = models.resnet50(pretrained=True).to(device)`, src/extractor/visualise_resnet.py:17-21).
+Created lazily, never at import.  Weights: a torchvision / DINO state-dict file named by
+RELAX_RESNET50_WEIGHTS / RELAX_VIT_WEIGHTS when present, else the deterministic synthetic weights
+(there is no network in the build environment)."""
+import logging
+import os
+
+import numpy as np
+
+from . import synth
+
+log = logging.getLogger("relax_vqa_amd")
+_state = {"engine": None, "rn": False, "vit": None}
+
+
+def _load_file(path):
+    import torch
+    sd = torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    return {k: v.numpy() if hasattr(v, "numpy") else np.asarray(v) for k, v in sd.items()}
+
+
+def get_engine(device=0):
+    if _state["engine"] is None:
+        from .engine import RelaxEngine
+        _state["engine"] = RelaxEngine(device)
+    return _state["engine"]
+
+
+def ensure_resnet50():
+    eng = get_engine()
+    if not _state["rn"]:
+        path = os.environ.get("RELAX_RESNET50_WEIGHTS")
+        if path:
+            sd = _load_file(path)
+        else:
+            log.warning("RELAX_RESNET50_WEIGHTS not set: using synthetic ResNet-50 weights")
+            sd = synth.resnet50_state_dict()
+        eng.load_resnet50(sd)
+        _state["rn"] = True
+    return eng
+
+
+def ensure_vit(name_model="vit_base"):
+    eng = get_engine()
+    if _state["vit"] != name_model:
+        path = os.environ.get("RELAX_VIT_WEIGHTS")
+        if path:
+            sd = _load_file(path)
+        else:
+            log.warning("RELAX_VIT_WEIGHTS not set: using synthetic %s weights", name_model)
+            sd = synth.vit_state_dict(name_model)
+        eng.load_vit(sd, name_model)
+        _state["vit"] = name_model
+    return eng
+
+
+def set_weights(resnet50=None, vit=None, vit_name="vit_base"):
+    """Explicit weight injection (tests, real checkpoints already in memory)."""
+    eng = get_engine()
+    if resnet50 is not None:
+        eng.load_resnet50(resnet50)
+        _state["rn"] = True
+    if vit is not None:
+        eng.load_vit(vit, vit_name)
+        _state["vit"] = vit_name
+    return eng
+
+
+def read_image_bgr(image_path):
+    """PNG/JPEG -> uint8 [H,W,3] BGR (what cv2.imread returns, src/main_fragment_layerstack.py:295)."""
+    from PIL import Image
+    rgb = np.asarray(Image.open(image_path).convert("RGB"))
+    return np.ascontiguousarray(rgb[..., ::-1])
+
+
+def require_fragment(img_bgr, what):
+    if img_bgr.shape[:2] != (224, 224):
+        raise NotImplementedError(
+            f"{what}: input is {img_bgr.shape[1]}x{img_bgr.shape[0]}; the whole-frame resize front-end "
+            "(PIL antialiased bilinear / LANCZOS to 224x224) is SURVEY §8(f) row f1 and is not built yet. "
+            "Fragments (224x224) are the supported input.")
+    return img_bgr

@@ -1,0 +1,96 @@
+"""The reference-named host API (relax-vqa_amd/extractor/*, main_fragment_layerstack) driven the way the
+reference's own drivers drive it (PNG paths, per-frame lists), checked against the oracle."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import relax_vqa_amd  # noqa: F401
+from oracle import fragment_ref, pooling_ref, resnet50_ref, vit_ref
+from tests.gpu_common import assert_close, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from relax_vqa_amd import main_fragment_layerstack as m
+    from relax_vqa_amd import runtime
+    rn, vit = synth.resnet50_state_dict(), synth.vit_state_dict("vit_base")
+    runtime.set_weights(resnet50=rn, vit=vit, vit_name="vit_base")
+    return m, rn, vit
+
+
+def _write_png_bgr(path, bgr):
+    Image.fromarray(np.ascontiguousarray(bgr[..., ::-1])).save(path)   # cv2.imwrite stores BGR arrays as RGB PNGs
+
+
+def test_driver_loop_like_the_reference(api, tmp_path):
+    m, rn, vit = api
+    T = 2
+    clip = synth.synthetic_clip(T, 272, 400, clip_id=8)
+    ori_acts, res_acts, vit_acts = [], [], []
+    refs = []
+    for t in range(T):
+        img_original, img_next = clip[t, 0], clip[t, 1]
+        # residual = cv2.absdiff(...); process_patches('frame_diff'); get_original_frame_patches  (fused on the GPU)
+        diff_frag, ori_frag, positions = m.fragment_pair(img_original, img_next)
+        ref = fragment_ref.fragment_pair(img_original, img_next)
+        refs.append(ref)
+        assert positions == [tuple(p) for p in ref["positions"].tolist()]
+        assert np.array_equal(diff_frag, ref["diff_frag"]) and np.array_equal(ori_frag, ref["ori_frag"])
+        # the step-by-step functions give the same answers
+        residual = fragment_ref.absdiff(img_next, img_original)
+        assert np.array_equal(m.get_patch_diff(residual, 16), ref["score"])
+        path, frag2, pos2 = m.process_patches(str(tmp_path / f"v_{t}.png"), "frame_diff", residual, 16, 224, 196)
+        assert path.endswith(f"v_{t}_residual_imp.png") and pos2 == positions and np.array_equal(frag2, diff_frag)
+        assert np.array_equal(m.get_original_frame_patches(img_original, positions, 16, 224), ori_frag)
+        # PNG round trip as the reference does it, then get_deep_feature on the paths
+        ori_path = str(tmp_path / f"v_{t}_ori_frag.png")
+        res_path = str(tmp_path / f"v_{t}_residual_imp.png")
+        _write_png_bgr(ori_path, ori_frag)
+        _write_png_bgr(res_path, diff_frag)
+        _, _, a = m.get_deep_feature("resnet50", "v", ori_path, "original", "layer_stack")
+        _, _, b = m.get_deep_feature("resnet50", "v", res_path, "original", "pool")
+        _, _, c = m.get_deep_feature("vit", "v", ori_path, "original", "pool")
+        assert list(a.keys()) == pooling_ref.RESNET50_TAPS and a["resnet50.conv1"].shape == (64, 112, 112)
+        assert b.shape == (2048, 1, 1) and c.shape == (196, 768)
+        ori_acts.append(a)
+        res_acts.append(b)
+        vit_acts.append(c)
+    f_ori = m.process_video_feature(ori_acts, "resnet50", "layer_stack")
+    f_res = m.process_video_feature(res_acts, "resnet50", "pool")
+    f_vit = m.process_video_feature(vit_acts, "vit")
+    combined = m.concatenate_features(f_ori, f_res)
+    assert combined.shape == (T, 15171) and f_vit.shape == (T, 2304)
+    tr = resnet50_ref.to_torch_state_dict(rn)
+    ori = np.stack([r["ori_frag"] for r in refs])
+    res = np.stack([r["diff_frag"] for r in refs])
+    assert_close(f_ori, resnet50_ref.layer_stack_features(tr, ori), "driver layer_stack")
+    assert_close(f_res, resnet50_ref.pool_features(tr, res), "driver pool")
+    assert_close(f_vit, vit_ref.pool_features(vit_ref.to_torch_state_dict(vit), ori, 12), "driver vit pool")
+    # raw dicts (no .pooled) are reduced on the GPU too
+    plain = [dict(a) for a in ori_acts]
+    assert_close(m.process_video_feature(plain, "resnet50", "layer_stack"), f_ori, "layer_stack from raw taps", rtol=1e-5)
+
+
+def test_merge_and_flow_fragment_path(api):
+    m, _, _ = api
+    g = np.random.default_rng(3)
+    flow_img = g.integers(0, 256, (272, 400, 3), dtype=np.uint8)
+    _, frag, pos = m.process_patches("x_1.png", "optical_flow", flow_img, 16, 224, 196)
+    want, wpos = fragment_ref.extract_important_patches(flow_img, fragment_ref.get_patch_diff(flow_img))
+    assert np.array_equal(frag, want) and pos == [tuple(p) for p in wpos.tolist()]
+    other = g.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    assert np.array_equal(m.merge_fragments(frag, other), fragment_ref.merge_fragments(frag, other))
+
+
+def test_unbuilt_rows_fail_loudly(api, tmp_path):
+    m, _, _ = api
+    with pytest.raises(NotImplementedError):
+        m.flow_to_rgb(np.zeros((4, 4, 2), np.float32))
+    p = str(tmp_path / "frame_1.png")
+    Image.fromarray(np.zeros((64, 80, 3), np.uint8)).save(p)
+    with pytest.raises(NotImplementedError):
+        m.get_deep_feature("resnet50", "v", p, "original", "layer_stack")   # whole-frame resize = SURVEY §8(f) f1
