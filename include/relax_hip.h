@@ -63,6 +63,12 @@ const char* relax_last_error(const relax_handle* h);
  * backbone entry points; call it up front to keep allocation out of timed code. */
 int relax_reserve(relax_handle* h, int max_images);
 
+/* Integer options.  "gemm_split_k" (default 1): cut the tail tiles of a contraction along K so the last round fills
+ * the chip; results stay deterministic for a given batch, but the K-summation order of tail tiles then depends on the
+ * batch size - set 0 when features must be bit-identical across batch compositions (e.g. comparing sharded runs).
+ * "gemm_variant", "gemm_group_m", "gemm_prio", "gemm_ablate": tuning / experiment knobs (see csrc/gemm.hip). */
+int relax_set_option(relax_handle* h, const char* key, int value);
+
 /* ---- weights ------------------------------------------------------------------------------- */
 /* Replaces `models.resnet50(pretrained=True)` (src/extractor/visualise_resnet.py:21,
  * visualise_resnet_layer.py:20).  names[i] are torchvision state-dict keys

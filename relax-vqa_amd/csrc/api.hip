@@ -1,5 +1,6 @@
 // Handle lifetime, error reporting, workspace and event profiling of librelax_hip.so.
 #include <cstdarg>
+#include <cstdlib>
 
 #include "relax_internal.h"
 
@@ -133,6 +134,11 @@ int relax_create(int device, relax_handle** out) {
     }
     relax_handle* h = new relax_handle();
     h->device = device;
+    if (const char* e = getenv("RELAX_GEMM_SPLIT")) h->gemm.split_k = atoi(e);
+    if (const char* e = getenv("RELAX_GEMM_VARIANT")) h->gemm.variant = atoi(e);
+    if (const char* e = getenv("RELAX_GEMM_GROUP_M")) h->gemm.group_m = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("RELAX_GEMM_PRIO")) h->gemm.prio = atoi(e);
+    if (const char* e = getenv("RELAX_GEMM_ABLATE")) h->gemm.ablate = atoi(e);
     *out = h;
     return RELAX_OK;
 }
@@ -171,6 +177,22 @@ int relax_reserve(relax_handle* h, int max_images) {
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
     RELAX_TRY(ensure_buf(h, h->arena, need));
     h->reserved_images = max_images;
+    return RELAX_OK;
+}
+
+int relax_set_option(relax_handle* h, const char* key, int value) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, key, "relax_set_option: key is NULL");
+    const std::string k(key);
+    if (k == "gemm_split_k") h->gemm.split_k = value;
+    else if (k == "gemm_variant") h->gemm.variant = value;
+    else if (k == "gemm_group_m") h->gemm.group_m = value > 0 ? value : 1;
+    else if (k == "gemm_prio") h->gemm.prio = value;
+    else if (k == "gemm_ablate") h->gemm.ablate = value;
+    else {
+        set_error(h, "relax_set_option: unknown option '%s'", key);
+        return RELAX_ERR_INVALID;
+    }
     return RELAX_OK;
 }
 

@@ -23,8 +23,6 @@ namespace relax {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 struct did not)
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;
 
 struct GemmParams {
     const float* in;
@@ -36,9 +34,11 @@ struct GemmParams {
     int M, N, Kpad;
     int H, W, Cin, cin_log2, Ho, Wo, KW, stride, pad, ntaps;
     int act;
-    int tiles_n, ntiles;
+    int tiles_m, tiles_n, ntiles, group_m;
     int full_tiles;  // tiles [0, full_tiles) run the whole K loop and the epilogue in-kernel
     int nsplit;      // tiles [full_tiles, ntiles) are cut into nsplit K slices (raw partial sums)
+    int prio;        // experiment knob: raise wave priority around the MFMA cluster
+    int ablate;      // timing-only experiment knob (wrong results): 1 no barrier, 2 no global loads, 4 no LDS stores
 };
 
 __device__ inline int xcd_remap(int b, int nwg) {
@@ -54,10 +54,12 @@ __device__ inline float apply_act(float v, int act) {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool TAPS>
+template <int BM, int BN, int WM, int WN, int BK, bool TAPS>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_f32(const GemmParams p) {
     constexpr int NT = WM * WN * 64;
-    constexpr int PASS = NT / 8;  // tile rows staged per pass (8 lanes x float4 = one 32-float K step of a row)
+    constexpr int LDK = BK + 4;   // padded LDS row: conflict-free b128 writes and reads for BK = 32 (36) and 16 (20)
+    constexpr int KL = BK / 4;    // lanes (float4) per K step of a row
+    constexpr int PASS = NT / KL; // tile rows staged per pass
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr int A_LOADS = BM / PASS;
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_f32(const GemmParams p
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int lrow = tid >> 3;  // row within a staging pass
-    const int c4 = tid & 7;     // which float4 of the 32-float K step
+    const int lrow = tid / KL;  // row within a staging pass
+    const int c4 = tid % KL;    // which float4 of the K step
 
     // work unit -> (tile, K slice)
     int tile, kt_begin, kt_end, slice = -1, split_tile = 0;
@@ -88,8 +90,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_f32(const GemmParams p
         kt_begin = (int)((int64_t)nk * slice / p.nsplit);
         kt_end = (int)((int64_t)nk * (slice + 1) / p.nsplit);
     }
-    const int m0 = (tile / p.tiles_n) * BM;
-    const int n0 = (tile % p.tiles_n) * BN;
+    // grouped order: consecutive tiles walk group_m row-tiles x all column tiles column by column, so the ~64
+    // workgroups resident on one XCD share both a few activation row-tiles and a few weight column-tiles in L2
+    int tm, tn;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = tile / per_group;
+        const int first = g * p.group_m;
+        const int gsz = p.tiles_m - first < p.group_m ? p.tiles_m - first : p.group_m;
+        const int w = tile - g * per_group;
+        tm = first + w % gsz;
+        tn = w / gsz;
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
 
     // per-thread row descriptors of the A operand (fixed for the whole K loop)
     int64_t a_base[A_LOADS];
@@ -171,9 +185,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_f32(const GemmParams p
     const int frag_off = (lane & 31) * LDK + 4 * (lane >> 5);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
+        if (kt + 1 < kt_end && !(p.ablate & 2)) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
         const float* As = smem + cur * STAGE + (wm * TM * 32) * LDK + frag_off;
         const float* Bs = smem + cur * STAGE + BM * LDK + (wn * TN * 32) * LDK + frag_off;
+        if (p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[TM], bf[TN];
@@ -191,58 +206,95 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_f32(const GemmParams p
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < kt_end) RELAX_STORE_TILE(cur ^ 1);
-        __syncthreads();
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
+        if (kt + 1 < kt_end && !(p.ablate & 4)) RELAX_STORE_TILE(cur ^ 1);
+        if (!(p.ablate & 1)) __syncthreads();
     }
 
-    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // ---- epilogue, staged through LDS -----------------------------------------------------------------------
+    // The accumulators hold one column per lane and rows in registers (C/D map of the 32x32 MFMA:
+    // col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); stored directly that is 64 dword stores per
+    // lane.  Instead each 64-row chunk of the tile goes through the (now free) staging LDS and leaves as whole
+    // 512-byte row segments: 16-byte loads/stores, 4x fewer memory instructions, bias/residual/activation fused.
+    constexpr int EP_ROWS = BM < 64 ? BM : 64;
+    constexpr int LDC = BN + 4;
+    constexpr int C4 = BN / 4;                       // float4 per tile row
+    constexpr int EP_ITERS = EP_ROWS * C4 / NT;
+    static_assert(EP_ROWS * LDC <= 2 * STAGE, "epilogue chunk must fit the staging LDS");
+    static_assert((EP_ROWS * C4) % NT == 0, "epilogue chunk must divide over the workgroup");
     const int half = lane >> 5;
-    if (slice >= 0) {
-        // K slice of a split tile: raw partial sums, tile-local row-major [BM][BN]; epilogue runs in splitk_finish
-        float* pt = p.partial + ((int64_t)split_tile * p.nsplit + slice) * (BM * BN);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lr = (wm * TM + i) * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
-                    pt[lr * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
-                }
-        return;
+    float* outp;
+    int64_t ldo;
+    if (slice >= 0) {   // K slice of a split tile: raw partial sums [BM][BN]; splitk_finish applies the epilogue
+        outp = p.partial + ((int64_t)split_tile * p.nsplit + slice) * (BM * BN);
+        ldo = BN;
+    } else {
+        outp = p.out + (int64_t)m0 * p.N + n0;
+        ldo = p.N;
     }
-    const bool full_rows = m0 + BM <= p.M;  // workgroup-uniform: interior tiles skip the per-row guards
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-        const float bias = p.bias ? p.bias[col] : 0.f;
+    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
+        if (pass > 0) __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int rbase = m0 + (wm * TM + i) * 32 + 4 * half;
-            if (full_rows) {
-                float res[16];
-                if (p.residual) {
+            const int rb = (wm * TM + i) * 32;  // first tile row of this accumulator block (wave-uniform)
+            if (rb / EP_ROWS == pass) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        res[r] = p.residual[(int64_t)(rbase + (r & 3) + 8 * (r >> 2)) * p.N + col];
-                } else {
+                        smem[(rb % EP_ROWS + 4 * half + (r & 3) + 8 * (r >> 2)) * LDC + (wn * TN + j) * 32 + (lane & 31)] =
+                            acc[i][j][r];
+            }
+        }
+        __syncthreads();
+        const bool interior = m0 + BM <= p.M;  // workgroup-uniform: interior tiles skip the per-row guards
+        if (slice >= 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) res[r] = 0.f;
-                }
+            for (int it = 0; it < EP_ITERS; ++it) {
+                const int idx = it * NT + tid;
+                const int lr = idx / C4, lc = (idx % C4) * 4;
+                *reinterpret_cast<f32x4*>(outp + (int64_t)(pass * EP_ROWS + lr) * ldo + lc) =
+                    *reinterpret_cast<const f32x4*>(smem + lr * LDC + lc);
+            }
+        } else if (interior) {
+            f32x4 v[EP_ITERS], rv[EP_ITERS];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    p.out[(int64_t)(rbase + (r & 3) + 8 * (r >> 2)) * p.N + col] =
-                        apply_act(acc[i][j][r] + bias + res[r], p.act);
-            } else {
+            for (int it = 0; it < EP_ITERS; ++it) {  // all residual loads in flight together
+                const int idx = it * NT + tid;
+                const int lr = idx / C4, lc = (idx % C4) * 4;
+                rv[it] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + (int64_t)(m0 + pass * EP_ROWS + lr) * p.N + n0 + lc)
+                                    : zero4;
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (row < p.M) {
-                        const int64_t o = (int64_t)row * p.N + col;
-                        float v = acc[i][j][r] + bias;
-                        if (p.residual) v += p.residual[o];
-                        p.out[o] = apply_act(v, p.act);
-                    }
+            for (int it = 0; it < EP_ITERS; ++it) {
+                const int idx = it * NT + tid;
+                const int lr = idx / C4, lc = (idx % C4) * 4;
+                v[it] = *reinterpret_cast<const f32x4*>(smem + lr * LDC + lc);
+                if (p.bias) v[it] += *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
+                v[it] += rv[it];  // (acc + bias) + residual: the same order on every path, so bits do not depend on the tile
+            }
+#pragma unroll
+            for (int it = 0; it < EP_ITERS; ++it) {
+                const int idx = it * NT + tid;
+                const int lr = idx / C4, lc = (idx % C4) * 4;
+                f32x4 w = {apply_act(v[it].x, p.act), apply_act(v[it].y, p.act), apply_act(v[it].z, p.act),
+                           apply_act(v[it].w, p.act)};
+                *reinterpret_cast<f32x4*>(outp + (int64_t)(pass * EP_ROWS + lr) * ldo + lc) = w;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < EP_ITERS; ++it) {
+                const int idx = it * NT + tid;
+                const int lr = idx / C4, lc = (idx % C4) * 4;
+                const int trow = pass * EP_ROWS + lr;
+                if (m0 + trow < p.M) {
+                    const int64_t o = (int64_t)trow * ldo + lc;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(smem + lr * LDC + lc);
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
+                    if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)m0 * p.N + n0 + o);
+                    f32x4 w = {apply_act(v.x, p.act), apply_act(v.y, p.act), apply_act(v.z, p.act), apply_act(v.w, p.act)};
+                    *reinterpret_cast<f32x4*>(outp + o) = w;
                 }
             }
         }
@@ -257,8 +309,18 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void splitk_finish(const GemmParams p) {
     const int split_tile = blockIdx.y;
     const int tile = p.full_tiles + split_tile;
-    const int m0 = (tile / p.tiles_n) * BM;
-    const int n0 = (tile % p.tiles_n) * BN;
+    int tm, tn;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = tile / per_group;
+        const int first = g * p.group_m;
+        const int gsz = p.tiles_m - first < p.group_m ? p.tiles_m - first : p.group_m;
+        const int w = tile - g * per_group;
+        tm = first + w % gsz;
+        tn = w / gsz;
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
     const int e4 = blockIdx.x * 256 + threadIdx.x;  // float4 index inside the tile
     if (e4 >= BM * BN / 4) return;
     const int lr = e4 / (BN / 4), lc = (e4 % (BN / 4)) * 4;
@@ -274,26 +336,15 @@ __global__ __launch_bounds__(256) void splitk_finish(const GemmParams p) {
     *reinterpret_cast<f32x4*>(p.out + o) = v;
 }
 
-struct TuneKnobs {
-    int force_variant = -1;  // RELAX_GEMM_VARIANT: pin one tile variant (experiments only)
-    int split = 1;           // RELAX_GEMM_SPLIT=0 disables tail split-K
-};
-
-static const TuneKnobs& knobs() {
-    static TuneKnobs k = [] {
-        TuneKnobs t;
-        if (const char* e = getenv("RELAX_GEMM_VARIANT")) t.force_variant = atoi(e);
-        if (const char* e = getenv("RELAX_GEMM_SPLIT")) t.split = atoi(e);
-        return t;
-    }();
-    return k;
-}
-
-template <int BM, int BN, int WM, int WN, bool TAPS>
+template <int BM, int BN, int WM, int WN, int BK, bool TAPS>
 static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     p.tiles_n = p.N / BN;
-    p.ntiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.ntiles = p.tiles_m * p.tiles_n;
+    p.group_m = h->gemm.group_m;
+    p.prio = h->gemm.prio;
+    p.ablate = h->gemm.ablate;
     p.full_tiles = p.ntiles;
     p.nsplit = 1;
     p.partial = nullptr;
@@ -302,27 +353,36 @@ static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hip
     const int slots = blocks_per_cu * 256;
     const int nk = p.Kpad / BK;
     const int rem = p.ntiles % slots;
-    if (knobs().split && rem > 0 && rem * 4 < slots * 3) {
-        int S = slots / rem;
-        if (S > nk / 4) S = nk / 4;
-        if (S > 16) S = 16;
-        if (S >= 2) {
-            const size_t need = sizeof(float) * (size_t)rem * S * BM * BN;
+    if (h->gemm.split_k && rem > 0) {
+        // time of the tail in rounds if its tiles are cut into S slices: ceil(rem*S/slots)/S, plus ~4 % of a round per
+        // extra slice for writing/re-reading the partial tiles; keep S = 1 unless splitting clearly wins
+        int best_s = 1;
+        double best = 1.0;
+        const int smax = nk / 4 < 16 ? nk / 4 : 16;
+        for (int S = 2; S <= smax; ++S) {
+            const double t = (double)((rem * S + slots - 1) / slots) / S + 0.04 * S;
+            if (t < best - 0.05) {
+                best = t;
+                best_s = S;
+            }
+        }
+        if (best_s >= 2) {
+            const size_t need = sizeof(float) * (size_t)rem * best_s * BM * BN;
             RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
             p.partial = static_cast<float*>(h->splitk_ws.p);
             p.full_tiles = p.ntiles - rem;
-            p.nsplit = S;
+            p.nsplit = best_s;
         }
     }
-    constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;
+    constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * (BK + 4);
     static bool attr_set = false;
     if (!attr_set) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f32<BM, BN, WM, WN, TAPS>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f32<BM, BN, WM, WN, BK, TAPS>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
-    hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, TAPS>), dim3(units), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, BK, TAPS>), dim3(units), dim3(NT), lds, s, p);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((splitk_finish<BM, BN>), dim3(BM * BN / 4 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
     RELAX_HIP_CHECK(h, hipGetLastError());
@@ -336,9 +396,9 @@ static int ilog2_exact(int v) {
 }
 
 // tile variants: id -> <BM, BN, WM, WN>, workgroups resident per CU (LDS / VGPR bound)
-#define RELAX_DISPATCH(BM_, BN_, WM_, WN_, BPC_)                                             \
-    (taps ? launch_variant<BM_, BN_, WM_, WN_, true>(h, p, BPC_, s)                          \
-          : launch_variant<BM_, BN_, WM_, WN_, false>(h, p, BPC_, s))
+#define RELAX_DISPATCH(BM_, BN_, WM_, WN_, BK_, BPC_)                                        \
+    (taps ? launch_variant<BM_, BN_, WM_, WN_, BK_, true>(h, p, BPC_, s)                     \
+          : launch_variant<BM_, BN_, WM_, WN_, BK_, false>(h, p, BPC_, s))
 
 int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     GemmParams p{};
@@ -351,7 +411,7 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     p.act = d.act;
     const bool taps = d.KH * d.KW > 1;
     RELAX_REQUIRE(h, p.M > 0 && p.N > 0 && p.Kpad > 0, "conv/gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.Kpad);
-    RELAX_REQUIRE(h, p.Kpad % BK == 0, "conv/gemm: K=%d must be a multiple of %d", p.Kpad, BK);
+    RELAX_REQUIRE(h, p.Kpad % 32 == 0, "conv/gemm: K=%d must be a multiple of 32", p.Kpad);
     RELAX_REQUIRE(h, p.N % 64 == 0, "conv/gemm: N=%d must be a multiple of 64", p.N);
     RELAX_REQUIRE(h, p.Cin % 4 == 0, "conv/gemm: Cin=%d must be a multiple of 4", p.Cin);
     RELAX_REQUIRE(h, (reinterpret_cast<uintptr_t>(d.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.w) & 15) == 0 &&
@@ -370,18 +430,20 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)(d.KH * d.KW * d.Cin);
     int span;
     RELAX_TRY(prof_begin(h, s, 0, flops, &span));
-    int variant = knobs().force_variant;
+    int variant = h->gemm.variant;
     if (variant < 0 || (variant != 5 && variant != 6 && p.N % 128 != 0)) {
         variant = (p.N % 128 == 0) ? 1 : 5;
     }
     int rc;
     switch (variant) {
-        case 1: rc = RELAX_DISPATCH(128, 128, 2, 2, 2); break;   // 4 waves, 64x64 per wave
-        case 2: rc = RELAX_DISPATCH(128, 128, 2, 4, 2); break;   // 8 waves, 64x32 per wave
-        case 3: rc = RELAX_DISPATCH(128, 128, 4, 2, 2); break;   // 8 waves, 32x64 per wave
-        case 4: rc = RELAX_DISPATCH(256, 128, 4, 2, 1); break;   // 8 waves, 64x64 per wave, 1 workgroup / CU
-        case 5: rc = RELAX_DISPATCH(128, 64, 2, 2, 2); break;    // 4 waves, 64x32 per wave
-        case 6: rc = RELAX_DISPATCH(64, 64, 2, 2, 4); break;     // 4 waves, 32x32 per wave
+        case 1: rc = RELAX_DISPATCH(128, 128, 2, 2, 32, 2); break;   // 4 waves, 64x64 per wave
+        case 2: rc = RELAX_DISPATCH(128, 128, 2, 4, 32, 2); break;   // 8 waves, 64x32 per wave
+        case 3: rc = RELAX_DISPATCH(128, 128, 4, 2, 32, 2); break;   // 8 waves, 32x64 per wave
+        case 4: rc = RELAX_DISPATCH(256, 128, 4, 2, 32, 1); break;   // 8 waves, 64x64 per wave, 1 workgroup / CU
+        case 5: rc = RELAX_DISPATCH(128, 64, 2, 2, 32, 2); break;   // 4 waves, 64x32 per wave
+        case 6: rc = RELAX_DISPATCH(64, 64, 2, 2, 32, 4); break;
+        case 7: rc = RELAX_DISPATCH(128, 128, 2, 2, 16, 3); break;   // BK 16: 36.9 KB LDS -> 3 workgroups / CU
+        case 8: rc = RELAX_DISPATCH(128, 128, 2, 4, 16, 3); break;   // 8 waves, BK 16   // 4 waves, 32x32 per wave
         default:
             set_error(h, "conv/gemm: unknown tile variant %d", variant);
             return RELAX_ERR_INVALID;
@@ -422,7 +484,7 @@ int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const
     d.Wo = (W + 2 * pad - KW) / stride + 1;
     d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad;
     d.w = w; d.Cout = Cout;
-    d.Kpad = ((KH * KW * Cin + BK - 1) / BK) * BK;
+    d.Kpad = ((KH * KW * Cin + 31) / 32) * 32;
     d.bias = bias; d.residual = residual; d.out = out; d.act = act;
     return launch_conv(h, d, static_cast<hipStream_t>(stream));
 }

@@ -285,10 +285,10 @@ constexpr int GAP_MAX_SPLIT = 16;
 int launch_gap_ws(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,
                   float* partial_ws, hipStream_t s) {
     RELAX_REQUIRE(h, C % 64 == 0 && HW > 0 && Nimg > 0, "gap: bad shape HW=%d C=%d", HW, C);
-    const int blocks = (C / 64) * Nimg;
-    int S = (1024 + blocks - 1) / blocks;
+    // the split depends on the layer geometry only (never on the batch), so a frame's features are bit-identical
+    // whatever batch it travels in
+    int S = HW / 196;
     if (S > GAP_MAX_SPLIT) S = GAP_MAX_SPLIT;
-    if (S > (HW + 15) / 16) S = (HW + 15) / 16;
     if (S < 1) S = 1;
     hipLaunchKernelGGL(gap_partial, dim3(C / 64, Nimg, S), dim3(256), 0, s, x, partial_ws, HW, C, S);
     hipLaunchKernelGGL(gap_finish, dim3((unsigned)(((int64_t)Nimg * C + 255) / 256)), dim3(256), 0, s, partial_ws, out,

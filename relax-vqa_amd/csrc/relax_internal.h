@@ -124,8 +124,20 @@ struct Profiler {
 
 }  // namespace relax
 
+namespace relax {
+// Tuning / reproducibility switches of the contraction kernel (relax_set_option; env defaults RELAX_GEMM_*).
+struct GemmOptions {
+    int split_k = 1;   // "gemm_split_k": tail split-K on (1) / off (0: K sums are batch-invariant bit for bit)
+    int variant = -1;  // "gemm_variant": pin a tile variant (experiments), -1 = automatic
+    int group_m = 8;   // "gemm_group_m": row-tiles per L2 group
+    int prio = 0;      // "gemm_prio": s_setprio around the MFMA cluster
+    int ablate = 0;    // "gemm_ablate": timing-only ablations (results are WRONG): 1 barrier, 2 global loads, 4 LDS stores
+};
+}  // namespace relax
+
 struct relax_handle {
     int device = 0;
+    relax::GemmOptions gemm;
     std::string last_error;
     relax::DevBuf arena;        // activation workspace shared by both backbones
     int reserved_images = 0;

@@ -100,6 +100,9 @@ class RelaxEngine:
         self.vit_dim = dim
         del keep
 
+    def set_option(self, key, value):
+        self._check(self.lib.relax_set_option(self.h, key.encode(), int(value)), "relax_set_option")
+
     def reserve(self, max_images):
         self._check(self.lib.relax_reserve(self.h, int(max_images)), "relax_reserve")
 
@@ -239,6 +242,26 @@ class RelaxEngine:
             _, pooled = self.vit_features(both, tokens=False, pooled=True)
             out["vit"] = torch.cat([pooled[:T], pooled[T:]], dim=1)
         return out
+
+    def clip_vectors(self, clips, resnet=True, vit=True):
+        """Several clips (list of uint8 [T,2,H,W,3] device tensors, any mix of resolutions) in ONE batched pass of
+        both backbones -> fp32 [len(clips), F] per-clip mean vectors.  Bigger batches fill the 256 CUs better
+        (more tiles per launch, fewer partial rounds); results per clip do not depend on the batching."""
+        frs = [self.fragment_pairs(c) for c in clips]
+        counts = [f["ori_frag"].shape[0] for f in frs]
+        ori = torch.cat([f["ori_frag"] for f in frs], dim=0)
+        res = torch.cat([f["diff_frag"] for f in frs], dim=0)
+        n = ori.shape[0]
+        both = torch.cat([ori, res], dim=0)
+        parts = []
+        if resnet:
+            ls, pool = self.resnet50_features(both, layer_stack=True, pool=True)
+            parts.append(torch.cat([ls[:n], pool[n:]], dim=1))
+        if vit:
+            _, pooled = self.vit_features(both, tokens=False, pooled=True)
+            parts.append(torch.cat([pooled[:n], pooled[n:]], dim=1))
+        per_frame = torch.cat(parts, dim=1)
+        return torch.stack([chunk.mean(dim=0) for chunk in torch.split(per_frame, counts, dim=0)])
 
     def clip_vector(self, frames, **kw):
         """Per-clip mean over frames of the concatenated features (src/demo_test.py:171-175)."""
