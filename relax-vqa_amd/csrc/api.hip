@@ -136,6 +136,7 @@ int relax_create(int device, relax_handle** out) {
     h->device = device;
     if (const char* e = getenv("RELAX_GEMM_SPLIT")) h->gemm.split_k = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_VARIANT")) h->gemm.variant = atoi(e);
+    if (const char* e = getenv("RELAX_GEMM_VARIANT_N64")) h->gemm.variant_n64 = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_GROUP_M")) h->gemm.group_m = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("RELAX_GEMM_PRIO")) h->gemm.prio = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_ABLATE")) h->gemm.ablate = atoi(e);
@@ -186,6 +187,7 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     const std::string k(key);
     if (k == "gemm_split_k") h->gemm.split_k = value;
     else if (k == "gemm_variant") h->gemm.variant = value;
+    else if (k == "gemm_variant_n64") h->gemm.variant_n64 = value;
     else if (k == "gemm_group_m") h->gemm.group_m = value > 0 ? value : 1;
     else if (k == "gemm_prio") h->gemm.prio = value;
     else if (k == "gemm_ablate") h->gemm.ablate = value;

@@ -54,8 +54,8 @@ __device__ inline float apply_act(float v, int act) {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool TAPS>
-__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_f32(const GemmParams p) {
+template <int BM, int BN, int WM, int WN, int BK, int OCC, bool TAPS>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int LDK = BK + 4;   // padded LDS row: conflict-free b128 writes and reads for BK = 32 (36) and 16 (20)
     constexpr int KL = BK / 4;    // lanes (float4) per K step of a row
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void splitk_finish(const GemmParams p) {
     *reinterpret_cast<f32x4*>(p.out + o) = v;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool TAPS>
+template <int BM, int BN, int WM, int WN, int BK, int OCC, bool TAPS>
 static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     p.tiles_n = p.N / BN;
@@ -377,12 +377,12 @@ static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hip
     constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * (BK + 4);
     static bool attr_set = false;
     if (!attr_set) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f32<BM, BN, WM, WN, BK, TAPS>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f32<BM, BN, WM, WN, BK, OCC, TAPS>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
-    hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, BK, TAPS>), dim3(units), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, BK, OCC, TAPS>), dim3(units), dim3(NT), lds, s, p);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((splitk_finish<BM, BN>), dim3(BM * BN / 4 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
     RELAX_HIP_CHECK(h, hipGetLastError());
@@ -396,9 +396,9 @@ static int ilog2_exact(int v) {
 }
 
 // tile variants: id -> <BM, BN, WM, WN>, workgroups resident per CU (LDS / VGPR bound)
-#define RELAX_DISPATCH(BM_, BN_, WM_, WN_, BK_, BPC_)                                        \
-    (taps ? launch_variant<BM_, BN_, WM_, WN_, BK_, true>(h, p, BPC_, s)                     \
-          : launch_variant<BM_, BN_, WM_, WN_, BK_, false>(h, p, BPC_, s))
+#define RELAX_DISPATCH(BM_, BN_, WM_, WN_, BK_, OCC_, BPC_)                                  \
+    (taps ? launch_variant<BM_, BN_, WM_, WN_, BK_, OCC_, true>(h, p, BPC_, s)               \
+          : launch_variant<BM_, BN_, WM_, WN_, BK_, OCC_, false>(h, p, BPC_, s))
 
 int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     GemmParams p{};
@@ -430,20 +430,22 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)(d.KH * d.KW * d.Cin);
     int span;
     RELAX_TRY(prof_begin(h, s, 0, flops, &span));
-    int variant = h->gemm.variant;
-    if (variant < 0 || (variant != 5 && variant != 6 && p.N % 128 != 0)) {
-        variant = (p.N % 128 == 0) ? 1 : 5;
-    }
+    // automatic choice: BK = 16 keeps three 128x128 workgroups (12 waves) per CU, which hides the prologue / epilogue of
+    // one tile under the MFMAs of the others (+8 % over BK = 32 with two workgroups, measured on config 3)
+    int variant = h->gemm.variant >= 0 ? h->gemm.variant : 7;
+    if (p.N % 128 != 0) variant = h->gemm.variant_n64 >= 0 ? h->gemm.variant_n64 : 10;
     int rc;
     switch (variant) {
-        case 1: rc = RELAX_DISPATCH(128, 128, 2, 2, 32, 2); break;   // 4 waves, 64x64 per wave
-        case 2: rc = RELAX_DISPATCH(128, 128, 2, 4, 32, 2); break;   // 8 waves, 64x32 per wave
-        case 3: rc = RELAX_DISPATCH(128, 128, 4, 2, 32, 2); break;   // 8 waves, 32x64 per wave
-        case 4: rc = RELAX_DISPATCH(256, 128, 4, 2, 32, 1); break;   // 8 waves, 64x64 per wave, 1 workgroup / CU
-        case 5: rc = RELAX_DISPATCH(128, 64, 2, 2, 32, 2); break;   // 4 waves, 64x32 per wave
-        case 6: rc = RELAX_DISPATCH(64, 64, 2, 2, 32, 4); break;
-        case 7: rc = RELAX_DISPATCH(128, 128, 2, 2, 16, 3); break;   // BK 16: 36.9 KB LDS -> 3 workgroups / CU
-        case 8: rc = RELAX_DISPATCH(128, 128, 2, 4, 16, 3); break;   // 8 waves, BK 16   // 4 waves, 32x32 per wave
+        case 1: rc = RELAX_DISPATCH(128, 128, 2, 2, 32, 1, 2); break;   // 4 waves, 64x64 per wave
+        case 2: rc = RELAX_DISPATCH(128, 128, 2, 4, 32, 1, 2); break;   // 8 waves, 64x32 per wave
+        case 3: rc = RELAX_DISPATCH(128, 128, 4, 2, 32, 1, 2); break;   // 8 waves, 32x64 per wave
+        case 4: rc = RELAX_DISPATCH(256, 128, 4, 2, 32, 1, 1); break;   // 8 waves, 64x64 per wave, 1 workgroup / CU
+        case 5: rc = RELAX_DISPATCH(128, 64, 2, 2, 32, 1, 2); break;   // 4 waves, 64x32 per wave
+        case 6: rc = RELAX_DISPATCH(64, 64, 2, 2, 32, 1, 4); break;
+        case 7: rc = RELAX_DISPATCH(128, 128, 2, 2, 16, 1, 3); break;   // BK 16: 36.9 KB LDS -> 3 workgroups / CU
+        case 8: rc = RELAX_DISPATCH(128, 128, 2, 4, 16, 1, 2); break;   // 8 waves, BK 16
+        case 9: rc = RELAX_DISPATCH(128, 128, 2, 2, 16, 4, 4); break;   // BK 16, registers capped for 4 workgroups / CU
+        case 10: rc = RELAX_DISPATCH(128, 64, 2, 2, 16, 1, 4); break;   // N = 64 layers, BK 16   // 4 waves, 32x32 per wave
         default:
             set_error(h, "conv/gemm: unknown tile variant %d", variant);
             return RELAX_ERR_INVALID;

@@ -128,7 +128,8 @@ namespace relax {
 // Tuning / reproducibility switches of the contraction kernel (relax_set_option; env defaults RELAX_GEMM_*).
 struct GemmOptions {
     int split_k = 1;   // "gemm_split_k": tail split-K on (1) / off (0: K sums are batch-invariant bit for bit)
-    int variant = -1;  // "gemm_variant": pin a tile variant (experiments), -1 = automatic
+    int variant = -1;  // "gemm_variant": pin the tile variant for N % 128 == 0 problems, -1 = automatic
+    int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)
     int group_m = 8;   // "gemm_group_m": row-tiles per L2 group
     int prio = 0;      // "gemm_prio": s_setprio around the MFMA cluster
     int ablate = 0;    // "gemm_ablate": timing-only ablations (results are WRONG): 1 barrier, 2 global loads, 4 LDS stores
