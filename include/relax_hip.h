@@ -117,6 +117,15 @@ int relax_gather_patches(relax_handle* h, const uint8_t* image, int64_t item_str
 int relax_merge_fragments(relax_handle* h, const uint8_t* a, const uint8_t* b, uint8_t* out, int64_t n_bytes,
                           relax_stream stream);
 
+/* ---- whole-frame front-end ------------------------------------------------------ */
+/* H x W -> 224 x 224, bit-identical to Pillow's 8-bit resample:
+ *   out_bilinear : what transforms.Resize((224,224)) gives a PIL image (src/extractor/visualise_resnet.py:40-47)
+ *   out_lanczos  : img.resize((224,224), Image.Resampling.LANCZOS)     (src/extractor/visualise_vit_layer.py:466-469)
+ * frames uint8 [H,W,3] per item (item n at frames + n*item_stride; channel order is irrelevant), outputs
+ * uint8 [N,224,224,3]; either output may be NULL.  One read of each frame serves both filters. */
+int relax_resize_frames(relax_handle* h, const uint8_t* frames, int64_t item_stride, int N, int H, int W,
+                        uint8_t* out_bilinear, uint8_t* out_lanczos, relax_stream stream);
+
 /* ---- stage B: backbones ---------------------------------------------------------------------- */
 /* ResNet-50 on N fragments (uint8 [N,224,224,3] BGR).  One forward per image yields everything
  * the reference gets from 15 hooked forwards + 1 avgpool forward:

@@ -150,6 +150,7 @@ int relax_destroy(relax_handle* h) {
     (void)hipDeviceSynchronize();
     free_resnet(h);
     free_vit(h);
+    free_resize(h);
     if (h->arena.p) (void)hipFree(h->arena.p);
     if (h->scratch.p) (void)hipFree(h->scratch.p);
     if (h->splitk_ws.p) (void)hipFree(h->splitk_ws.p);

@@ -106,6 +106,13 @@ struct VitW {
     std::vector<void*> allocs;
 };
 
+// ---- resize coefficient tables (Pillow-exact), cached per (input size, filter) ------------------------------
+struct ResizeTable {
+    int in_size = 0, filt = 0, ksize = 0;
+    int32_t* bounds = nullptr;  // device [224][2]: first tap, tap count
+    int32_t* coeffs = nullptr;  // device [224][ksize]: 22-bit fixed point
+};
+
 // ---- event profiling ----------------------------------------------------------------------------
 struct ProfSpan {
     hipEvent_t start, stop;
@@ -144,6 +151,8 @@ struct relax_handle {
     int reserved_images = 0;
     relax::DevBuf scratch;      // stage-A scratch (scores)
     relax::DevBuf splitk_ws;    // split-K partial tiles of the contraction kernel
+    relax::DevBuf resize_ws;    // uint8 intermediates of the two-pass resize
+    std::vector<relax::ResizeTable> resize_tables;
     relax::ResNet50W rn;
     relax::VitW vit;
     relax::Profiler prof;
@@ -182,6 +191,7 @@ int launch_nhwc_to_nchw(relax_handle* h, const float* x, float* y, int Nimg, int
 // model drivers
 void free_resnet(relax_handle* h);
 void free_vit(relax_handle* h);
+void free_resize(relax_handle* h);
 size_t resnet_arena_bytes(int n_images);
 size_t vit_arena_bytes(const VitW& v, int n_images);
 

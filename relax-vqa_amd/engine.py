@@ -178,6 +178,24 @@ class RelaxEngine:
                     "relax_merge_fragments")
         return out
 
+    def resize_frames(self, frames, bilinear=True, lanczos=True):
+        """frames uint8 [N,H,W,3] -> (bilinear, lanczos) uint8 [N,224,224,3] each (None if not requested), bit-identical
+        to PIL's Image.resize((224,224), BILINEAR / LANCZOS) (the reference's whole-frame inputs)."""
+        if isinstance(frames, np.ndarray):
+            frames = torch.from_numpy(np.ascontiguousarray(frames))
+        frames = frames.to(self.device, non_blocking=True)
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+            raise ValueError(f"frames must be uint8 [N,H,W,3], got {frames.dtype} {tuple(frames.shape)}")
+        N, H, W, _ = frames.shape
+        if frames.stride()[1:] != (W * 3, 3, 1):      # items may be strided (e.g. clip[:, 0]); pixels must be packed
+            frames = frames.contiguous()
+        item_stride = frames.stride(0) if N > 1 else H * W * 3
+        ob = torch.empty((N, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device) if bilinear else None
+        ol = torch.empty((N, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device) if lanczos else None
+        self._check(self.lib.relax_resize_frames(self.h, _ptr(frames), item_stride, N, H, W, _ptr(ob), _ptr(ol), _stream()),
+                    "relax_resize_frames")
+        return ob, ol
+
     # ---- stage B ------------------------------------------------------------------------------
     def _frags(self, frags):
         frags = self._dev_u8(frags)
@@ -262,6 +280,23 @@ class RelaxEngine:
             parts.append(torch.cat([pooled[:n], pooled[n:]], dim=1))
         per_frame = torch.cat(parts, dim=1)
         return torch.stack([chunk.mean(dim=0) for chunk in torch.split(per_frame, counts, dim=0)])
+
+    def whole_frame_features(self, frames):
+        """frames uint8 [N,H,W,3] BGR (whole sampled frames) -> (ResNet-50 layer-stack fp32 [N,13120], ViT pooled
+        fp32 [N,2304]): the per-frame features of src/main_layer_stack.py:81-151 / src/demo_test.py:81-87, with the
+        Pillow-exact resizes done on the GPU."""
+        bil, lan = self.resize_frames(frames)
+        ls, _ = self.resnet50_features(bil, layer_stack=True, pool=False)
+        _, vp = self.vit_features(lan, tokens=False, pooled=True)
+        return ls, vp
+
+    def full_clip_vector(self, frames, flow_images=None):
+        """frames uint8 [T,2,H,W,3] -> fp32 [35203]: the vector src/demo_test.py:171-175 assembles
+        (whole-frame ResNet-50 LS | whole-frame ViT | fragment ResNet-50 LS+pool | fragment ViT x2), each part averaged
+        over the sampled frames.  Without flow_images the residual fragment is the frame-difference fragment alone."""
+        f = self.extract_clip(frames, flow_images=flow_images)
+        ls, vp = self.whole_frame_features(frames[:, 0])
+        return torch.cat([ls.mean(dim=0), vp.mean(dim=0), f["resnet"].mean(dim=0), f["vit"].mean(dim=0)])
 
     def clip_vector(self, frames, **kw):
         """Per-clip mean over frames of the concatenated features (src/demo_test.py:171-175)."""

@@ -54,7 +54,7 @@ def process_fragment_array(frag_bgr_u8, all_layers):
 def process_video_frame(video_name, image_path, all_layers, qp):
     filename = os.path.basename(image_path)
     frame_number = _frame_number(filename)
-    img = runtime.require_fragment(runtime.read_image_bgr(image_path), "visualise_resnet.process_video_frame")
+    img = runtime.to_model_input(runtime.read_image_bgr(image_path), "resnet50")
     activations = process_fragment_array(img, all_layers)
     combined = "resnet50_feature_map_original" if qp == "original_ugc" else f"resnet50_feature_map_qp_{qp}"
     return activations, f"../features/resnet50/{video_name}/frame_{frame_number}_{combined}.npy"

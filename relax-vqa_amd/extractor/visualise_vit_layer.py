@@ -46,7 +46,7 @@ def process_fragment_array(frag_bgr_u8, model):
 def process_video_frame(image_path, video_name, qp, model, patch_size, device):
     filename = os.path.basename(image_path)
     frame_number = _frame_number(filename)
-    img = runtime.require_fragment(runtime.read_image_bgr(image_path), "visualise_vit_layer.process_video_frame")
+    img = runtime.to_model_input(runtime.read_image_bgr(image_path), "vit")
     feats = process_fragment_array(img, model)
     combined = "vit_feature_map_original" if qp == "original" else f"vit_feature_map_qp_{qp}"
     return feats, f"../features/vit/{video_name}/frame_attention_{frame_number}_{combined}.npy"

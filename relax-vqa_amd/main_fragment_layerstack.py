@@ -91,7 +91,8 @@ def get_deep_feature(network_name, video_name, image, qp, layer_name):
     png_path = f"../visualisation/{network_name}/{video_name}/"
     npy_path = f"../features/{network_name}/{video_name}/"
     if isinstance(image, str):
-        image = runtime.require_fragment(runtime.read_image_bgr(image), "get_deep_feature")
+        image = runtime.read_image_bgr(image)
+    image = runtime.to_model_input(image, network_name)   # whole frames: PIL-exact resize on the GPU (main_layer_stack.py)
     if network_name == "resnet50":
         if layer_name == "layer_stack":
             frame_npy = visualise_resnet.process_fragment_array(image, ALL_LAYERS)

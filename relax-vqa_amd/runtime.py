@@ -76,10 +76,13 @@ def read_image_bgr(image_path):
     return np.ascontiguousarray(rgb[..., ::-1])
 
 
-def require_fragment(img_bgr, what):
-    if img_bgr.shape[:2] != (224, 224):
-        raise NotImplementedError(
-            f"{what}: input is {img_bgr.shape[1]}x{img_bgr.shape[0]}; the whole-frame resize front-end "
-            "(PIL antialiased bilinear / LANCZOS to 224x224) is SURVEY §8(f) row f1 and is not built yet. "
-            "Fragments (224x224) are the supported input.")
-    return img_bgr
+def to_model_input(img_bgr, network_name):
+    """uint8 [H,W,3] -> uint8 [224,224,3] the way the reference's extractors do it: a fragment passes through; a whole
+    frame is resized on the GPU with PIL-exact BILINEAR (ResNet-50, torchvision Resize on a PIL image,
+    src/extractor/visualise_resnet.py:40-47) or LANCZOS (ViT, src/extractor/visualise_vit_layer.py:466-469)."""
+    if img_bgr.shape[:2] == (224, 224):
+        return img_bgr
+    eng = get_engine()
+    vit = network_name == "vit"
+    bil, lan = eng.resize_frames(img_bgr[None], bilinear=not vit, lanczos=vit)
+    return (lan if vit else bil)[0].cpu().numpy()

@@ -90,7 +90,38 @@ def test_unbuilt_rows_fail_loudly(api, tmp_path):
     m, _, _ = api
     with pytest.raises(NotImplementedError):
         m.flow_to_rgb(np.zeros((4, 4, 2), np.float32))
-    p = str(tmp_path / "frame_1.png")
-    Image.fromarray(np.zeros((64, 80, 3), np.uint8)).save(p)
     with pytest.raises(NotImplementedError):
-        m.get_deep_feature("resnet50", "v", p, "original", "layer_stack")   # whole-frame resize = SURVEY §8(f) f1
+        m.get_deep_feature("vgg16", "v", np.zeros((224, 224, 3), np.uint8), "original", "pool")
+
+
+def test_whole_frame_path_like_main_layer_stack(api, tmp_path):
+    """Whole sampled frames (src/main_layer_stack.py:81-151, src/demo_test.py:81-87): PIL-exact resize on the GPU, then
+    the same backbones; checked against PIL + oracle."""
+    m, rn, vit = api
+    g = np.random.default_rng(17)
+    frame = g.integers(0, 256, (270, 480, 3), dtype=np.uint8)          # BGR as cv2 holds it
+    p = str(tmp_path / "vid_3.png")
+    _write_png_bgr(p, frame)
+    _, _, a = m.get_deep_feature("resnet50", "vid", p, "original", "layer_stack")
+    _, _, c = m.get_deep_feature("vit", "vid", p, "original", "pool")
+    pil = Image.open(p)
+    rn_in = np.ascontiguousarray(np.asarray(pil.resize((224, 224), Image.BILINEAR))[..., ::-1])[None]
+    vit_in = np.ascontiguousarray(np.asarray(pil.resize((224, 224), Image.LANCZOS))[..., ::-1])[None]
+    want_ls = resnet50_ref.layer_stack_features(resnet50_ref.to_torch_state_dict(rn), rn_in)
+    assert_close(m.process_video_feature([a], "resnet50", "layer_stack"), want_ls, "whole-frame layer_stack")
+    want_tok = vit_ref.tokens(vit_ref.to_torch_state_dict(vit), vit_in, 12)[0]
+    assert_close(c, want_tok, "whole-frame vit tokens")
+
+
+def test_full_35203_vector(api):
+    from relax_vqa_amd import runtime
+    import torch
+    m, rn, vit = api
+    clip = synth.synthetic_clip(2, 272, 400, clip_id=12)
+    vec = runtime.get_engine().full_clip_vector(torch.from_numpy(clip).cuda()).cpu().numpy()
+    assert vec.shape == (35203,) and np.isfinite(vec).all()
+    # whole-frame block against PIL + oracle
+    from oracle import resize_ref
+    rn_in = np.stack([resize_ref.resize(clip[t, 0], 224, 224, resize_ref.BILINEAR) for t in range(2)])
+    want = resnet50_ref.layer_stack_features(resnet50_ref.to_torch_state_dict(rn), rn_in).mean(axis=0)
+    assert_close(vec[:13120], want, "full vector: whole-frame ResNet block")
