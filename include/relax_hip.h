@@ -144,6 +144,17 @@ int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float*
 int relax_vit_features(relax_handle* h, const uint8_t* frags, int N, float* tokens, float* pooled,
                        relax_stream stream);
 
+/* ---- quality head at inference --------------------------------------------------- */
+/* Replaces imputer.transform + scaler.transform + Mlp.forward (src/demo_test.py:177-208, src/model_regression.py:37-58).
+ * State-dict keys of the reference's Mlp (fc1/bn1/fc2/fc3; a 'module.' prefix is stripped and 'n_averaged' ignored as
+ * fix_state_dict does, demo_test.py:25-35); HOST pointers.  imputer_statistics = SimpleImputer.statistics_ (may be
+ * NULL), scaler_scale / scaler_min = MinMaxScaler.scale_ / .min_, all HOST float64 [input_features]. */
+int relax_load_mlp_head(relax_handle* h, const float* const* tensors, const char* const* names, const int64_t* numels,
+                        int n, const double* imputer_statistics, const double* scaler_scale, const double* scaler_min,
+                        int input_features);
+/* features: device fp32 [n, input_features] (the all-gathered per-clip vectors) -> scores: device fp32 [n]. */
+int relax_mlp_head(relax_handle* h, const float* features, int n, float* scores, relax_stream stream);
+
 /* ---- operator level (what the backbones are built from; parity-tested one by one) ------------ */
 /* out[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + residual[M,N]);  act: 0 none, 1 relu, 2 gelu(erf).
  * fp32 in, fp32 MFMA accumulate.  K % 32 == 0, N % 64 == 0.  bias/residual may be NULL. */

@@ -39,7 +39,7 @@ from PIL import Image  # noqa: E402
 
 import relax_vqa_amd  # noqa: E402,F401
 from relax_vqa_amd import synth  # noqa: E402
-from oracle import fragment_ref, pooling_ref, vit_ref  # noqa: E402
+from oracle import fragment_ref, mlp_ref, pooling_ref, vit_ref  # noqa: E402
 
 
 def sha(a):
@@ -206,9 +206,42 @@ def golden_vit(rv, report):
                                    shape=list(tokens.shape))
 
 
+def golden_mlp_head(report):
+    """The reference's Mlp class + its real KoNViD imputer/scaler pickles (model/scaler/*.pkl) on synthetic features."""
+    import warnings
+    import joblib
+    warnings.filterwarnings("ignore")
+    for m in ["seaborn", "matplotlib", "matplotlib.pyplot", "data_processing", "data_processing.split_train_test"]:
+        sys.modules[m] = mock.MagicMock()
+    sys.path.insert(0, REF_SRC)
+    import model_regression as mr
+    imp = joblib.load(os.path.join(REF, "model", "scaler", "konvid_1k_imputer.pkl"))
+    sc = joblib.load(os.path.join(REF, "model", "scaler", "konvid_1k_scaler.pkl"))
+    F_ = int(sc.scale_.shape[0])
+    assert F_ == 35203
+    g = np.random.Generator(np.random.PCG64(77))
+    u = g.uniform(-0.1, 1.1, (3, F_))
+    feats = (sc.data_min_ + u * (sc.data_max_ - sc.data_min_)).astype(np.float32)
+    feats[0, 5] = np.nan
+    feats[2, 20000:20010] = np.nan
+    sd_np = synth.mlp_head_state_dict(F_, 256, seed=23)
+    model = mr.Mlp(input_features=F_, out_features=1, drop_rate=0.2, act_layer=torch.nn.GELU)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd_np.items()}, strict=False)
+    model.eval()
+    x = sc.transform(imp.transform(feats))      # demo_test.py:179-180
+    with torch.no_grad():
+        want = model(torch.tensor(x, dtype=torch.float)).squeeze(-1).numpy()
+    mine = mlp_ref.predict(sd_np, feats, imp.statistics_, sc.scale_, sc.min_)
+    err = float(np.abs(mine - want).max() / np.abs(want).max())
+    assert err < 1e-6, err
+    np.savez_compressed(os.path.join(GOLD, "mlp_head.npz"), features=feats, imputer_statistics=imp.statistics_,
+                        scale=sc.scale_, min=sc.min_, expected=want)
+    report["mlp_head"] = dict(expected=[float(v) for v in want], restatement_vs_reference_maxrel=err, input_features=F_)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    report = dict(fragment_synthetic={}, fragment_png={}, pooling={}, vit={},
+    report = dict(fragment_synthetic={}, fragment_png={}, pooling={}, vit={}, mlp_head={},
                   numpy=np.__version__, torch=torch.__version__)
     mfl, mrf, mfp = import_reference_drivers()
     golden_fragment_synthetic(mfl, report)
@@ -216,6 +249,7 @@ def main():
     golden_pooling(mfl, mrf, mfp, report)
     rv = import_reference_vit()
     golden_vit(rv, report)
+    golden_mlp_head(report)
     with open(os.path.join(GOLD, "pin_report.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
     print(json.dumps(report, indent=1, sort_keys=True))

@@ -32,6 +32,9 @@ PROTOTYPES = {
     "relax_resize_frames": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
     "relax_resnet50_features": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, C.POINTER(c_vp), c_vp]),
     "relax_vit_features": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
+    "relax_load_mlp_head": (C.c_int, [c_vp, C.POINTER(c_vp), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int,
+                                      c_vp, c_vp, c_vp, C.c_int]),
+    "relax_mlp_head": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp]),
     "relax_op_gemm": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "relax_op_conv2d_nhwc": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [C.c_int] * 10 + [c_vp]),
     "relax_op_layernorm": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_float, c_vp]),

@@ -106,6 +106,16 @@ struct VitW {
     std::vector<void*> allocs;
 };
 
+// ---- quality head (imputer + scaler + MLP), BatchNorm folded into fc1 ----------------------------------------
+struct HeadW {
+    bool loaded = false;
+    int F = 0, Fpad = 0, H1 = 0, H2 = 0;
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr;
+    float b3 = 0.f;
+    double *stats = nullptr, *scale = nullptr, *mn = nullptr;
+    std::vector<void*> allocs;
+};
+
 // ---- resize coefficient tables (Pillow-exact), cached per (input size, filter) ------------------------------
 struct ResizeTable {
     int in_size = 0, filt = 0, ksize = 0;
@@ -152,6 +162,8 @@ struct relax_handle {
     relax::DevBuf scratch;      // stage-A scratch (scores)
     relax::DevBuf splitk_ws;    // split-K partial tiles of the contraction kernel
     relax::DevBuf resize_ws;    // uint8 intermediates of the two-pass resize
+    relax::DevBuf head_ws;      // scaled features + hidden activations of the quality head
+    relax::HeadW head;
     std::vector<relax::ResizeTable> resize_tables;
     relax::ResNet50W rn;
     relax::VitW vit;
@@ -192,6 +204,7 @@ int launch_nhwc_to_nchw(relax_handle* h, const float* x, float* y, int Nimg, int
 void free_resnet(relax_handle* h);
 void free_vit(relax_handle* h);
 void free_resize(relax_handle* h);
+void free_head(relax_handle* h);
 size_t resnet_arena_bytes(int n_images);
 size_t vit_arena_bytes(const VitW& v, int n_images);
 

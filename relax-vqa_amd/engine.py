@@ -100,6 +100,25 @@ class RelaxEngine:
         self.vit_dim = dim
         del keep
 
+    def load_mlp_head(self, state_dict, scaler_scale, scaler_min, imputer_statistics=None):
+        """state_dict: the reference Mlp's keys (src/model_regression.py:37-58); scaler_* / imputer_statistics: the
+        MinMaxScaler.scale_/.min_ and SimpleImputer.statistics_ arrays of the reference's model/scaler/*.pkl."""
+        ptrs, names, numels, n, keep = self._marshal_state_dict(state_dict)
+        sc = np.ascontiguousarray(scaler_scale, dtype=np.float64)
+        mn = np.ascontiguousarray(scaler_min, dtype=np.float64)
+        st = None if imputer_statistics is None else np.ascontiguousarray(imputer_statistics, dtype=np.float64)
+        rc = self.lib.relax_load_mlp_head(self.h, ptrs, names, numels, n, C.c_void_p(st.ctypes.data) if st is not None else None,
+                                          C.c_void_p(sc.ctypes.data), C.c_void_p(mn.ctypes.data), int(sc.size))
+        self._check(rc, "relax_load_mlp_head")
+        del keep
+
+    def mlp_head(self, features):
+        """features fp32 [n, F] on the device -> predicted scores fp32 [n] (src/demo_test.py:177-208)."""
+        features = features.to(self.device, torch.float32).contiguous()
+        out = torch.empty((features.shape[0],), dtype=torch.float32, device=self.device)
+        self._check(self.lib.relax_mlp_head(self.h, _ptr(features), features.shape[0], _ptr(out), _stream()), "relax_mlp_head")
+        return out
+
     def set_option(self, key, value):
         self._check(self.lib.relax_set_option(self.h, key.encode(), int(value)), "relax_set_option")
 

@@ -87,6 +87,27 @@ def vit_state_dict(name_model="vit_base", patch=16, seed=11):
     return sd
 
 
+def mlp_head_state_dict(input_features=35203, hidden=256, seed=23):
+    """fp32 numpy state dict with the key names of the reference's Mlp (src/model_regression.py:37-58)."""
+    g = _rng(seed)
+
+    def nrm(shape, std):
+        return g.standard_normal(shape, dtype=np.float32) * np.float32(std)
+
+    return {
+        "fc1.weight": nrm((hidden, input_features), input_features ** -0.5 * 4.0),
+        "fc1.bias": nrm((hidden,), 0.1),
+        "bn1.weight": g.uniform(0.5, 1.5, hidden).astype(np.float32),
+        "bn1.bias": nrm((hidden,), 0.1),
+        "bn1.running_mean": nrm((hidden,), 0.5),
+        "bn1.running_var": g.uniform(0.5, 2.0, hidden).astype(np.float32),
+        "fc2.weight": nrm((hidden // 2, hidden), hidden ** -0.5 * 2.0),
+        "fc2.bias": nrm((hidden // 2,), 0.1),
+        "fc3.weight": nrm((1, hidden // 2), (hidden // 2) ** -0.5 * 20.0),
+        "fc3.bias": np.float32([50.0]),
+    }
+
+
 def synthetic_pair(height, width, seed, patch=16, max_amp=64):
     """One (orig, next) pair, uint8 [H,W,3] BGR each.  next = clip(orig + noise)
     with a per-16x16-patch noise amplitude in {0..max_amp}, so patch scores are
