@@ -39,7 +39,7 @@ from PIL import Image  # noqa: E402
 
 import relax_vqa_amd  # noqa: E402,F401
 from relax_vqa_amd import synth  # noqa: E402
-from oracle import fragment_ref, mlp_ref, pooling_ref, vit_ref  # noqa: E402
+from oracle import flow_ref, fragment_ref, mlp_ref, pooling_ref, vit_ref  # noqa: E402
 
 
 def sha(a):
@@ -206,6 +206,30 @@ def golden_vit(rv, report):
                                    shape=list(tokens.shape))
 
 
+def pin_flow(report):
+    """Farneback + flow_to_rgb restatement against the reference's example `_residual_of.png` images (OpenCV 4.9 output
+    on real frame pairs): tolerance pin (float rounding differs from OpenCV's SIMD code)."""
+    base = os.path.join(REF, "visualisation", "visualisation_example")
+
+    def load(p):
+        return np.ascontiguousarray(np.asarray(Image.open(p).convert("RGB"))[..., ::-1])
+
+    for d, stem in [("original_5636101558", "5636101558_2"), ("original_5636101558", "5636101558_3"),
+                    ("original_5636101558", "5636101558_4"),
+                    ("original_TelevisionClip_1080P-68c6", "TelevisionClip_1080P-68c6_1")]:
+        p = os.path.join(base, d, stem)
+        orig, nxt, want = load(p + ".png"), load(p + "_next.png"), load(p + "_residual_of.png")
+        got = flow_ref.flow_to_rgb(flow_ref.farneback(flow_ref.bgr2gray(orig), flow_ref.bgr2gray(nxt)))
+        diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        wf, wp = fragment_ref.extract_important_patches(want, fragment_ref.get_patch_diff(want))
+        gf, gp = fragment_ref.extract_important_patches(got, fragment_ref.get_patch_diff(got))
+        same = len(set(map(tuple, wp.tolist())) & set(map(tuple, gp.tolist())))
+        report["flow_png"][stem] = dict(bytes_exact=float((diff == 0).mean()), bytes_within_1=float((diff <= 1).mean()),
+                                        max_abs_diff=int(diff.max()), positions_equal_of_196=same,
+                                        flow_fragment_bytes_exact=float((wf == gf).mean()))
+        assert (diff == 0).mean() > 0.995 and same >= 194, (stem, report["flow_png"][stem])
+
+
 def golden_mlp_head(report):
     """The reference's Mlp class + its real KoNViD imputer/scaler pickles (model/scaler/*.pkl) on synthetic features."""
     import warnings
@@ -241,7 +265,7 @@ def golden_mlp_head(report):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    report = dict(fragment_synthetic={}, fragment_png={}, pooling={}, vit={}, mlp_head={},
+    report = dict(fragment_synthetic={}, fragment_png={}, pooling={}, vit={}, mlp_head={}, flow_png={},
                   numpy=np.__version__, torch=torch.__version__)
     mfl, mrf, mfp = import_reference_drivers()
     golden_fragment_synthetic(mfl, report)
@@ -250,6 +274,7 @@ def main():
     rv = import_reference_vit()
     golden_vit(rv, report)
     golden_mlp_head(report)
+    pin_flow(report)
     with open(os.path.join(GOLD, "pin_report.json"), "w") as f:
         json.dump(report, f, indent=1, sort_keys=True)
     print(json.dumps(report, indent=1, sort_keys=True))
