@@ -117,6 +117,18 @@ int relax_gather_patches(relax_handle* h, const uint8_t* image, int64_t item_str
 int relax_merge_fragments(relax_handle* h, const uint8_t* a, const uint8_t* b, uint8_t* out, int64_t n_bytes,
                           relax_stream stream);
 
+/* ---- optical flow --------------------------------------------------------------- */
+/* Replaces cv2.calcOpticalFlowFarneback(gray(orig), gray(next), None, 0.5, 3, 15, 3, 5, 1.2, 0) and flow_to_rgb
+ * (src/main_fragment_layerstack.py:313-316, 162-175; src/main_residual_fragment.py:283-287).  Parameters are the
+ * reference's literals.  orig/next as in relax_fragment_pairs.
+ *   flow     : fp32 [T,H,W,2] (dx,dy)                       (may be NULL)
+ *   flow_bgr : uint8 [T,H,W,3] the visualisation image that process_patches('optical_flow', ...) consumes (may be NULL)
+ * OpenCV's algorithm restated (not ported); parity is by tolerance against the reference's example flow PNGs. */
+int relax_optical_flow(relax_handle* h, const uint8_t* orig, const uint8_t* next, int64_t pair_stride, int T, int H, int W,
+                       float* flow, uint8_t* flow_bgr, relax_stream stream);
+/* flow_to_rgb alone: fp32 [T,H,W,2] -> uint8 [T,H,W,3] (BGR, despite the reference's name). */
+int relax_flow_to_rgb(relax_handle* h, const float* flow, int T, int H, int W, uint8_t* flow_bgr, relax_stream stream);
+
 /* ---- whole-frame front-end ------------------------------------------------------ */
 /* H x W -> 224 x 224, bit-identical to Pillow's 8-bit resample:
  *   out_bilinear : what transforms.Resize((224,224)) gives a PIL image (src/extractor/visualise_resnet.py:40-47)

@@ -29,6 +29,8 @@ PROTOTYPES = {
                                        c_vp, c_vp, c_vp, c_vp, c_vp]),
     "relax_gather_patches": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp]),
     "relax_merge_fragments": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, c_vp]),
+    "relax_optical_flow": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
+    "relax_flow_to_rgb": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
     "relax_resize_frames": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
     "relax_resnet50_features": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, C.POINTER(c_vp), c_vp]),
     "relax_vit_features": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),

@@ -153,6 +153,7 @@ int relax_destroy(relax_handle* h) {
     free_resize(h);
     free_head(h);
     if (h->head_ws.p) (void)hipFree(h->head_ws.p);
+    if (h->flow_ws.p) (void)hipFree(h->flow_ws.p);
     if (h->arena.p) (void)hipFree(h->arena.p);
     if (h->scratch.p) (void)hipFree(h->scratch.p);
     if (h->splitk_ws.p) (void)hipFree(h->splitk_ws.p);

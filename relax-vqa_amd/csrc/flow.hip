@@ -1,0 +1,515 @@
+// Farneback dense optical flow + the reference's flow visualisation on gfx950.
+//
+// Reference call sites (xinyiW915/ReLaX-VQA):
+//   src/main_fragment_layerstack.py:313-315  cv2.calcOpticalFlowFarneback(gray(orig), gray(next), None, 0.5, 3, 15, 3, 5, 1.2, 0)
+//   src/main_fragment_layerstack.py:162-175  flow_to_rgb (cartToPolar, NORM_MINMAX, hue = ang*180/pi/2, HSV -> BGR)
+// The algorithm is OpenCV's (opencv-python 4.9, modules/video/src/optflowgf.cpp), restated - not ported from source,
+// which is not available here - and pinned by tolerance to the reference's example flow PNGs (oracle/flow_ref.py).
+// All stages are HBM-bound streaming kernels, batched over the pairs of a clip (one launch per stage per pyramid
+// level for ALL pairs, so the coarse levels still fill the chip):
+//   gray (fixed-point BGR2GRAY) -> per level: Gaussian blur of the full-resolution frame (3/3/9/19 taps, reflect-101)
+//   -> linear resize -> polynomial expansion (vertical + horizontal pass) -> matrix update -> 3 x (15x15 box blur in
+//   double + 2x2 solve [-> matrix update]) -> x2 linear upsampling of the flow into the next finer level.
+// Then: magnitude min/max reduction, fastAtan2, normalisation, 8-bit HSV -> BGR (float formula, truncated).
+#include <cfloat>
+#include <cmath>
+
+#include "relax_internal.h"
+
+namespace relax {
+
+constexpr int POLY_N = 5;
+constexpr int WINSIZE = 15;
+constexpr int ITERS = 3;
+constexpr int MAX_GAUSS = 32;
+
+struct PolyConsts {
+    float g[POLY_N + 1], xg[POLY_N + 1], xxg[POLY_N + 1];
+    double ig11, ig03, ig33, ig55;
+};
+struct GaussKernel {
+    float k[MAX_GAUSS];
+    int ksize;
+};
+
+__device__ inline int reflect101(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);   // (only reached for n smaller than the kernel radius)
+}
+__device__ inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+
+// uint8 BGR frame pair -> float gray [P][2][H][W]; (B*1868 + G*9617 + R*4899 + 2^13) >> 14
+__global__ __launch_bounds__(256) void flow_gray(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ next,
+                                                 int64_t pair_stride, int HW, float* __restrict__ gray, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int pix = (int)(i % HW);
+    const int64_t img = i / HW;            // pair * 2 + which
+    const uint8_t* src = ((img & 1) ? next : orig) + (img >> 1) * pair_stride + (int64_t)pix * 3;
+    gray[i] = (float)(((int)src[0] * 1868 + (int)src[1] * 9617 + (int)src[2] * 4899 + (1 << 13)) >> 14);
+}
+
+template <bool VERTICAL>
+__global__ __launch_bounds__(256) void gauss_pass(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                  GaussKernel gk, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const float* img = src + (i / ((int64_t)W * H)) * ((int64_t)W * H);
+    const int r = gk.ksize / 2;
+    float acc = 0.f;
+    for (int t = 0; t < gk.ksize; ++t) {
+        const float v = VERTICAL ? img[(int64_t)reflect101(y + t - r, H) * W + x] : img[(int64_t)y * W + reflect101(x + t - r, W)];
+        acc += gk.k[t] * v;
+    }
+    dst[i] = acc;
+}
+
+// cv::resize INTER_LINEAR on float [B][H][W][C] -> [B][h][w][C], result scaled by mul (flow upsampling: 1/pyr_scale)
+__global__ __launch_bounds__(256) void resize_linear_f32(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                         int h, int w, int C, double scale_y, double scale_x, float mul,
+                                                         int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int dx = (int)((i / C) % w);
+    const int dy = (int)((i / ((int64_t)C * w)) % h);
+    const int64_t b = i / ((int64_t)C * w * h);
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= W - 1) { fx = 0.f; sx = W - 1; }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    if (sy < 0) { fy = 0.f; sy = 0; }
+    if (sy >= H - 1) { fy = 0.f; sy = H - 1; }
+    const int sx1 = sx + 1 < W ? sx + 1 : W - 1;
+    const int sy1 = sy + 1 < H ? sy + 1 : H - 1;
+    const float* im = src + b * ((int64_t)H * W * C);
+    const float r0 = im[((int64_t)sy * W + sx) * C + c] * (1.f - fx) + im[((int64_t)sy * W + sx1) * C + c] * fx;
+    const float r1 = im[((int64_t)sy1 * W + sx) * C + c] * (1.f - fx) + im[((int64_t)sy1 * W + sx1) * C + c] * fx;
+    dst[i] = (r0 * (1.f - fy) + r1 * fy) * mul;
+}
+
+// FarnebackPolyExp, vertical part: I [B][h][w] -> T [B][h][w][3]
+__global__ __launch_bounds__(256) void poly_vertical(const float* __restrict__ I, float* __restrict__ T, int h, int w,
+                                                     PolyConsts pc, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % w);
+    const int y = (int)((i / w) % h);
+    const float* img = I + (i / ((int64_t)w * h)) * ((int64_t)w * h);
+    float t0 = img[(int64_t)y * w + x] * pc.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int k = 1; k <= POLY_N; ++k) {
+        const float up = img[(int64_t)(y - k < 0 ? 0 : y - k) * w + x];
+        const float dn = img[(int64_t)(y + k > h - 1 ? h - 1 : y + k) * w + x];
+        const float p = up + dn;
+        t0 += pc.g[k] * p;
+        t1 += pc.xg[k] * (dn - up);
+        t2 += pc.xxg[k] * p;
+    }
+    T[i * 3] = t0;
+    T[i * 3 + 1] = t1;
+    T[i * 3 + 2] = t2;
+}
+
+// horizontal part (replicated border), double accumulators as in OpenCV: T -> R [B][h][w][5]
+__global__ __launch_bounds__(256) void poly_horizontal(const float* __restrict__ T, float* __restrict__ R, int h, int w,
+                                                       PolyConsts pc, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % w);
+    const float* row = T + (i - x) * 3;
+    double b1 = row[x * 3] * pc.g[0], b2 = 0, b3 = row[x * 3 + 1] * pc.g[0], b4 = 0, b5 = row[x * 3 + 2] * pc.g[0], b6 = 0;
+#pragma unroll
+    for (int k = 1; k <= POLY_N; ++k) {
+        const float* p = row + (x + k > w - 1 ? w - 1 : x + k) * 3;
+        const float* m = row + (x - k < 0 ? 0 : x - k) * 3;
+        const double tg = p[0] + m[0];
+        b1 += tg * pc.g[k];
+        b4 += tg * pc.xxg[k];
+        b2 += (p[0] - m[0]) * pc.xg[k];
+        b3 += (p[1] + m[1]) * pc.g[k];
+        b6 += (p[1] - m[1]) * pc.xg[k];
+        b5 += (p[2] + m[2]) * pc.g[k];
+    }
+    float* o = R + i * 5;
+    o[1] = (float)(b2 * pc.ig11);
+    o[0] = (float)(b3 * pc.ig11);
+    o[3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+    o[2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+    o[4] = (float)(b6 * pc.ig55);
+}
+
+// FarnebackUpdateMatrices: R [P][2][h][w][5], flow [P][h][w][2] -> M [P][h][w][5]
+__global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict__ R, const float* __restrict__ flow,
+                                                         float* __restrict__ M, int h, int w, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % w);
+    const int y = (int)((i / w) % h);
+    const int64_t pair = i / ((int64_t)w * h);
+    const int64_t hw = (int64_t)w * h;
+    const float* R0 = R + (pair * 2) * hw * 5 + ((int64_t)y * w + x) * 5;
+    const float* R1 = R + (pair * 2 + 1) * hw * 5;
+    const float dx = flow[i * 2], dy = flow[i * 2 + 1];
+    float fx = x + dx, fy = y + dy;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    fx -= x1;
+    fy -= y1;
+    float r2, r3, r4, r5, r6;
+    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const float* p = R1 + ((int64_t)y1 * w + x1) * 5;
+        const int64_t st = (int64_t)w * 5;
+        r2 = a00 * p[0] + a01 * p[5] + a10 * p[st] + a11 * p[st + 5];
+        r3 = a00 * p[1] + a01 * p[6] + a10 * p[st + 1] + a11 * p[st + 6];
+        r4 = a00 * p[2] + a01 * p[7] + a10 * p[st + 2] + a11 * p[st + 7];
+        r5 = a00 * p[3] + a01 * p[8] + a10 * p[st + 3] + a11 * p[st + 8];
+        r6 = a00 * p[4] + a01 * p[9] + a10 * p[st + 4] + a11 * p[st + 9];
+        r4 = (R0[2] + r4) * 0.5f;
+        r5 = (R0[3] + r5) * 0.5f;
+        r6 = (R0[4] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[2];
+        r5 = R0[3];
+        r6 = R0[4] * 0.5f;
+    }
+    r2 = (R0[0] - r2) * 0.5f;
+    r3 = (R0[1] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    const int BORDER = 5;
+    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+        const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        const float sc = (x < BORDER ? border[x] : 1.f) * (x >= w - BORDER ? border[w - x - 1] : 1.f) *
+                         (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
+        r2 *= sc; r3 *= sc; r4 *= sc; r5 *= sc; r6 *= sc;
+    }
+    float* o = M + i * 5;
+    o[0] = r4 * r4 + r6 * r6;
+    o[1] = (r4 + r5) * r6;
+    o[2] = r5 * r5 + r6 * r6;
+    o[3] = r4 * r2 + r6 * r3;
+    o[4] = r6 * r2 + r5 * r3;
+}
+
+// 15-row box sum (replicated border) in double: M [P][h][w][5] -> VS [P][h][w][5]
+__global__ __launch_bounds__(256) void box_vertical(const float* __restrict__ M, double* __restrict__ VS, int h, int w,
+                                                    int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over P*h*w*5
+    if (i >= total) return;
+    const int64_t row5 = (int64_t)w * 5;
+    const int col = (int)(i % row5);
+    const int y = (int)((i / row5) % h);
+    const float* img = M + (i / (row5 * h)) * (row5 * h);
+    double s = 0;
+#pragma unroll
+    for (int j = -WINSIZE / 2; j <= WINSIZE / 2; ++j) s += img[(int64_t)clampi(y + j, 0, h - 1) * row5 + col];
+    VS[i] = s;
+}
+
+// 15-column box sum + the 2x2 solve: VS -> flow [P][h][w][2]
+__global__ __launch_bounds__(256) void box_horizontal_solve(const double* __restrict__ VS, float* __restrict__ flow, int h,
+                                                            int w, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over P*h*w
+    if (i >= total) return;
+    const int x = (int)(i % w);
+    const double* row = VS + (i - x) * 5;
+    double g11 = 0, g12 = 0, g22 = 0, h1 = 0, h2 = 0;
+#pragma unroll
+    for (int j = -WINSIZE / 2; j <= WINSIZE / 2; ++j) {
+        const double* p = row + clampi(x + j, 0, w - 1) * 5;
+        g11 += p[0]; g12 += p[1]; g22 += p[2]; h1 += p[3]; h2 += p[4];
+    }
+    const double sc = 1.0 / (WINSIZE * WINSIZE);
+    g11 *= sc; g12 *= sc; g22 *= sc; h1 *= sc; h2 *= sc;
+    const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
+    flow[i * 2] = (float)((g11 * h2 - g12 * h1) * idet);
+    flow[i * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+}
+
+// ---- flow_to_rgb ------------------------------------------------------------------------------------------------
+__device__ inline float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / M_PI), p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    const float p5 = 0.1555786518463281f * (float)(180 / M_PI), p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// per-pair min / max of the flow magnitude (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void mag_minmax(const float* __restrict__ flow, int HW, unsigned* __restrict__ mm) {
+    __shared__ unsigned smin[256], smax[256];
+    const int pair = blockIdx.y;
+    const float* f = flow + (int64_t)pair * HW * 2;
+    unsigned lo = 0xffffffffu, hi = 0u;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        const float x = f[i * 2], y = f[i * 2 + 1];
+        const unsigned u = __float_as_uint(sqrtf(x * x + y * y));
+        lo = u < lo ? u : lo;
+        hi = u > hi ? u : hi;
+    }
+    smin[threadIdx.x] = lo;
+    smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) {
+            smin[threadIdx.x] = smin[threadIdx.x + s] < smin[threadIdx.x] ? smin[threadIdx.x + s] : smin[threadIdx.x];
+            smax[threadIdx.x] = smax[threadIdx.x + s] > smax[threadIdx.x] ? smax[threadIdx.x + s] : smax[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMin(&mm[pair], smin[0]);                 // mins [0,P), maxs [P,2P)
+        atomicMax(&mm[gridDim.y + pair], smax[0]);
+    }
+}
+
+__device__ inline void minmax_affine(double smin, double smax, float* scale, float* shift) {
+    const double d = smax - smin;
+    const double sc = 255.0 * (d > DBL_EPSILON ? 1.0 / d : 0.0);
+    *scale = (float)sc;
+    *shift = (float)(0.0 - smin * sc);
+}
+
+__global__ __launch_bounds__(256) void flow_visualise(const float* __restrict__ flow, const unsigned* __restrict__ mm, int P, int HW,
+                                                      uint8_t* __restrict__ bgr, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int pair = (int)(i / HW);
+    const float x = flow[i * 2], y = flow[i * 2 + 1];
+    float mag = sqrtf(x * x + y * y);
+    const float ang = fast_atan2_deg(y, x) * (float)(M_PI / 180);
+    // mag = normalize(mag); V = trunc(normalize(mag)): the 2nd min/max are the images of the 1st (monotone affine map)
+    float s1, b1, s2, b2;
+    const float mn = __uint_as_float(mm[pair]), mx = __uint_as_float(mm[P + pair]);
+    minmax_affine(mn, mx, &s1, &b1);
+    mag = mag * s1 + b1;
+    minmax_affine((double)(mn * s1 + b1), (double)(mx * s1 + b1), &s2, &b2);
+    const float vf = mag * s2 + b2;
+    const float hue = ang * 180.f / (float)M_PI / 2.f;
+    const int Hh = (int)(uint8_t)(int)hue;              // numpy float32 -> uint8 assignment truncates
+    const int Vv = (int)(uint8_t)(int)vf;
+    // 8-bit HSV -> BGR, S = 255: OpenCV's float formula, converted by truncation (oracle/flow_ref.py)
+    const float hh = (float)Hh * (6.0f / 180.0f);
+    int sector = (int)floorf(hh);
+    const float f = hh - (float)sector;
+    sector %= 6;
+    const float s = 255.f * (1.0f / 255.0f), v = (float)Vv * (1.0f / 255.0f);
+    const float tab[4] = {v, v * (1.f - s), v * (1.f - s * f), v * (1.f - s * (1.f - f))};
+    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    uint8_t* o = bgr + i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float t = floorf(tab[sd[sector][c]] * 255.f);
+        o[c] = (uint8_t)(t < 0.f ? 0.f : (t > 255.f ? 255.f : t));
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------
+static void prepare_poly(PolyConsts* pc) {
+    const int n = POLY_N;
+    const double sigma = 1.2;
+    float g[2 * POLY_N + 1];
+    double s = 0.;
+    for (int x = -n; x <= n; ++x) {
+        g[x + n] = (float)std::exp(-x * x / (2 * sigma * sigma));
+        s += g[x + n];
+    }
+    s = 1. / s;
+    float xg[2 * POLY_N + 1], xxg[2 * POLY_N + 1];
+    for (int x = -n; x <= n; ++x) {
+        g[x + n] = (float)(g[x + n] * s);
+        xg[x + n] = (float)(x * g[x + n]);
+        xxg[x + n] = (float)(x * x * g[x + n]);
+    }
+    double G00 = 0, G11 = 0, G33 = 0, G55 = 0;
+    for (int y = -n; y <= n; ++y)
+        for (int x = -n; x <= n; ++x) {
+            const double w = (double)g[y + n] * g[x + n];
+            G00 += w;
+            G11 += w * x * x;
+            G33 += w * x * x * x * x;
+            G55 += w * x * x * y * y;
+        }
+    // invert the 6x6 moment matrix: rows/cols {0,3,4} couple ([G00 G11 G11; G11 G33 G55; G11 G55 G33]), 1, 2, 5 are diagonal
+    const double a = G00, b = G11, c = G33, d = G55;
+    const double det = a * (c * c - d * d) - 2.0 * b * b * (c - d);
+    pc->ig11 = 1.0 / G11;
+    pc->ig03 = (b * d - b * c) / det;          // cofactor (0,3) / det (symmetric)
+    pc->ig33 = (a * c - b * b) / det;
+    pc->ig55 = 1.0 / G55;
+    for (int k = 0; k <= n; ++k) {
+        pc->g[k] = g[k + n];
+        pc->xg[k] = xg[k + n];
+        pc->xxg[k] = xxg[k + n];
+    }
+}
+
+static void make_gauss(int ksize, double sigma, GaussKernel* gk) {
+    gk->ksize = ksize;
+    if (ksize == 3 && sigma <= 0) {
+        gk->k[0] = 0.25f; gk->k[1] = 0.5f; gk->k[2] = 0.25f;
+        return;
+    }
+    const double s = sigma > 0 ? sigma : ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8;
+    double sum = 0;
+    for (int i = 0; i < ksize; ++i) {
+        const double x = i - (ksize - 1) * 0.5;
+        gk->k[i] = (float)std::exp(-0.5 / (s * s) * x * x);
+        sum += gk->k[i];
+    }
+    const float inv = (float)(1.0 / sum);
+    for (int i = 0; i < ksize; ++i) gk->k[i] *= inv;
+}
+
+static inline unsigned nblocks(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+static int visualise(relax_handle* h, const float* flow, int P, int HW, uint8_t* bgr, unsigned* mm, hipStream_t s) {
+    RELAX_HIP_CHECK(h, hipMemsetAsync(mm, 0xff, sizeof(unsigned) * P, s));       // running minima
+    RELAX_HIP_CHECK(h, hipMemsetAsync(mm + P, 0, sizeof(unsigned) * P, s));       // running maxima
+    hipLaunchKernelGGL(mag_minmax, dim3(64, P), dim3(256), 0, s, flow, HW, mm);
+    const int64_t tot = (int64_t)P * HW;
+    hipLaunchKernelGGL(flow_visualise, dim3(nblocks(tot)), dim3(256), 0, s, flow, mm, P, HW, bgr, tot);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next, int64_t pair_stride, int P, int H, int W,
+                      float* flow_out, uint8_t* bgr_out, hipStream_t s) {
+    const int64_t HW = (int64_t)H * W;
+    // workspace carve (floats unless noted), all sized for level 0
+    const size_t per_pair = (size_t)HW * (2 + 2 + 2 + 2 + 6 + 10 + 5 + 2 + 2) * sizeof(float) + (size_t)HW * 5 * sizeof(double) + 16;
+    RELAX_TRY(ensure_buf(h, h->flow_ws, per_pair * P));
+    float* gray = static_cast<float*>(h->flow_ws.p);
+    float* tmp = gray + (size_t)P * 2 * HW;
+    float* blur = tmp + (size_t)P * 2 * HW;
+    float* I = blur + (size_t)P * 2 * HW;
+    float* T = I + (size_t)P * 2 * HW;         // [P*2][h][w][3]
+    float* R = T + (size_t)P * 6 * HW;         // [P][2][h][w][5]
+    float* M = R + (size_t)P * 10 * HW;        // [P][h][w][5]
+    float* flowA = M + (size_t)P * 5 * HW;     // [P][h][w][2]
+    float* flowB = flowA + (size_t)P * 2 * HW;
+    double* VS = reinterpret_cast<double*>(flowB + (size_t)P * 2 * HW);
+    unsigned* mm = reinterpret_cast<unsigned*>(VS + (size_t)P * 5 * HW);
+
+    PolyConsts pc;
+    prepare_poly(&pc);
+    const int64_t tot_px2 = (int64_t)P * 2 * HW;
+    hipLaunchKernelGGL(flow_gray, dim3(nblocks(tot_px2)), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray, tot_px2);
+
+    int levels = 0;
+    {
+        double sc = 1.0;
+        for (; levels < 3; ++levels) {
+            sc *= 0.5;
+            if (W * sc < 32 || H * sc < 32) break;
+        }
+    }
+    float* prev_flow = nullptr;
+    int ph = 0, pw = 0;
+    float* cur = flowA;
+    for (int k = levels; k >= 0; --k) {
+        double scale = 1.0;
+        for (int i = 0; i < k; ++i) scale *= 0.5;
+        const double sigma = (1. / scale - 1) * 0.5;
+        int smooth = (int)lrint(sigma * 5) | 1;
+        if (smooth < 3) smooth = 3;
+        RELAX_REQUIRE(h, smooth <= MAX_GAUSS, "optical flow: smoothing kernel %d too large", smooth);
+        const int w = (int)lrint(W * scale), hh = (int)lrint(H * scale);
+        const int64_t hw = (int64_t)w * hh;
+        if (!prev_flow) {
+            RELAX_HIP_CHECK(h, hipMemsetAsync(cur, 0, sizeof(float) * P * 2 * hw, s));
+        } else {
+            const int64_t tot = (int64_t)P * hw * 2;
+            hipLaunchKernelGGL(resize_linear_f32, dim3(nblocks(tot)), dim3(256), 0, s, prev_flow, cur, ph, pw, hh, w, 2,
+                               (double)ph / hh, (double)pw / w, 2.0f, tot);
+        }
+        GaussKernel gk;
+        make_gauss(smooth, sigma, &gk);
+        hipLaunchKernelGGL(gauss_pass<false>, dim3(nblocks(tot_px2)), dim3(256), 0, s, gray, tmp, H, W, gk, tot_px2);
+        hipLaunchKernelGGL(gauss_pass<true>, dim3(nblocks(tot_px2)), dim3(256), 0, s, tmp, blur, H, W, gk, tot_px2);
+        const float* Isrc = blur;
+        const int64_t tot_l2 = (int64_t)P * 2 * hw;
+        if (w != W || hh != H) {
+            hipLaunchKernelGGL(resize_linear_f32, dim3(nblocks(tot_l2)), dim3(256), 0, s, blur, I, H, W, hh, w, 1,
+                               (double)H / hh, (double)W / w, 1.0f, tot_l2);
+            Isrc = I;
+        }
+        hipLaunchKernelGGL(poly_vertical, dim3(nblocks(tot_l2)), dim3(256), 0, s, Isrc, T, hh, w, pc, tot_l2);
+        hipLaunchKernelGGL(poly_horizontal, dim3(nblocks(tot_l2)), dim3(256), 0, s, T, R, hh, w, pc, tot_l2);
+        const int64_t tot_l = (int64_t)P * hw;
+        hipLaunchKernelGGL(update_matrices_k, dim3(nblocks(tot_l)), dim3(256), 0, s, R, cur, M, hh, w, tot_l);
+        for (int it = 0; it < ITERS; ++it) {
+            hipLaunchKernelGGL(box_vertical, dim3(nblocks(tot_l * 5)), dim3(256), 0, s, M, VS, hh, w, tot_l * 5);
+            hipLaunchKernelGGL(box_horizontal_solve, dim3(nblocks(tot_l)), dim3(256), 0, s, VS, cur, hh, w, tot_l);
+            if (it < ITERS - 1)
+                hipLaunchKernelGGL(update_matrices_k, dim3(nblocks(tot_l)), dim3(256), 0, s, R, cur, M, hh, w, tot_l);
+        }
+        prev_flow = cur;
+        ph = hh;
+        pw = w;
+        cur = (cur == flowA) ? flowB : flowA;
+    }
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    if (flow_out)
+        RELAX_HIP_CHECK(h, hipMemcpyAsync(flow_out, prev_flow, sizeof(float) * P * 2 * HW, hipMemcpyDeviceToDevice, s));
+    if (bgr_out) RELAX_TRY(visualise(h, prev_flow, P, (int)HW, bgr_out, mm, s));
+    return RELAX_OK;
+}
+
+}  // namespace relax
+
+using namespace relax;
+
+extern "C" {
+
+int relax_optical_flow(relax_handle* h, const uint8_t* orig, const uint8_t* next, int64_t pair_stride, int T, int H, int W,
+                       float* flow, uint8_t* flow_bgr, relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, orig && next && T > 0 && H >= 16 && W >= 16, "relax_optical_flow: bad arguments");
+    RELAX_REQUIRE(h, flow || flow_bgr, "relax_optical_flow: no output requested");
+    RELAX_REQUIRE(h, pair_stride >= (int64_t)H * W * 3 || T == 1, "relax_optical_flow: pair stride smaller than a frame");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // bound the workspace: ~ 212 B per pixel per pair; keep chunks under ~6 GB
+    const int64_t HW = (int64_t)H * W;
+    int chunk = (int)((6ll << 30) / (HW * 212));
+    if (chunk < 1) chunk = 1;
+    if (chunk > T) chunk = T;
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+        const int P = T - t0 < chunk ? T - t0 : chunk;
+        RELAX_TRY(flow_chunk(h, orig + t0 * pair_stride, next + t0 * pair_stride, pair_stride, P, H, W,
+                             flow ? flow + (int64_t)t0 * HW * 2 : nullptr, flow_bgr ? flow_bgr + (int64_t)t0 * HW * 3 : nullptr, s));
+    }
+    return RELAX_OK;
+}
+
+
+int relax_flow_to_rgb(relax_handle* h, const float* flow, int T, int H, int W, uint8_t* flow_bgr, relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, flow && flow_bgr && T > 0 && H > 0 && W > 0, "relax_flow_to_rgb: bad arguments");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned) * 2 * (size_t)T));
+    return visualise(h, flow, T, H * W, flow_bgr, static_cast<unsigned*>(h->scratch.p), static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -162,6 +162,7 @@ struct relax_handle {
     relax::DevBuf scratch;      // stage-A scratch (scores)
     relax::DevBuf splitk_ws;    // split-K partial tiles of the contraction kernel
     relax::DevBuf resize_ws;    // uint8 intermediates of the two-pass resize
+    relax::DevBuf flow_ws;      // optical-flow pyramid workspace
     relax::DevBuf head_ws;      // scaled features + hidden activations of the quality head
     relax::HeadW head;
     std::vector<relax::ResizeTable> resize_tables;

@@ -1,8 +1,8 @@
 """Counterpart of the reference's end-to-end demo (src/demo_test.py:51-219) on in-memory frames: the full 35203-d
 clip vector (whole-frame + fragment features of both backbones) through imputer, scaler and the MLP head, all on the
 GPU.  ffmpeg sampling (src/extractor/vf_extract.py) is out of scope: the caller supplies the sampled (frame, next)
-pairs, uint8 [T,2,H,W,3] BGR.  Optical flow is SURVEY §8(f) f2: pass `flow_images` computed elsewhere, or leave it out
-(the residual fragment is then the frame-difference fragment, the deviation BASELINE config 2-4 state)."""
+pairs, uint8 [T,2,H,W,3] BGR.  With flow=True (default) the residual fragment is the reference's 50/50 merge of the
+frame-difference and optical-flow fragments (Farneback + flow_to_rgb on the GPU)."""
 import numpy as np
 import torch
 
@@ -21,7 +21,7 @@ def load_head(state_dict, imputer, scaler):
     runtime.get_engine().load_mlp_head(sd, scale, mn, stats)
 
 
-def evaluate_video_quality(frames, video_type="konvid_1k", is_finetune=False, flow_images=None):
+def evaluate_video_quality(frames, video_type="konvid_1k", is_finetune=False, flow_images=None, flow=True):
     """frames uint8 [T,2,H,W,3] (numpy or device tensor) -> predicted quality score (float).
     Rescaling rule of src/demo_test.py:211-219: non-fine-tuned models on youtube_ugc / konvid_1k map 0-100 to 1-5."""
     eng = runtime.ensure_vit("vit_base")
@@ -29,8 +29,8 @@ def evaluate_video_quality(frames, video_type="konvid_1k", is_finetune=False, fl
     if isinstance(frames, np.ndarray):
         frames = torch.from_numpy(frames)
     frames = frames.to(eng.device)
-    flow = None if flow_images is None else torch.as_tensor(flow_images).to(eng.device)
-    vec = eng.full_clip_vector(frames, flow_images=flow)
+    flow_img = None if flow_images is None else torch.as_tensor(flow_images).to(eng.device)
+    vec = eng.full_clip_vector(frames, flow_images=flow_img, flow=flow)
     pred = float(eng.mlp_head(vec[None])[0].item())
     if not is_finetune and video_type in ("youtube_ugc", "konvid_1k"):
         pred = (pred / 100) * 4 + 1

@@ -197,6 +197,30 @@ class RelaxEngine:
                     "relax_merge_fragments")
         return out
 
+    def optical_flow(self, frames, want_flow=False, want_image=True):
+        """frames uint8 [T,2,H,W,3] BGR -> (flow fp32 [T,H,W,2] | None, flow image uint8 [T,H,W,3] | None): Farneback flow
+        with the reference's parameters and its flow_to_rgb visualisation (src/main_fragment_layerstack.py:313-316)."""
+        frames = self._dev_u8(frames)
+        if frames.dim() != 5 or frames.shape[1] != 2 or frames.shape[4] != 3:
+            raise ValueError(f"frames must be [T,2,H,W,3], got {tuple(frames.shape)}")
+        T, _, H, W, _ = frames.shape
+        fl = torch.empty((T, H, W, 2), dtype=torch.float32, device=self.device) if want_flow else None
+        im = torch.empty((T, H, W, 3), dtype=torch.uint8, device=self.device) if want_image else None
+        fb = H * W * 3
+        base = frames.data_ptr()
+        rc = self.lib.relax_optical_flow(self.h, C.c_void_p(base), C.c_void_p(base + fb), 2 * fb, T, H, W, _ptr(fl), _ptr(im),
+                                         _stream())
+        self._check(rc, "relax_optical_flow")
+        return fl, im
+
+    def flow_to_rgb(self, flow):
+        """flow fp32 [T,H,W,2] -> uint8 [T,H,W,3] (src/main_fragment_layerstack.py:162-175)."""
+        flow = flow.to(self.device, torch.float32).contiguous()
+        T, H, W, _ = flow.shape
+        out = torch.empty((T, H, W, 3), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.relax_flow_to_rgb(self.h, _ptr(flow), T, H, W, _ptr(out), _stream()), "relax_flow_to_rgb")
+        return out
+
     def resize_frames(self, frames, bilinear=True, lanczos=True):
         """frames uint8 [N,H,W,3] -> (bilinear, lanczos) uint8 [N,224,224,3] each (None if not requested), bit-identical
         to PIL's Image.resize((224,224), BILINEAR / LANCZOS) (the reference's whole-frame inputs)."""
@@ -258,7 +282,7 @@ class RelaxEngine:
         return tk, pl
 
     # ---- whole clip ---------------------------------------------------------------------------
-    def extract_clip(self, frames, resnet=True, vit=True, flow_images=None):
+    def extract_clip(self, frames, resnet=True, vit=True, flow_images=None, flow=False):
         """frames uint8 [T,2,H,W,3] on the device -> per-frame features (all fp32, on the device):
              resnet: [T,15171] = layer-stack of the original fragment | pool of the residual fragment
              vit:    [T,4608]  = pool of the original fragment | pool of the residual fragment
@@ -266,6 +290,8 @@ class RelaxEngine:
         fragment when flow_images (uint8 [T,H,W,3]) are supplied (src/main_fragment_layerstack.py:313-325)."""
         fr = self.fragment_pairs(frames)
         resid = fr["diff_frag"]
+        if flow and flow_images is None:
+            _, flow_images = self.optical_flow(frames)     # full ReLaX: Farneback + flow_to_rgb on the GPU
         if flow_images is not None:
             fl = self.fragment_image(flow_images)
             resid = self.merge_fragments(resid, fl["frag"])
@@ -309,11 +335,11 @@ class RelaxEngine:
         _, vp = self.vit_features(lan, tokens=False, pooled=True)
         return ls, vp
 
-    def full_clip_vector(self, frames, flow_images=None):
+    def full_clip_vector(self, frames, flow_images=None, flow=False):
         """frames uint8 [T,2,H,W,3] -> fp32 [35203]: the vector src/demo_test.py:171-175 assembles
         (whole-frame ResNet-50 LS | whole-frame ViT | fragment ResNet-50 LS+pool | fragment ViT x2), each part averaged
         over the sampled frames.  Without flow_images the residual fragment is the frame-difference fragment alone."""
-        f = self.extract_clip(frames, flow_images=flow_images)
+        f = self.extract_clip(frames, flow_images=flow_images, flow=flow)
         ls, vp = self.whole_frame_features(frames[:, 0])
         return torch.cat([ls.mean(dim=0), vp.mean(dim=0), f["resnet"].mean(dim=0), f["vit"].mean(dim=0)])
 

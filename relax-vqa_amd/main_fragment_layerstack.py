@@ -4,7 +4,7 @@ reference only used files as glue, every function running on the HIP engine (no 
 
   get_patch_diff, extract_important_patches, get_original_frame_patches, process_patches, merge_fragments,
   concatenate_features, get_deep_feature, process_video_feature        (reference :83-248)
-  flow_to_rgb / Farneback: SURVEY §8(f) f2, not built yet.
+  calc_optical_flow_farneback, flow_to_rgb                              (reference :313-316, :162-175)
 """
 import numpy as np
 import torch
@@ -75,9 +75,18 @@ def merge_fragments(diff_fragment, flow_fragment):
                                                 torch.from_numpy(_u8(flow_fragment))).cpu().numpy()
 
 
+def calc_optical_flow_farneback(img_original, img_next):
+    """cv2.calcOpticalFlowFarneback(gray(orig), gray(next), None, 0.5, 3, 15, 3, 5, 1.2, 0) on the GPU (reference
+    :313-315; BGR->gray included).  -> float32 [H,W,2]"""
+    frames = torch.from_numpy(np.stack([_u8(img_original), _u8(img_next)])[None])
+    flow, _ = runtime.get_engine().optical_flow(frames, want_flow=True, want_image=False)
+    return flow[0].cpu().numpy()
+
+
 def flow_to_rgb(flow):
-    raise NotImplementedError("Farneback optical flow + flow_to_rgb are SURVEY §8(f) row f2 (not built yet); pass a "
-                              "flow image computed elsewhere to process_patches('optical_flow', ...)")
+    """float32 [H,W,2] -> uint8 [H,W,3] flow visualisation (reference :162-175; BGR despite the name)."""
+    f = torch.from_numpy(np.ascontiguousarray(flow, dtype=np.float32))[None]
+    return runtime.get_engine().flow_to_rgb(f)[0].cpu().numpy()
 
 
 def concatenate_features(original_feature, residual_feature):

@@ -1,0 +1,87 @@
+"""Optical flow (Farneback + flow_to_rgb) on the GPU: against the oracle (tight float tolerance) and against the
+reference's own OpenCV output on the shipped 960x540 pair (tolerance pin)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import flow_ref, fragment_ref
+from tests.gpu_common import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, suffix):
+    p = os.path.join(golden_dir, "png_5636101558_3", f"5636101558_3{suffix}.png")
+    return np.ascontiguousarray(np.asarray(Image.open(p).convert("RGB"))[..., ::-1])
+
+
+def _smooth_pair(h, w, seed):
+    """A textured frame and a slightly warped copy (random noise has no meaningful flow)."""
+    g = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = np.zeros((h, w, 3), np.float32)
+    for _ in range(12):
+        fx, fy, ph = g.uniform(0.01, 0.12), g.uniform(0.01, 0.12), g.uniform(0, 6.28, 3)
+        for c in range(3):
+            base[..., c] += g.uniform(10, 30) * np.sin(xx * fx + yy * fy + ph[c])
+    a = np.clip(base + 128, 0, 255).astype(np.uint8)
+    b = np.roll(np.roll(a, 2, axis=1), 1, axis=0)
+    b[h // 3: 2 * h // 3] = np.roll(a, -3, axis=1)[h // 3: 2 * h // 3]
+    return a, b
+
+
+def test_flow_matches_oracle():
+    a, b = _smooth_pair(200, 264, 1)
+    frames = np.stack([a, b])[None]
+    flow, img = engine().optical_flow(torch.from_numpy(frames).cuda(), want_flow=True, want_image=True)
+    flow, img = flow[0].cpu().numpy(), img[0].cpu().numpy()
+    want = flow_ref.farneback(flow_ref.bgr2gray(a), flow_ref.bgr2gray(b))
+    err = np.abs(flow - want)
+    assert err.max() < 2e-2 and err.mean() < 1e-4, (err.max(), err.mean())     # float reassociation only
+    want_img = flow_ref.flow_to_rgb(want)
+    d = np.abs(img.astype(np.int32) - want_img.astype(np.int32))
+    assert (d == 0).mean() > 0.995 and (d <= 1).mean() > 0.9995, ((d == 0).mean(), (d <= 1).mean())
+    # visualisation alone on the oracle's flow: exact input, so (near) exact output
+    img2 = engine().flow_to_rgb(torch.from_numpy(want[None]).cuda())[0].cpu().numpy()
+    assert (img2 == want_img).mean() > 0.999      # hue / value truncation boundaries under FMA contraction
+
+
+def test_reference_png_pair(golden_dir):
+    orig, nxt, want = _load(golden_dir, ""), _load(golden_dir, "_next"), _load(golden_dir, "_residual_of")
+    _, img = engine().optical_flow(torch.from_numpy(np.stack([orig, nxt])[None]).cuda())
+    img = img[0].cpu().numpy()
+    d = np.abs(img.astype(np.int32) - want.astype(np.int32))
+    assert (d == 0).mean() > 0.999 and (d <= 1).mean() > 0.9999, ((d == 0).mean(), (d <= 1).mean())
+    fo = engine().fragment_image(torch.from_numpy(img[None]).cuda())
+    n = int(fo["counts"][0])
+    got_pos = set(map(tuple, fo["positions"][0, :n].cpu().numpy().tolist()))
+    _, wp = fragment_ref.extract_important_patches(want, fragment_ref.get_patch_diff(want))
+    assert len(got_pos & set(map(tuple, wp.tolist()))) >= 195
+    # and the whole merged-fragment step of the reference (src/main_fragment_layerstack.py:319-325)
+    fr = engine().fragment_pairs(torch.from_numpy(np.stack([orig, nxt])[None]).cuda())
+    merged = engine().merge_fragments(fr["diff_frag"], fo["frag"])[0].cpu().numpy()
+    ref_merged = _load(golden_dir, "_residual_merged_frag")
+    assert (merged == ref_merged).mean() > 0.995
+
+
+def test_batch_of_pairs_and_chunking():
+    pairs = [_smooth_pair(120, 168, s) for s in range(3)]
+    frames = np.stack([np.stack(p) for p in pairs])
+    flow, _ = engine().optical_flow(torch.from_numpy(frames).cuda(), want_flow=True, want_image=False)
+    one, _ = engine().optical_flow(torch.from_numpy(frames[1:2]).cuda(), want_flow=True, want_image=False)
+    assert torch.equal(flow[1], one[0])          # a pair's flow does not depend on its batch
+
+
+def test_full_relax_clip_with_flow():
+    from tests.gpu_common import rn50_weights, vit_weights
+    rn50_weights(), vit_weights("vit_base")
+    a, b = _smooth_pair(272, 400, 9)
+    frames = torch.from_numpy(np.stack([a, b])[None]).cuda()
+    out = engine().extract_clip(frames, flow=True)
+    assert out["resnet"].shape == (1, 15171) and out["vit"].shape == (1, 4608)
+    assert bool(torch.isfinite(out["resnet"]).all()) and bool(torch.isfinite(out["vit"]).all())
+    vec = engine().full_clip_vector(frames, flow=True)
+    assert vec.shape == (35203,)
