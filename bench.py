@@ -39,6 +39,10 @@ WORKLOADS = {
     "config2": (720, 1280, 16, False),
     "config3": (1080, 1920, 32, True),
     "config4": (540, 960, 16, True),
+    # full ReLaX (config 5 recipe: whole-frame + fragment features of both backbones, residual+flow fragments -> 35203-d)
+    # at the sizes one GPU can be fed quickly; not the headline
+    "full1080p": (1080, 1920, 32, True),
+    "full2160p": (2160, 3840, 32, True),
 }
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 HBM_PEAK_GBPS = 8000.0
@@ -100,9 +104,16 @@ def main():
              for i in range(n_resident)]
     feat_dim = 15171 + (4608 if use_vit else 0)
 
+    full = args.workload.startswith("full")
+    if full:
+        feat_dim = 35203
+
     def step(i):
         batch = [clips[(i * B + j) % n_resident] for j in range(B)]
-        vecs = eng.clip_vectors(batch, resnet=True, vit=use_vit)          # [B, feat_dim]
+        if full:
+            vecs = torch.stack([eng.full_clip_vector(c, flow=True) for c in batch])
+        else:
+            vecs = eng.clip_vectors(batch, resnet=True, vit=use_vit)          # [B, feat_dim]
         if world > 1:
             return rdist.gather_clip_vectors(vecs, world * B, rank, world)
         return vecs

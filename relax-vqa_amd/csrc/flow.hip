@@ -192,44 +192,57 @@ __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict
                          (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
         r2 *= sc; r3 *= sc; r4 *= sc; r5 *= sc; r6 *= sc;
     }
-    float* o = M + i * 5;
+    float* o = M + pair * 5 * hw + ((int64_t)y * w + x);   // planar [P][5][h][w]: the box filters stream it coalesced
     o[0] = r4 * r4 + r6 * r6;
-    o[1] = (r4 + r5) * r6;
-    o[2] = r5 * r5 + r6 * r6;
-    o[3] = r4 * r2 + r6 * r3;
-    o[4] = r6 * r2 + r5 * r3;
+    o[hw] = (r4 + r5) * r6;
+    o[2 * hw] = r5 * r5 + r6 * r6;
+    o[3 * hw] = r4 * r2 + r6 * r3;
+    o[4 * hw] = r6 * r2 + r5 * r3;
 }
 
-// 15-row box sum (replicated border) in double: M [P][h][w][5] -> VS [P][h][w][5]
-__global__ __launch_bounds__(256) void box_vertical(const float* __restrict__ M, double* __restrict__ VS, int h, int w,
-                                                    int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over P*h*w*5
+// 15-row box sum (replicated border): planar M [P*5][h][w] -> VS [P*5][h][w].  One thread walks a 64-row segment of one
+// column with a running double sum (2 loads per output instead of 15); lanes are adjacent columns (coalesced).
+constexpr int BOX_SEG = 64;
+__global__ __launch_bounds__(256) void box_vertical(const float* __restrict__ M, float* __restrict__ VS, int h, int w,
+                                                    int nseg, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over planes * nseg * w
     if (i >= total) return;
-    const int64_t row5 = (int64_t)w * 5;
-    const int col = (int)(i % row5);
-    const int y = (int)((i / row5) % h);
-    const float* img = M + (i / (row5 * h)) * (row5 * h);
+    const int x = (int)(i % w);
+    const int seg = (int)((i / w) % nseg);
+    const int64_t plane = i / ((int64_t)w * nseg);
+    const float* img = M + plane * ((int64_t)h * w) + x;
+    float* out = VS + plane * ((int64_t)h * w) + x;
+    const int y0 = seg * BOX_SEG;
+    const int y1 = y0 + BOX_SEG < h ? y0 + BOX_SEG : h;
+    constexpr int m = WINSIZE / 2;
     double s = 0;
 #pragma unroll
-    for (int j = -WINSIZE / 2; j <= WINSIZE / 2; ++j) s += img[(int64_t)clampi(y + j, 0, h - 1) * row5 + col];
-    VS[i] = s;
+    for (int j = -m; j <= m; ++j) s += img[(int64_t)clampi(y0 + j, 0, h - 1) * w];
+    out[(int64_t)y0 * w] = (float)s;
+    for (int y = y0 + 1; y < y1; ++y) {
+        s += (double)img[(int64_t)clampi(y + m, 0, h - 1) * w] - (double)img[(int64_t)clampi(y - m - 1, 0, h - 1) * w];
+        out[(int64_t)y * w] = (float)s;
+    }
 }
 
-// 15-column box sum + the 2x2 solve: VS -> flow [P][h][w][2]
-__global__ __launch_bounds__(256) void box_horizontal_solve(const double* __restrict__ VS, float* __restrict__ flow, int h,
+// 15-column box sum + the 2x2 solve: planar VS -> flow [P][h][w][2]
+__global__ __launch_bounds__(256) void box_horizontal_solve(const float* __restrict__ VS, float* __restrict__ flow, int h,
                                                             int w, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over P*h*w
     if (i >= total) return;
     const int x = (int)(i % w);
-    const double* row = VS + (i - x) * 5;
-    double g11 = 0, g12 = 0, g22 = 0, h1 = 0, h2 = 0;
+    const int64_t hw = (int64_t)h * w;
+    const int64_t pair = i / hw;
+    const float* row = VS + pair * 5 * hw + (i - pair * hw - x);
+    double acc[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = -WINSIZE / 2; j <= WINSIZE / 2; ++j) {
-        const double* p = row + clampi(x + j, 0, w - 1) * 5;
-        g11 += p[0]; g12 += p[1]; g22 += p[2]; h1 += p[3]; h2 += p[4];
+        const int xx = clampi(x + j, 0, w - 1);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) acc[c] += row[c * hw + xx];
     }
     const double sc = 1.0 / (WINSIZE * WINSIZE);
-    g11 *= sc; g12 *= sc; g22 *= sc; h1 *= sc; h2 *= sc;
+    const double g11 = acc[0] * sc, g12 = acc[1] * sc, g22 = acc[2] * sc, h1 = acc[3] * sc, h2 = acc[4] * sc;
     const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
     flow[i * 2] = (float)((g11 * h2 - g12 * h1) * idet);
     flow[i * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
@@ -397,7 +410,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
                       float* flow_out, uint8_t* bgr_out, hipStream_t s) {
     const int64_t HW = (int64_t)H * W;
     // workspace carve (floats unless noted), all sized for level 0
-    const size_t per_pair = (size_t)HW * (2 + 2 + 2 + 2 + 6 + 10 + 5 + 2 + 2) * sizeof(float) + (size_t)HW * 5 * sizeof(double) + 16;
+    const size_t per_pair = (size_t)HW * (2 + 2 + 2 + 2 + 6 + 10 + 5 + 5 + 2 + 2) * sizeof(float) + 16;
     RELAX_TRY(ensure_buf(h, h->flow_ws, per_pair * P));
     float* gray = static_cast<float*>(h->flow_ws.p);
     float* tmp = gray + (size_t)P * 2 * HW;
@@ -408,7 +421,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
     float* M = R + (size_t)P * 10 * HW;        // [P][h][w][5]
     float* flowA = M + (size_t)P * 5 * HW;     // [P][h][w][2]
     float* flowB = flowA + (size_t)P * 2 * HW;
-    double* VS = reinterpret_cast<double*>(flowB + (size_t)P * 2 * HW);
+    float* VS = flowB + (size_t)P * 2 * HW;    // [P][5][h][w]
     unsigned* mm = reinterpret_cast<unsigned*>(VS + (size_t)P * 5 * HW);
 
     PolyConsts pc;
@@ -457,9 +470,11 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
         hipLaunchKernelGGL(poly_vertical, dim3(nblocks(tot_l2)), dim3(256), 0, s, Isrc, T, hh, w, pc, tot_l2);
         hipLaunchKernelGGL(poly_horizontal, dim3(nblocks(tot_l2)), dim3(256), 0, s, T, R, hh, w, pc, tot_l2);
         const int64_t tot_l = (int64_t)P * hw;
+        const int nseg = (hh + BOX_SEG - 1) / BOX_SEG;
         hipLaunchKernelGGL(update_matrices_k, dim3(nblocks(tot_l)), dim3(256), 0, s, R, cur, M, hh, w, tot_l);
         for (int it = 0; it < ITERS; ++it) {
-            hipLaunchKernelGGL(box_vertical, dim3(nblocks(tot_l * 5)), dim3(256), 0, s, M, VS, hh, w, tot_l * 5);
+            hipLaunchKernelGGL(box_vertical, dim3(nblocks((int64_t)P * 5 * nseg * w)), dim3(256), 0, s, M, VS, hh, w, nseg,
+                               (int64_t)P * 5 * nseg * w);
             hipLaunchKernelGGL(box_horizontal_solve, dim3(nblocks(tot_l)), dim3(256), 0, s, VS, cur, hh, w, tot_l);
             if (it < ITERS - 1)
                 hipLaunchKernelGGL(update_matrices_k, dim3(nblocks(tot_l)), dim3(256), 0, s, R, cur, M, hh, w, tot_l);
@@ -490,9 +505,9 @@ int relax_optical_flow(relax_handle* h, const uint8_t* orig, const uint8_t* next
     RELAX_REQUIRE(h, pair_stride >= (int64_t)H * W * 3 || T == 1, "relax_optical_flow: pair stride smaller than a frame");
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // bound the workspace: ~ 212 B per pixel per pair; keep chunks under ~6 GB
+    // bound the workspace: 152 B per pixel per pair; keep chunks under ~6 GB
     const int64_t HW = (int64_t)H * W;
-    int chunk = (int)((6ll << 30) / (HW * 212));
+    int chunk = (int)((6ll << 30) / (HW * 160));
     if (chunk < 1) chunk = 1;
     if (chunk > T) chunk = T;
     for (int t0 = 0; t0 < T; t0 += chunk) {
