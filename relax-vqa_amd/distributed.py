@@ -35,7 +35,7 @@ def shard_clips(n_clips, rank, world):
 def gather_clip_vectors(local, n_clips, rank, world, group=None):
     """local: [len(shard_clips(n_clips, rank, world)), F] -> [n_clips, F] on every rank, rows in clip order.
     Ragged shards are padded to ceil(n_clips / world) rows for a single fixed-size all-gather."""
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return local
     per = -(-n_clips // world)
     F = local.shape[1]

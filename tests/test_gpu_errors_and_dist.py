@@ -1,0 +1,63 @@
+"""Error behaviour of the C-ABI (status codes + messages -> RuntimeError) and the RCCL all-gather path on one GPU."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_common import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_errors_are_reported_not_swallowed():
+    eng = engine()
+    lib, h = eng.lib, eng.h
+    assert lib.relax_fragment_pairs(h, None, None, 0, 1, 16, 16, 196, None, None, None, None, None, None) == -1
+    assert b"NULL" in lib.relax_last_error(h)
+    f = torch.zeros((1, 2, 32, 32, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError, match="top_n"):
+        eng.fragment_pairs(f, top_n=500)
+    with pytest.raises(ValueError):
+        eng.fragment_pairs(torch.zeros((1, 3, 32, 32, 3), dtype=torch.uint8))
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        eng.op_gemm(torch.zeros(8, 40, device="cuda"), torch.zeros(64, 40, device="cuda"))
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        eng.op_gemm(torch.zeros(8, 64, device="cuda"), torch.zeros(48, 64, device="cuda"))
+    with pytest.raises(RuntimeError, match="unknown option"):
+        eng.set_option("no_such_option", 1)
+    sd = synth.resnet50_state_dict()
+    bad = dict(sd)
+    del bad["layer3.4.conv2.weight"]
+    from relax_vqa_amd.engine import RelaxEngine
+    e2 = RelaxEngine(0)
+    with pytest.raises(RuntimeError, match="missing key 'layer3.4.conv2.weight'"):
+        e2.load_resnet50(bad)
+    with pytest.raises(RuntimeError, match="relax_load_resnet50 first"):
+        e2.resnet50_features(torch.zeros((1, 224, 224, 3), dtype=torch.uint8))
+    bad = dict(sd)
+    bad["conv1.weight"] = np.zeros((64, 3, 5, 5), np.float32)
+    with pytest.raises(RuntimeError, match="conv1.weight"):
+        e2.load_resnet50(bad)
+    e2.close()
+    assert lib.relax_create(99, C.byref(C.c_void_p())) != 0 and b"out of range" in lib.relax_last_error(None)
+
+
+def test_rccl_all_gather_single_rank():
+    """backend 'nccl' is RCCL on ROCm: run the feature all-gather through it (world size 1 is all one box offers)."""
+    import torch.distributed as dist
+    from relax_vqa_amd import distributed as rd
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        local = torch.randn(3, 19779, device="cuda")
+        out = rd.gather_clip_vectors(local, 3, 0, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(out, local)
+    finally:
+        dist.destroy_process_group()
