@@ -70,6 +70,19 @@ def cpu_baseline(H, W, T, use_vit, rn_sd, vit_sd, sample_pairs):
     }
 
 
+def hbm_traffic_per_launch(workload, clips_per_step):
+    """PMC-measured HBM bytes per contraction launch, if a committed profile exists for this exact workload."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("workload") == workload and rec.get("clips_per_step") == clips_per_step:
+            return rec["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +148,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gemm_ms, gemm_flops, gemm_launches = eng.profile_read(0)
     frag_ms, frag_bytes, frag_launches = eng.profile_read(1)
+    _, gemm_alg_bytes, _ = eng.profile_read(2)
     eng.profile_enable(False)
     assert out.shape == (world * B, feat_dim) and bool(torch.isfinite(out).all())
 
@@ -159,7 +173,10 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "conv_gemm_f32 (fp32 implicit-GEMM conv / GEMM, v_mfma_f32_32x32x2_f32)",
                 "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": hbm_traffic_per_launch(args.workload, B),
+                "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (own passes, FETCH doubled "
+                                "per the gfx950 guide), measured once for this workload: profiles/r01_hbm_traffic.json",
+                "algorithmic_bytes_per_launch": gemm_alg_bytes / max(gemm_launches, 1),
                 "launches": gemm_launches, "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                 "algorithmic_gflop_per_launch": gemm_flops / max(gemm_launches, 1) / 1e9,
                 "kernel_time_share_of_step": gemm_ms * 1e-3 / elapsed,

@@ -197,7 +197,8 @@ int relax_op_token_stats(relax_handle* h, const float* x, float* out, int Nimg, 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* While enabled, every launch of the contraction kernel (GEMM / implicit-GEMM conv) and of the patch-score
  * kernel is bracketed by HIP events on the caller's stream.  relax_profile_read synchronises those events and
- * returns totals since the last enable: kind 0 = contraction (work = FLOPs), kind 1 = patch score (work = bytes). */
+ * returns totals since the last enable: kind 0 = contraction (work = FLOPs), kind 1 = patch score (work = bytes),
+ * kind 2 = contraction again with work = its algorithmic HBM bytes (operands and results touched once). */
 int relax_profile_enable(relax_handle* h, int on);
 int relax_profile_read(relax_handle* h, int kind, double* total_ms, double* total_work, int64_t* launches);
 

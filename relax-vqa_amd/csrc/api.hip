@@ -49,7 +49,7 @@ int upload(relax_handle* h, const float* host, size_t n, float** dev, std::vecto
     return RELAX_OK;
 }
 
-int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_idx) {
+int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_idx, double bytes) {
     *span_idx = -1;
     Profiler& p = h->prof;
     if (!p.on) return RELAX_OK;
@@ -63,6 +63,7 @@ int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_
         }
     }
     sp.work = work;
+    sp.bytes = bytes;
     sp.kind = kind;
     RELAX_HIP_CHECK(h, hipEventRecord(sp.start, s));
     p.spans.push_back(sp);
@@ -84,6 +85,7 @@ static int prof_drain(relax_handle* h) {
         RELAX_HIP_CHECK(h, hipEventElapsedTime(&ms, sp.start, sp.stop));
         p.total_ms[sp.kind] += ms;
         p.total_work[sp.kind] += sp.work;
+        p.total_bytes[sp.kind] += sp.bytes;
         p.launches[sp.kind] += 1;
         p.pool.push_back(sp.start);
         p.pool.push_back(sp.stop);
@@ -210,6 +212,7 @@ int relax_profile_enable(relax_handle* h, int on) {
         for (int k = 0; k < 2; ++k) {
             h->prof.total_ms[k] = 0;
             h->prof.total_work[k] = 0;
+            h->prof.total_bytes[k] = 0;
             h->prof.launches[k] = 0;
         }
     }
@@ -218,11 +221,12 @@ int relax_profile_enable(relax_handle* h, int on) {
 
 int relax_profile_read(relax_handle* h, int kind, double* total_ms, double* total_work, int64_t* launches) {
     if (!h) return RELAX_ERR_INVALID;
-    RELAX_REQUIRE(h, kind == 0 || kind == 1, "relax_profile_read: kind must be 0 or 1");
+    RELAX_REQUIRE(h, kind >= 0 && kind <= 2, "relax_profile_read: kind must be 0, 1 or 2");
     RELAX_TRY(prof_drain(h));
-    if (total_ms) *total_ms = h->prof.total_ms[kind];
-    if (total_work) *total_work = h->prof.total_work[kind];
-    if (launches) *launches = h->prof.launches[kind];
+    const int k = kind == 2 ? 0 : kind;   // kind 2: the contraction launches again, work = algorithmic HBM bytes
+    if (total_ms) *total_ms = h->prof.total_ms[k];
+    if (total_work) *total_work = kind == 2 ? h->prof.total_bytes[0] : h->prof.total_work[k];
+    if (launches) *launches = h->prof.launches[k];
     return RELAX_OK;
 }
 

@@ -215,7 +215,7 @@ __device__ inline uint32_t absdiff_u8x4(uint32_t a, uint32_t b) {
 template <int MODE, bool ALIGNED>
 __global__ __launch_bounds__(256) void gather_fragment(const uint8_t* __restrict__ a_base,
                                                        const uint8_t* __restrict__ b_base, int64_t item_stride,
-                                                       int W, const int32_t* __restrict__ positions,
+                                                       int H, int W, const int32_t* __restrict__ positions,
                                                        const int32_t* __restrict__ counts,
                                                        uint8_t* __restrict__ frag) {
     const int t = blockIdx.y;
@@ -231,6 +231,11 @@ __global__ __launch_bounds__(256) void gather_fragment(const uint8_t* __restrict
     if (k < counts[t]) {
         const int y = positions[((int64_t)t * RELAX_TOP_N + k) * 2];
         const int x = positions[((int64_t)t * RELAX_TOP_N + k) * 2 + 1];
+        // caller-supplied positions (relax_gather_patches) are not trusted: an out-of-range patch yields a zero tile
+        if ((unsigned)y >= (unsigned)(H / P) || (unsigned)x >= (unsigned)(W / P)) {
+            *reinterpret_cast<uint4*>(dst) = v;
+            return;
+        }
         const int64_t off = t * item_stride + ((int64_t)(y * P + r) * W + (int64_t)x * P) * 3 + c * 16;
         if (ALIGNED) {
             v = *reinterpret_cast<const uint4*>(a_base + off);
@@ -331,12 +336,12 @@ static int fragment_common(relax_handle* h, bool pair, const uint8_t* a, const u
     hipLaunchKernelGGL(select_topn, dim3(T), SEL_THREADS, 0, s, scores, npatch, pw, top_n, positions, counts);
     dim3 ggrid((RELAX_TOP_N * P * 3 + 255) / 256, T);
     if (frag_a) {
-        if (al) hipLaunchKernelGGL((gather_fragment<0, true>), ggrid, 256, 0, s, a, b, item_stride, W, positions, counts, frag_a);
-        else hipLaunchKernelGGL((gather_fragment<0, false>), ggrid, 256, 0, s, a, b, item_stride, W, positions, counts, frag_a);
+        if (al) hipLaunchKernelGGL((gather_fragment<0, true>), ggrid, 256, 0, s, a, b, item_stride, H, W, positions, counts, frag_a);
+        else hipLaunchKernelGGL((gather_fragment<0, false>), ggrid, 256, 0, s, a, b, item_stride, H, W, positions, counts, frag_a);
     }
     if (frag_diff && pair) {
-        if (al) hipLaunchKernelGGL((gather_fragment<1, true>), ggrid, 256, 0, s, a, b, item_stride, W, positions, counts, frag_diff);
-        else hipLaunchKernelGGL((gather_fragment<1, false>), ggrid, 256, 0, s, a, b, item_stride, W, positions, counts, frag_diff);
+        if (al) hipLaunchKernelGGL((gather_fragment<1, true>), ggrid, 256, 0, s, a, b, item_stride, H, W, positions, counts, frag_diff);
+        else hipLaunchKernelGGL((gather_fragment<1, false>), ggrid, 256, 0, s, a, b, item_stride, H, W, positions, counts, frag_diff);
     }
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
@@ -372,8 +377,8 @@ int relax_gather_patches(relax_handle* h, const uint8_t* image, int64_t item_str
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool al = ((W * 3) % 16 == 0) && (item_stride % 16 == 0) && aligned16(image);
     dim3 ggrid((RELAX_TOP_N * P * 3 + 255) / 256, T);
-    if (al) hipLaunchKernelGGL((gather_fragment<0, true>), ggrid, 256, 0, s, image, image, item_stride, W, positions, counts, frag);
-    else hipLaunchKernelGGL((gather_fragment<0, false>), ggrid, 256, 0, s, image, image, item_stride, W, positions, counts, frag);
+    if (al) hipLaunchKernelGGL((gather_fragment<0, true>), ggrid, 256, 0, s, image, image, item_stride, H, W, positions, counts, frag);
+    else hipLaunchKernelGGL((gather_fragment<0, false>), ggrid, 256, 0, s, image, image, item_stride, H, W, positions, counts, frag);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }

@@ -429,7 +429,9 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     }
     const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)(d.KH * d.KW * d.Cin);
     int span;
-    RELAX_TRY(prof_begin(h, s, 0, flops, &span));
+    // algorithmic HBM bytes: activation in, weights, output (+ residual), each touched once
+    const double bytes = 4.0 * ((double)d.Nimg * d.H * d.W * d.Cin + (double)p.N * p.Kpad + (double)p.M * p.N * (d.residual ? 2.0 : 1.0));
+    RELAX_TRY(prof_begin(h, s, 0, flops, &span, bytes));
     // automatic choice: BK = 16 keeps three 128x128 workgroups (12 waves) per CU, which hides the prologue / epilogue of
     // one tile under the MFMAs of the others (+8 % over BK = 32 with two workgroups, measured on config 3)
     int variant = h->gemm.variant >= 0 ? h->gemm.variant : 7;

@@ -127,6 +127,7 @@ struct ResizeTable {
 struct ProfSpan {
     hipEvent_t start, stop;
     double work;
+    double bytes;  // algorithmic HBM bytes of the launch (contraction kernel), 0 otherwise
     int kind;
 };
 
@@ -136,6 +137,7 @@ struct Profiler {
     std::vector<hipEvent_t> pool;
     double total_ms[2] = {0, 0};
     double total_work[2] = {0, 0};
+    double total_bytes[2] = {0, 0};
     int64_t launches[2] = {0, 0};
 };
 
@@ -177,7 +179,7 @@ int ensure_buf(relax_handle* h, DevBuf& b, size_t bytes);
 int upload(relax_handle* h, const float* host, size_t n, float** dev, std::vector<void*>& allocs);
 
 // profiling helpers: call around a launch; no-ops when profiling is off
-int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_idx);
+int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_idx, double bytes = 0);
 int prof_end(relax_handle* h, hipStream_t s, int span_idx);
 
 // contraction kernel launcher (gemm.hip)

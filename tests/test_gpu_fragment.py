@@ -131,3 +131,14 @@ def test_gather_with_given_positions():
     for t in range(2):
         n = out["counts"][t]
         assert np.array_equal(got[t], fragment_ref.get_original_frame_patches(clip[t, 1], out["positions"][t, :n]))
+
+
+def test_gather_rejects_out_of_range_positions():
+    img = np.random.default_rng(2).integers(1, 256, (1, 64, 80, 3), dtype=np.uint8)
+    pos = torch.full((1, 196, 2), -1, dtype=torch.int32)
+    pos[0, 0] = torch.tensor([1, 2])
+    pos[0, 1] = torch.tensor([400, 3])          # far outside the 4 x 5 patch grid
+    pos[0, 2] = torch.tensor([-7, 0])
+    got = engine().gather_patches(torch.from_numpy(img).cuda(), pos, torch.tensor([3], dtype=torch.int32)).cpu().numpy()
+    assert np.array_equal(got[0, :16, :16], img[0, 16:32, 32:48])
+    assert not got[0, :16, 16:48].any()          # the two bad tiles are zero, nothing was read out of bounds
