@@ -19,11 +19,11 @@ constexpr int TILES_PER_ROW = RELAX_TARGET / P;  // 14
 constexpr int FRAG_ROW_BYTES = RELAX_TARGET * 3; // 672
 
 // ---- patch score ------------------------------------------------------------------------------
-// One workgroup per (patch row py, item t): a strip of 16 image rows.  Work item = one 16-byte
-// chunk (row r, chunk c); chunk c belongs to patch c/3.  Lanes walk consecutive chunks, so a wave
-// reads 1 KiB of contiguous frame bytes per instruction.
+// One workgroup per (patch row py, item t): a strip of 16 image rows.  A lane owns one 16-byte
+// chunk column c (patch c/3) for the 16 rows; lanes are consecutive chunks, so a wave reads 1 KiB
+// of contiguous frame bytes per instruction and keeps 16 such loads in flight.
 template <bool PAIR>
-__global__ __launch_bounds__(256) void patch_score_aligned(const uint8_t* __restrict__ a_base,
+__global__ __launch_bounds__(512) void patch_score_aligned(const uint8_t* __restrict__ a_base,
                                                            const uint8_t* __restrict__ b_base,
                                                            int64_t item_stride, int W, int pw, int ph,
                                                            uint32_t* __restrict__ scores) {
@@ -32,32 +32,32 @@ __global__ __launch_bounds__(256) void patch_score_aligned(const uint8_t* __rest
     const int t = blockIdx.y;
     const int row_bytes = W * 3;
     const int nchunks = pw * 3;
-    const int nitems = nchunks * P;
     for (int p = threadIdx.x; p < pw; p += blockDim.x) lds_sum[p] = 0;
     __syncthreads();
     const uint8_t* a = a_base + t * item_stride + (int64_t)py * P * row_bytes;
     const uint8_t* b = PAIR ? b_base + t * item_stride + (int64_t)py * P * row_bytes : nullptr;
-    int r = 0, c = threadIdx.x;
-    while (c >= nchunks) { c -= nchunks; ++r; }
-    for (int item = threadIdx.x; item < nitems; item += blockDim.x) {
-        const int64_t off = (int64_t)r * row_bytes + c * 16;
-        const uint4 va = *reinterpret_cast<const uint4*>(a + off);
-        uint32_t s;
-        if (PAIR) {
-            const uint4 vb = *reinterpret_cast<const uint4*>(b + off);
-            s = __builtin_amdgcn_sad_u8(va.x, vb.x, 0u);
-            s = __builtin_amdgcn_sad_u8(va.y, vb.y, s);
-            s = __builtin_amdgcn_sad_u8(va.z, vb.z, s);
-            s = __builtin_amdgcn_sad_u8(va.w, vb.w, s);
-        } else {
-            s = __builtin_amdgcn_sad_u8(va.x, 0u, 0u);
-            s = __builtin_amdgcn_sad_u8(va.y, 0u, s);
-            s = __builtin_amdgcn_sad_u8(va.z, 0u, s);
-            s = __builtin_amdgcn_sad_u8(va.w, 0u, s);
+    // a lane owns chunk column c for all 16 rows of the strip: 8 rows (16 x 16-byte loads) in flight at a time
+    for (int c = threadIdx.x; c < nchunks; c += blockDim.x) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int r0 = 0; r0 < P; r0 += 8) {
+            uint4 va[8], vb[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int64_t off = (int64_t)(r0 + r) * row_bytes + c * 16;
+                va[r] = *reinterpret_cast<const uint4*>(a + off);
+                if (PAIR) vb[r] = *reinterpret_cast<const uint4*>(b + off);
+                else vb[r] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                s = __builtin_amdgcn_sad_u8(va[r].x, vb[r].x, s);
+                s = __builtin_amdgcn_sad_u8(va[r].y, vb[r].y, s);
+                s = __builtin_amdgcn_sad_u8(va[r].z, vb[r].z, s);
+                s = __builtin_amdgcn_sad_u8(va[r].w, vb[r].w, s);
+            }
         }
         atomicAdd(&lds_sum[c / 3], s);  // integer LDS atomic: order-independent, exact
-        c += blockDim.x;
-        while (c >= nchunks) { c -= nchunks; ++r; }
     }
     __syncthreads();
     uint32_t* out = scores + ((int64_t)t * ph + py) * pw;
@@ -325,11 +325,14 @@ static int fragment_common(relax_handle* h, bool pair, const uint8_t* a, const u
     int span;
     RELAX_TRY(prof_begin(h, s, 1, bytes, &span));
     dim3 grid(ph, T);
+    const int nchunks = pw * 3;
+    const int passes = (nchunks + 511) / 512;
+    const int ablock = (((nchunks + passes - 1) / passes + 63) / 64) * 64;  // 1080p: 360 chunks -> 384 lanes, 1 pass
     if (pair) {
-        if (al) hipLaunchKernelGGL(patch_score_aligned<true>, grid, 256, lds, s, a, b, item_stride, W, pw, ph, scores);
+        if (al) hipLaunchKernelGGL(patch_score_aligned<true>, grid, ablock, lds, s, a, b, item_stride, W, pw, ph, scores);
         else hipLaunchKernelGGL(patch_score_generic<true>, grid, 256, lds, s, a, b, item_stride, W, pw, ph, scores);
     } else {
-        if (al) hipLaunchKernelGGL(patch_score_aligned<false>, grid, 256, lds, s, a, b, item_stride, W, pw, ph, scores);
+        if (al) hipLaunchKernelGGL(patch_score_aligned<false>, grid, ablock, lds, s, a, b, item_stride, W, pw, ph, scores);
         else hipLaunchKernelGGL(patch_score_generic<false>, grid, 256, lds, s, a, b, item_stride, W, pw, ph, scores);
     }
     RELAX_TRY(prof_end(h, s, span));

@@ -115,3 +115,23 @@ def test_extract_clip_config3_1080p_with_vit():
     assert_close(out["resnet"][:, :13120], resnet50_ref.layer_stack_features(tr, ori), "clip layer-stack 1080p")
     vec = engine().clip_vector(torch.from_numpy(clip).cuda())
     assert vec.shape == (15171 + 4608,)
+
+
+def test_clip_vectors_batch_of_mixed_resolutions_config4_shape():
+    """BASELINE config 4 shape (540p) next to a 720p clip in ONE batched pass; each row must equal the clip processed
+    alone (to fp32 rounding with the default tail split-K, bit for bit without it)."""
+    rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    a = torch.from_numpy(synth.synthetic_clip(3, 540, 960, clip_id=40)).cuda()
+    b = torch.from_numpy(synth.synthetic_clip(2, 720, 1280, clip_id=41)).cuda()
+    both = eng.clip_vectors([a, b])
+    assert both.shape == (2, 15171 + 4608)
+    alone = torch.stack([eng.clip_vector(a), eng.clip_vector(b)])
+    assert_close(both, alone.cpu().numpy(), "batched vs single clips", rtol=1e-4, atol_frac=1e-5)
+    eng.set_option("gemm_split_k", 0)
+    try:
+        both0 = eng.clip_vectors([a, b])
+        alone0 = torch.stack([eng.clip_vector(a), eng.clip_vector(b)])
+        assert torch.equal(both0, alone0), "batching changed bits with split-K off"
+    finally:
+        eng.set_option("gemm_split_k", 1)
