@@ -17,7 +17,9 @@
  *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All work
  *     is enqueued on it; no hidden synchronisation.
  *   - a handle owns only weights + workspace; it is NOT thread-safe; one handle
- *     per (process, device).
+ *     per (process, device).  The workspace is reused from call to call, so calls on
+ *     one handle must be ordered: issue them on ONE stream (or order the streams with
+ *     events); two backbone calls running concurrently on different streams would race.
  *   - images are uint8 HWC **BGR** exactly as cv2.imread holds them
  *     (src/main_fragment_layerstack.py:295-296); fragments are 224x224x3.
  */
@@ -66,7 +68,8 @@ int relax_reserve(relax_handle* h, int max_images);
 /* Integer options.  "gemm_split_k" (default 1): cut the tail tiles of a contraction along K so the last round fills
  * the chip; results stay deterministic for a given batch, but the K-summation order of tail tiles then depends on the
  * batch size - set 0 when features must be bit-identical across batch compositions (e.g. comparing sharded runs).
- * "gemm_variant", "gemm_group_m", "gemm_prio", "gemm_ablate": tuning / experiment knobs (see csrc/gemm.hip). */
+ * "gemm_variant", "gemm_variant_n64", "gemm_group_m", "gemm_prio": tuning knobs (tile variants are listed in csrc/gemm.hip;
+ * none of them changes results beyond fp32 rounding). */
 int relax_set_option(relax_handle* h, const char* key, int value);
 
 /* ---- weights ------------------------------------------------------------------------------- */

@@ -175,7 +175,6 @@ const char* relax_last_error(const relax_handle* h) {
 int relax_reserve(relax_handle* h, int max_images) {
     if (!h) return RELAX_ERR_INVALID;
     RELAX_REQUIRE(h, max_images > 0, "relax_reserve: max_images must be > 0");
-    if (max_images <= h->reserved_images) return RELAX_OK;
     size_t need = resnet_arena_bytes(max_images);
     if (h->vit.loaded) {
         size_t v = vit_arena_bytes(h->vit, max_images);
@@ -196,7 +195,6 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     else if (k == "gemm_variant_n64") h->gemm.variant_n64 = value;
     else if (k == "gemm_group_m") h->gemm.group_m = value > 0 ? value : 1;
     else if (k == "gemm_prio") h->gemm.prio = value;
-    else if (k == "gemm_ablate") h->gemm.ablate = value;
     else {
         set_error(h, "relax_set_option: unknown option '%s'", key);
         return RELAX_ERR_INVALID;

@@ -151,7 +151,7 @@ struct GemmOptions {
     int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)
     int group_m = 8;   // "gemm_group_m": row-tiles per L2 group
     int prio = 0;      // "gemm_prio": s_setprio around the MFMA cluster
-    int ablate = 0;    // "gemm_ablate": timing-only ablations (results are WRONG): 1 barrier, 2 global loads, 4 LDS stores
+    int ablate = 0;    // env RELAX_GEMM_ABLATE only: timing-only ablations (results are WRONG): 1 barrier, 2 global loads, 4 LDS stores
 };
 }  // namespace relax
 
