@@ -113,7 +113,7 @@ def main():
 
     # two distinct resident clips per rank, alternated (inputs are in HBM before the timed region starts)
     n_resident = 2
-    clips = [torch.from_numpy(synth.synthetic_clip(T, H, W, clip_id=rank * n_resident + i)).cuda()
+    clips = [torch.from_numpy(synth.synthetic_clip(T, H, W, clip_id=rank * n_resident + i, distinct=4)).cuda()
              for i in range(n_resident)]
     feat_dim = 15171 + (4608 if use_vit else 0)
 

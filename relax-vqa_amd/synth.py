@@ -123,11 +123,17 @@ def synthetic_pair(height, width, seed, patch=16, max_amp=64):
     return orig, nxt
 
 
-def synthetic_clip(n_pairs, height, width, clip_id=0):
+def synthetic_clip(n_pairs, height, width, clip_id=0, distinct=None):
     """uint8 [T,2,H,W,3]: frames[t,0]=sampled frame, frames[t,1]=the frame after
-    it (the pairing of src/video_frames_extract.py:51-69)."""
+    it (the pairing of src/video_frames_extract.py:51-69).  `distinct` < n_pairs draws only that many pairs from the
+    generator and derives the rest by rolling them by whole patches (different content and index maps per pair at a
+    fraction of the host time; used by bench.py, never by the parity tests)."""
     out = np.empty((n_pairs, 2, height, width, 3), dtype=np.uint8)
-    for t in range(n_pairs):
+    distinct = n_pairs if distinct is None else max(1, min(distinct, n_pairs))
+    for t in range(distinct):
         o, n = synthetic_pair(height, width, seed=1000 + clip_id * 4096 + t)
         out[t, 0], out[t, 1] = o, n
+    for t in range(distinct, n_pairs):
+        shift = 16 * (t // distinct)
+        out[t] = np.roll(out[t % distinct], shift=(shift, 3 * shift), axis=(1, 2))
     return out
