@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=4)
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 measurement")
     ap.add_argument("--clips-per-step", type=int, default=4,
                     help="clips each rank pushes through the engine per step (one batched pass: B*2*T fragments)")
     args = ap.parse_args()
@@ -152,6 +153,28 @@ def main():
     eng.profile_enable(False)
     assert out.shape == (world * B, feat_dim) and bool(torch.isfinite(out).all())
 
+    # opt-in bf16x3 precision, measured beside the headline (same workload, same step function); never the headline
+    fast = None
+    if world == 1 and not args.no_fast_mode:
+        eng.set_precision("bf16x3")
+        for i in range(2):
+            step(i)
+        barrier()
+        eng.profile_enable(True)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        barrier()
+        e1 = time.perf_counter() - t1
+        f_ms, f_flops, f_n = eng.profile_read(0)
+        eng.profile_enable(False)
+        eng.set_precision("fp32")
+        fast = {"precision": "bf16x3: fp32 operands split into bf16 hi+lo, hi*hi+hi*lo+lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate",
+                "value": args.steps * B / e1, "unit": "clips/s", "ms_per_step": e1 / args.steps * 1e3,
+                "contraction_algorithmic_tflops": f_flops / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0,
+                "parity": "features within ~1e-5 norm-relative of the fp32 path (bar 1e-3): tests/test_gpu_backbones.py::"
+                          "test_bf16x3_mode_meets_the_feature_tolerance"}
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -188,6 +211,8 @@ def main():
                 "traffic": None, "launches": frag_launches,
             },
         }
+        if fast is not None:
+            result["fast_mode"] = fast
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(H, W, T, use_vit, rn_sd, vit_sd, args.cpu_sample_pairs)
             result["speedup_vs_cpu_faithful"] = result["value"] / result["cpu_baseline"]["value"]

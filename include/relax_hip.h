@@ -65,7 +65,10 @@ const char* relax_last_error(const relax_handle* h);
  * backbone entry points; call it up front to keep allocation out of timed code. */
 int relax_reserve(relax_handle* h, int max_images);
 
-/* Integer options.  "gemm_split_k" (default 1): cut the tail tiles of a contraction along K so the last round fills
+/* Integer options.  "gemm_precision" (default 0): 0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 1 = "bf16x3":
+ * every fp32 operand is split on the fly into bf16 hi + lo and a*b = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
+ * with fp32 accumulation (about 2^-16 relative error per product; measured features within ~1e-5 of the fp32 path).
+ * "gemm_split_k" (default 1): cut the tail tiles of a contraction along K so the last round fills
  * the chip; results stay deterministic for a given batch, but the K-summation order of tail tiles then depends on the
  * batch size - set 0 when features must be bit-identical across batch compositions (e.g. comparing sharded runs).
  * "gemm_variant", "gemm_variant_n64", "gemm_group_m", "gemm_prio": tuning knobs (tile variants are listed in csrc/gemm.hip;

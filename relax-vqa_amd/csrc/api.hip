@@ -137,6 +137,7 @@ int relax_create(int device, relax_handle** out) {
     relax_handle* h = new relax_handle();
     h->device = device;
     if (const char* e = getenv("RELAX_GEMM_SPLIT")) h->gemm.split_k = atoi(e);
+    if (const char* e = getenv("RELAX_GEMM_PRECISION")) h->gemm.precision = atoi(e) == 1 ? 1 : 0;
     if (const char* e = getenv("RELAX_GEMM_VARIANT")) h->gemm.variant = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_VARIANT_N64")) h->gemm.variant_n64 = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_GROUP_M")) h->gemm.group_m = atoi(e) > 0 ? atoi(e) : 1;
@@ -191,6 +192,7 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     RELAX_REQUIRE(h, key, "relax_set_option: key is NULL");
     const std::string k(key);
     if (k == "gemm_split_k") h->gemm.split_k = value;
+    else if (k == "gemm_precision") h->gemm.precision = value == 1 ? 1 : 0;
     else if (k == "gemm_variant") h->gemm.variant = value;
     else if (k == "gemm_variant_n64") h->gemm.variant_n64 = value;
     else if (k == "gemm_group_m") h->gemm.group_m = value > 0 ? value : 1;

@@ -21,7 +21,9 @@
 namespace relax {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in VGPRs (HIP's float4 struct did not)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));  // native vector: stays in VGPRs (HIP's float4 struct did not)
 
 
 struct GemmParams {
@@ -48,14 +50,35 @@ __device__ inline int xcd_remap(int b, int nwg) {
     return base + (b >> 3);
 }
 
+// x = hi + lo with hi = the top 16 bits of x (exact in bf16) and lo = bf16_rne(x - hi): 16 mantissa bits kept, 3 VALU
+// per element (and, sub, and half a v_perm / v_cvt_pk each).
+__device__ inline void split_bf16x4(const f32x4 v, uint2* hi, uint2* lo) {
+    const unsigned u0 = __float_as_uint(v.x), u1 = __float_as_uint(v.y), u2 = __float_as_uint(v.z), u3 = __float_as_uint(v.w);
+    const float l0 = v.x - __uint_as_float(u0 & 0xffff0000u), l1 = v.y - __uint_as_float(u1 & 0xffff0000u);
+    const float l2 = v.z - __uint_as_float(u2 & 0xffff0000u), l3 = v.w - __uint_as_float(u3 & 0xffff0000u);
+    hi->x = __builtin_amdgcn_perm(u1, u0, 0x07060302u);   // {u1[31:16], u0[31:16]}
+    hi->y = __builtin_amdgcn_perm(u3, u2, 0x07060302u);
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t p0 = __builtin_convertvector((f32x2_t){l0, l1}, bf16x2_t);
+    const bf16x2_t p1 = __builtin_convertvector((f32x2_t){l2, l3}, bf16x2_t);
+    lo->x = __builtin_bit_cast(unsigned, p0);
+    lo->y = __builtin_bit_cast(unsigned, p1);
+}
+
 __device__ inline float apply_act(float v, int act) {
     if (act == 1) return v > 0.f ? v : 0.f;
     if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int OCC, bool TAPS>
+// PREC 0: exact fp32 products on v_mfma_f32_32x32x2_f32.
+// PREC 1 ("bf16x3", opt-in): every fp32 operand is split on the fly into two bf16 values x = hi + lo (16 mantissa bits
+// kept), and a*b is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-16
+// relative error per product (features stay within ~1e-5 of the fp32 path, bar 1e-3) at 3/16 of the fp32 MFMA cycles.
+template <int BM, int BN, int WM, int WN, int BK, int OCC, bool TAPS, int PREC>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmParams p) {
+    static_assert(PREC == 0 || BK == 32, "bf16x3 stages 32-deep K steps (one 144-byte LDS row: 32 hi + 32 lo + pad)");
     constexpr int NT = WM * WN * 64;
     constexpr int LDK = BK + 4;   // padded LDS row: conflict-free b128 writes and reads for BK = 32 (36) and 16 (20)
     constexpr int KL = BK / 4;    // lanes (float4) per K step of a row
@@ -131,9 +154,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
     const float* wrow0 = p.w + (int64_t)(n0 + lrow) * p.Kpad + c4 * 4;
     const int64_t wpass = (int64_t)PASS * p.Kpad;  // weight rows per staging pass
 
-    f32x4 ra[A_LOADS], rb[B_LOADS];
+    f32x4 ra0[A_LOADS], rb0[B_LOADS];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#define RELAX_LOAD_TILE(k0_)                                                                          \
+#define RELAX_LOAD_TILE_R(k0_, ra, rb)                                                                        \
     {                                                                                                 \
         const int k_ = (k0_) + c4 * 4;                                                                \
         if (TAPS) {                                                                                   \
@@ -160,15 +183,36 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
         _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                           \
             rb[i] = *reinterpret_cast<const f32x4*>(wrow0 + i * wpass + (k0_));                       \
     }
-#define RELAX_STORE_TILE(buf_)                                                                        \
+#define RELAX_STORE_TILE_R(buf_, ra, rb)                                                                        \
     {                                                                                                 \
         float* As_ = smem + (buf_) * STAGE;                                                           \
         float* Bs_ = As_ + BM * LDK;                                                                  \
-        _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                           \
-            *reinterpret_cast<f32x4*>(As_ + (i * PASS + lrow) * LDK + c4 * 4) = ra[i];                \
-        _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                           \
-            *reinterpret_cast<f32x4*>(Bs_ + (i * PASS + lrow) * LDK + c4 * 4) = rb[i];                \
+        if (PREC == 0) {                                                                              \
+            _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i)                                       \
+                *reinterpret_cast<f32x4*>(As_ + (i * PASS + lrow) * LDK + c4 * 4) = ra[i];            \
+            _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                       \
+                *reinterpret_cast<f32x4*>(Bs_ + (i * PASS + lrow) * LDK + c4 * 4) = rb[i];            \
+        } else {                                                                                      \
+            /* row image: [32 x bf16 hi][32 x bf16 lo][16 B pad] = 144 B = 18 x 8-byte slots */         \
+            uint2* A8_ = reinterpret_cast<uint2*>(As_);                                                 \
+            uint2* B8_ = reinterpret_cast<uint2*>(Bs_);                                                 \
+            _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                     \
+                uint2 hi_, lo_;                                                                       \
+                split_bf16x4(ra[i], &hi_, &lo_);                                                      \
+                A8_[(i * PASS + lrow) * 18 + c4] = hi_;                                               \
+                A8_[(i * PASS + lrow) * 18 + 8 + c4] = lo_;                                           \
+            }                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                     \
+                uint2 hi_, lo_;                                                                       \
+                split_bf16x4(rb[i], &hi_, &lo_);                                                      \
+                B8_[(i * PASS + lrow) * 18 + c4] = hi_;                                               \
+                B8_[(i * PASS + lrow) * 18 + 8 + c4] = lo_;                                           \
+            }                                                                                         \
+        }                                                                                             \
     }
+
+#define RELAX_LOAD_TILE(k0_) RELAX_LOAD_TILE_R(k0_, ra0, rb0)
+#define RELAX_STORE_TILE(buf_) RELAX_STORE_TILE_R(buf_, ra0, rb0)
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -178,38 +222,93 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    RELAX_LOAD_TILE(kt_begin * BK);
-    RELAX_STORE_TILE(0);
-    __syncthreads();
-
     const int frag_off = (lane & 31) * LDK + 4 * (lane >> 5);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end && !(p.ablate & 2)) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
-        const float* As = smem + cur * STAGE + (wm * TM * 32) * LDK + frag_off;
-        const float* Bs = smem + cur * STAGE + BM * LDK + (wn * TN * 32) * LDK + frag_off;
-        if (p.prio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK + q * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + q * 8);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (p.prio) __builtin_amdgcn_s_setprio(0);
-        if (kt + 1 < kt_end && !(p.ablate & 4)) RELAX_STORE_TILE(cur ^ 1);
-        if (!(p.ablate & 1)) __syncthreads();
+#define RELAX_COMPUTE(cur_)  \
+    {  \
+        const float* As = smem + (cur_) * STAGE + (wm * TM * 32) * LDK + frag_off;  \
+        const float* Bs = smem + (cur_) * STAGE + BM * LDK + (wn * TN * 32) * LDK + frag_off;  \
+        if (p.prio) __builtin_amdgcn_s_setprio(1);  \
+        if constexpr (PREC == 0) {  \
+_Pragma("unroll")  \
+            for (int q = 0; q < BK / 8; ++q) {  \
+                f32x4 af[TM], bf[TN];  \
+_Pragma("unroll")  \
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK + q * 8);  \
+_Pragma("unroll")  \
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + q * 8);  \
+_Pragma("unroll")  \
+                for (int i = 0; i < TM; ++i)  \
+_Pragma("unroll")  \
+                    for (int j = 0; j < TN; ++j) {  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);  \
+                    }  \
+            }  \
+        } else {  \
+  \
+            const char* Ab = reinterpret_cast<const char*>(smem + (cur_) * STAGE + (wm * TM * 32 + (lane & 31)) * LDK) + 16 * (lane >> 5);  \
+            const char* Bb = reinterpret_cast<const char*>(smem + (cur_) * STAGE + BM * LDK + (wn * TN * 32 + (lane & 31)) * LDK) + 16 * (lane >> 5);  \
+_Pragma("unroll")  \
+            for (int ks = 0; ks < 2; ++ks) {  \
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];  \
+_Pragma("unroll")  \
+                for (int i = 0; i < TM; ++i) {  \
+                    ah[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + ks * 32);  \
+                    al[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + 64 + ks * 32);  \
+                }  \
+_Pragma("unroll")  \
+                for (int j = 0; j < TN; ++j) {  \
+                    bh[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + ks * 32);  \
+                    bl[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + 64 + ks * 32);  \
+                }  \
+_Pragma("unroll")  \
+                for (int i = 0; i < TM; ++i)  \
+_Pragma("unroll")  \
+                    for (int j = 0; j < TN; ++j) {  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);  \
+                    }  \
+            }  \
+        }  \
+        if (p.prio) __builtin_amdgcn_s_setprio(0);  \
     }
+
+    if constexpr (PREC == 0) {
+        RELAX_LOAD_TILE(kt_begin * BK);
+        RELAX_STORE_TILE(0);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int cur = (kt - kt_begin) & 1;
+            if (kt + 1 < kt_end && !(p.ablate & 2)) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
+            RELAX_COMPUTE(cur);
+            if (kt + 1 < kt_end && !(p.ablate & 4)) RELAX_STORE_TILE(cur ^ 1);
+            if (!(p.ablate & 1)) __syncthreads();
+        }
+    } else {
+        // bf16x3: a K step is only 24 MFMAs (768 cycles) per wave, too short to cover a global load, so the register
+        // stage runs TWO steps ahead (two named register sets, loop unrolled by two so every index is static).
+        f32x4 ra1[A_LOADS], rb1[B_LOADS];
+        RELAX_LOAD_TILE_R(kt_begin * BK, ra0, rb0);
+        RELAX_STORE_TILE_R(0, ra0, rb0);
+        if (kt_begin + 1 < kt_end) RELAX_LOAD_TILE_R((kt_begin + 1) * BK, ra1, rb1);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            if (kt + 2 < kt_end) RELAX_LOAD_TILE_R((kt + 2) * BK, ra0, rb0);
+            RELAX_COMPUTE(0);
+            if (kt + 1 < kt_end) RELAX_STORE_TILE_R(1, ra1, rb1);
+            __syncthreads();
+            if (kt + 1 < kt_end) {
+                if (kt + 3 < kt_end) RELAX_LOAD_TILE_R((kt + 3) * BK, ra1, rb1);
+                RELAX_COMPUTE(1);
+                if (kt + 2 < kt_end) RELAX_STORE_TILE_R(0, ra0, rb0);
+                __syncthreads();
+            }
+        }
+    }
+#undef RELAX_COMPUTE
 
     // ---- epilogue, staged through LDS -----------------------------------------------------------------------
     // The accumulators hold one column per lane and rows in registers (C/D map of the 32x32 MFMA:
@@ -303,6 +402,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
 
 #undef RELAX_LOAD_TILE
 #undef RELAX_STORE_TILE
+#undef RELAX_LOAD_TILE_R
+#undef RELAX_STORE_TILE_R
 
 // Sums the K slices of the split tiles in slice order (deterministic) and applies the epilogue.
 template <int BM, int BN>
@@ -336,7 +437,7 @@ __global__ __launch_bounds__(256) void splitk_finish(const GemmParams p) {
     *reinterpret_cast<f32x4*>(p.out + o) = v;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int OCC, bool TAPS>
+template <int BM, int BN, int WM, int WN, int BK, int OCC, bool TAPS, int PREC>
 static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     p.tiles_n = p.N / BN;
@@ -377,12 +478,12 @@ static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hip
     constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * (BK + 4);
     static bool attr_set = false;
     if (!attr_set) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f32<BM, BN, WM, WN, BK, OCC, TAPS>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f32<BM, BN, WM, WN, BK, OCC, TAPS, PREC>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
-    hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, BK, OCC, TAPS>), dim3(units), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, BK, OCC, TAPS, PREC>), dim3(units), dim3(NT), lds, s, p);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((splitk_finish<BM, BN>), dim3(BM * BN / 4 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
     RELAX_HIP_CHECK(h, hipGetLastError());
@@ -397,8 +498,11 @@ static int ilog2_exact(int v) {
 
 // tile variants: id -> <BM, BN, WM, WN>, workgroups resident per CU (LDS / VGPR bound)
 #define RELAX_DISPATCH(BM_, BN_, WM_, WN_, BK_, OCC_, BPC_)                                  \
-    (taps ? launch_variant<BM_, BN_, WM_, WN_, BK_, OCC_, true>(h, p, BPC_, s)               \
-          : launch_variant<BM_, BN_, WM_, WN_, BK_, OCC_, false>(h, p, BPC_, s))
+    (taps ? launch_variant<BM_, BN_, WM_, WN_, BK_, OCC_, true, 0>(h, p, BPC_, s)            \
+          : launch_variant<BM_, BN_, WM_, WN_, BK_, OCC_, false, 0>(h, p, BPC_, s))
+#define RELAX_DISPATCH_X3(BM_, BN_, WM_, WN_, OCC_, BPC_)                                    \
+    (taps ? launch_variant<BM_, BN_, WM_, WN_, 32, OCC_, true, 1>(h, p, BPC_, s)             \
+          : launch_variant<BM_, BN_, WM_, WN_, 32, OCC_, false, 1>(h, p, BPC_, s))
 
 int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     GemmParams p{};
@@ -437,6 +541,12 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     int variant = h->gemm.variant >= 0 ? h->gemm.variant : 7;
     if (p.N % 128 != 0) variant = h->gemm.variant_n64 >= 0 ? h->gemm.variant_n64 : 10;
     int rc;
+    if (h->gemm.precision == 1) {   // opt-in bf16x3
+        rc = (p.N % 128 == 0) ? RELAX_DISPATCH_X3(128, 128, 2, 2, 2, 2) : RELAX_DISPATCH_X3(128, 64, 2, 2, 2, 2);
+        RELAX_TRY(rc);
+        RELAX_TRY(prof_end(h, s, span));
+        return RELAX_OK;
+    }
     switch (variant) {
         case 1: rc = RELAX_DISPATCH(128, 128, 2, 2, 32, 1, 2); break;   // 4 waves, 64x64 per wave
         case 2: rc = RELAX_DISPATCH(128, 128, 2, 4, 32, 1, 2); break;   // 8 waves, 64x32 per wave
@@ -457,6 +567,7 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     return RELAX_OK;
 }
 #undef RELAX_DISPATCH
+#undef RELAX_DISPATCH_X3
 
 }  // namespace relax
 

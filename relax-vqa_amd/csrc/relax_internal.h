@@ -146,6 +146,7 @@ struct Profiler {
 namespace relax {
 // Tuning / reproducibility switches of the contraction kernel (relax_set_option; env defaults RELAX_GEMM_*).
 struct GemmOptions {
+    int precision = 0; // "gemm_precision": 0 = exact fp32 MFMA (default), 1 = bf16x3 split products (opt-in, ~1e-5 relative)
     int split_k = 1;   // "gemm_split_k": tail split-K on (1) / off (0: K sums are batch-invariant bit for bit)
     int variant = -1;  // "gemm_variant": pin the tile variant for N % 128 == 0 problems, -1 = automatic
     int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)

@@ -119,6 +119,12 @@ class RelaxEngine:
         self._check(self.lib.relax_mlp_head(self.h, _ptr(features), features.shape[0], _ptr(out), _stream()), "relax_mlp_head")
         return out
 
+    def set_precision(self, mode):
+        """'fp32' (default): exact fp32 products on the fp32 MFMA.  'bf16x3' (opt-in): each fp32 operand is split into
+        two bf16 values and a*b = hi*hi + hi*lo + lo*hi runs on the bf16 MFMA with fp32 accumulation; features stay
+        within ~1e-5 (norm-relative) of the fp32 path - the parity bar is 1e-3 - at roughly half the time."""
+        self.set_option("gemm_precision", {"fp32": 0, "bf16x3": 1}[mode])
+
     def set_option(self, key, value):
         self._check(self.lib.relax_set_option(self.h, key.encode(), int(value)), "relax_set_option")
 

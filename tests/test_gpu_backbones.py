@@ -135,3 +135,25 @@ def test_clip_vectors_batch_of_mixed_resolutions_config4_shape():
         assert torch.equal(both0, alone0), "batching changed bits with split-K off"
     finally:
         eng.set_option("gemm_split_k", 1)
+
+
+def test_bf16x3_mode_meets_the_feature_tolerance():
+    """The opt-in bf16x3 precision (hi/lo bf16 split products, fp32 accumulate) against the fp32 oracle: the 1e-3 feature
+    bar of the north star holds with ~100x margin in norm-relative terms."""
+    sd_r, sd_v = rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    frags = _fragments(4, seed=5)
+    eng.set_precision("bf16x3")
+    try:
+        ls, pool = eng.resnet50_features(torch.from_numpy(frags).cuda())
+        _, pooled = eng.vit_features(torch.from_numpy(frags).cuda(), tokens=False, pooled=True)
+    finally:
+        eng.set_precision("fp32")
+    tr, tv = resnet50_ref.to_torch_state_dict(sd_r), vit_ref.to_torch_state_dict(sd_v)
+    want_ls, want_pool = resnet50_ref.layer_stack_features(tr, frags), resnet50_ref.pool_features(tr, frags)
+    want_vit = vit_ref.pool_features(tv, frags, 12)
+    for name, got, want in (("layer-stack", ls, want_ls), ("pool", pool, want_pool), ("vit pooled", pooled, want_vit)):
+        got = got.cpu().numpy()
+        rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+        assert rel < 5e-5, (name, rel)
+        assert_close(got, want, f"bf16x3 {name}", rtol=1e-3, atol_frac=2e-4)

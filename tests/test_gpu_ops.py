@@ -108,3 +108,32 @@ def test_gap(n, hw, c):
     want = x.double().mean(dim=1).float().numpy()
     got = engine().op_gap(x.cuda())
     assert_close(got, want, f"gap {n}x{hw}x{c}")
+
+
+# ---- opt-in bf16x3 precision (split products on the bf16 MFMA) -------------------------------------------------------
+@pytest.fixture
+def bf16x3():
+    engine().set_precision("bf16x3")
+    yield
+    engine().set_precision("fp32")
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 512), (197 * 3, 2304, 768), (12608, 768, 3072), (50, 64, 64), (4096, 64, 576)])
+def test_gemm_bf16x3_accuracy(bf16x3, M, N, K):
+    A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    want = (A.double() @ W.double().T).float().numpy()
+    got = engine().op_gemm(A.cuda(), W.cuda()).cpu().numpy()
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel < 2e-5, rel                       # ~2^-16 per product, random signs
+    assert_close(got, want, f"bf16x3 gemm {M}x{N}x{K}", rtol=1e-3, atol_frac=2e-4)
+
+
+@pytest.mark.parametrize("Nimg,H,Cin,Cout,k,stride,pad", CONVS[:8])
+def test_conv_bf16x3_accuracy(bf16x3, Nimg, H, Cin, Cout, k, stride, pad):
+    x = _rand(Nimg, Cin, H, H, seed=7)
+    w = _rand(Cout, Cin, k, k, seed=8, scale=(Cin * k * k) ** -0.5)
+    b = _rand(Cout, seed=9)
+    want = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)).float().numpy()
+    got = engine().op_conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), torch.from_numpy(pack_conv_weight(w.numpy())).cuda(),
+                                  b.cuda(), None, Cout, k, k, stride, pad, act=1).permute(0, 3, 1, 2).cpu().numpy()
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-5
