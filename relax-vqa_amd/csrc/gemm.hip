@@ -50,20 +50,20 @@ __device__ inline int xcd_remap(int b, int nwg) {
     return base + (b >> 3);
 }
 
-// x = hi + lo with hi = the top 16 bits of x (exact in bf16) and lo = bf16_rne(x - hi): 16 mantissa bits kept, 3 VALU
-// per element (and, sub, and half a v_perm / v_cvt_pk each).
+// x = hi + lo with hi = bf16_rne(x) and lo = bf16_rne(x - hi): 16 mantissa bits kept.  Both roundings are to nearest, so
+// the dropped lo*lo term has no preferred sign (a truncating hi makes lo >= 0 relative to x and the error drifts: measured
+// 1.2e-4 instead of 5e-6 on the 13120-d layer-stack vector).  3 VALU per element (half a cvt_pk twice, shift/and, sub).
 __device__ inline void split_bf16x4(const f32x4 v, uint2* hi, uint2* lo) {
-    const unsigned u0 = __float_as_uint(v.x), u1 = __float_as_uint(v.y), u2 = __float_as_uint(v.z), u3 = __float_as_uint(v.w);
-    const float l0 = v.x - __uint_as_float(u0 & 0xffff0000u), l1 = v.y - __uint_as_float(u1 & 0xffff0000u);
-    const float l2 = v.z - __uint_as_float(u2 & 0xffff0000u), l3 = v.w - __uint_as_float(u3 & 0xffff0000u);
-    hi->x = __builtin_amdgcn_perm(u1, u0, 0x07060302u);   // {u1[31:16], u0[31:16]}
-    hi->y = __builtin_amdgcn_perm(u3, u2, 0x07060302u);
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    const bf16x2_t p0 = __builtin_convertvector((f32x2_t){l0, l1}, bf16x2_t);
-    const bf16x2_t p1 = __builtin_convertvector((f32x2_t){l2, l3}, bf16x2_t);
-    lo->x = __builtin_bit_cast(unsigned, p0);
-    lo->y = __builtin_bit_cast(unsigned, p1);
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v.x, v.y}, bf16x2_t));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v.z, v.w}, bf16x2_t));
+    const float l0 = v.x - __uint_as_float(h01 << 16), l1 = v.y - __uint_as_float(h01 & 0xffff0000u);
+    const float l2 = v.z - __uint_as_float(h23 << 16), l3 = v.w - __uint_as_float(h23 & 0xffff0000u);
+    hi->x = h01;
+    hi->y = h23;
+    lo->x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){l0, l1}, bf16x2_t));
+    lo->y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){l2, l3}, bf16x2_t));
 }
 
 __device__ inline float apply_act(float v, int act) {
