@@ -80,7 +80,7 @@ constexpr int ATT_THREADS = KTILES * 64;
 constexpr size_t ATT_LDS = sizeof(float) * (2 * KPAD * KV_LD + KTILES * 32);
 
 __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __restrict__ qkv,
-                                                                 float* __restrict__ out, int heads) {
+                                                                 float* __restrict__ out, int heads, int ablate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
     float* Vs = smem + KPAD * KV_LD;
@@ -91,29 +91,40 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
     const int ld = 3 * dim;
     const float* base = qkv + (int64_t)img * NTOK * ld + head * 64;
 
-    for (int idx = tid; idx < KPAD * 16; idx += ATT_THREADS) {
+    // All global loads of the workgroup's K, V and Q go out together (KPAD*16 float4 per matrix = 8 per thread), then
+    // the LDS image is written: one memory latency per workgroup instead of eight dependent load->store rounds.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int STAGE_ITERS = KPAD * 16 / ATT_THREADS;   // 8
+    static_assert(KPAD * 16 % ATT_THREADS == 0, "K/V staging must divide evenly over the workgroup");
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 kreg[STAGE_ITERS], vreg[STAGE_ITERS];
+#pragma unroll
+    for (int it = 0; it < STAGE_ITERS; ++it) {
+        const int idx = it * ATT_THREADS + tid;
         const int row = idx >> 4, c = idx & 15;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        kreg[it] = zero4;
+        vreg[it] = zero4;
         if (row < NTOK) {
-            kv = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + dim + c * 4);
-            vv = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + 2 * dim + c * 4);
+            kreg[it] = *reinterpret_cast<const f32x4*>(base + (int64_t)row * ld + dim + c * 4);
+            vreg[it] = *reinterpret_cast<const f32x4*>(base + (int64_t)row * ld + 2 * dim + c * 4);
         }
-        *reinterpret_cast<float4*>(Ks + row * KV_LD + c * 4) = kv;
-        *reinterpret_cast<float4*>(Vs + row * KV_LD + c * 4) = vv;
     }
-    __syncthreads();
-
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, half = lane >> 5;
     const int qrow = wave * 32 + li;
     const int qclamped = qrow < NTOK ? qrow : NTOK - 1;
     const float* qp = base + (int64_t)qclamped * ld + 4 * half;
-    float4 qf[8];
+    f32x4 qf[8];
 #pragma unroll
-    for (int q8 = 0; q8 < 8; ++q8) {
-        float4 t = *reinterpret_cast<const float4*>(qp + 8 * q8);
-        qf[q8] = make_float4(t.x * 0.125f, t.y * 0.125f, t.z * 0.125f, t.w * 0.125f);  // head_dim^-0.5, exact
+    for (int q8 = 0; q8 < 8; ++q8) qf[q8] = *reinterpret_cast<const f32x4*>(qp + 8 * q8) * 0.125f;  // head_dim^-0.5, exact
+#pragma unroll
+    for (int it = 0; it < STAGE_ITERS; ++it) {
+        const int idx = it * ATT_THREADS + tid;
+        const int row = idx >> 4, c = idx & 15;
+        *reinterpret_cast<f32x4*>(Ks + row * KV_LD + c * 4) = kreg[it];
+        *reinterpret_cast<f32x4*>(Vs + row * KV_LD + c * 4) = vreg[it];
     }
+    __syncthreads();
 
     floatx16 sacc[KTILES];
 #pragma unroll
@@ -122,8 +133,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
         for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
         const float* kp = Ks + (kt * 32 + li) * KV_LD + 4 * half;
 #pragma unroll
-        for (int q8 = 0; q8 < 8; ++q8) {
-            const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * q8);
+        for (int q8 = 0; q8 < ((ablate & 32) ? 1 : 8); ++q8) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 8 * q8);
             sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[q8].x, sacc[kt], 0, 0, 0);
             sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[q8].y, sacc[kt], 0, 0, 0);
             sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[q8].z, sacc[kt], 0, 0, 0);
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
     for (int kt = 0; kt < KTILES; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = expf(sacc[kt][r] - mx);
+            const float e = (ablate & 8) ? (sacc[kt][r] - mx) * 0.001f + 1.0f : expf(sacc[kt][r] - mx);
             sacc[kt][r] = e;
             sum += e;
         }
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
 #pragma unroll
-    for (int kt = 0; kt < KTILES; ++kt)
+    for (int kt = 0; kt < ((ablate & 16) ? 1 : KTILES); ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -189,7 +200,7 @@ int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, in
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_197x64, dim3(Nimg * heads), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads);
+    hipLaunchKernelGGL(attention_197x64, dim3(Nimg * heads), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, h->gemm.ablate & 56);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }
