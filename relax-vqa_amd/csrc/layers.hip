@@ -68,128 +68,170 @@ int launch_layernorm(relax_handle* h, const float* x, const float* g, const floa
     return RELAX_OK;
 }
 
-// ---- attention: one workgroup per (image, head), 7 waves = 7 query tiles of 32 -----------------------------
-// S^T = K Q^T is computed with the KEY on the MFMA row (register) axis and the QUERY on the lane,
-// so each lane owns one query's scores: softmax is register-local plus one lane^32 exchange, and
-// the probabilities already sit in the A-operand layout of the P V product (no LDS round trip).
+// ---- attention: persistent workgroups walk the (image, head) items; 7 waves = 7 query tiles of 32 -----------------
+// S^T = K Q^T is computed with the KEY on the MFMA row (register) axis and the QUERY on the lane, so each lane owns one
+// query's scores: softmax is register-local plus one lane^32 exchange, and the probabilities already sit in the
+// A-operand layout of the P V product (no LDS round trip).  K and V share ONE LDS buffer (61 KB): K is resident during
+// the score phase while V streams into registers, V replaces K for the P V phase while the next item's K streams into
+// registers - the global traffic (150 KB per item, ~6 us at the per-CU load rate) hides under the MFMA phases instead
+// of preceding them.
 constexpr int NTOK = 197;
 constexpr int KTILES = 7;         // 224 = 7 * 32 padded keys
 constexpr int KPAD = KTILES * 32;
 constexpr int KV_LD = 68;         // 64 + 4: conflict-free ds_read_b128 of K rows
 constexpr int ATT_THREADS = KTILES * 64;
-constexpr size_t ATT_LDS = sizeof(float) * (2 * KPAD * KV_LD + KTILES * 32);
+constexpr size_t ATT_LDS = sizeof(float) * (KPAD * KV_LD + KTILES * 32);
+constexpr int STAGE_ITERS = KPAD * 16 / ATT_THREADS;   // 8 float4 per thread per matrix
+static_assert(KPAD * 16 % ATT_THREADS == 0, "K/V staging must divide evenly over the workgroup");
 
-__global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __restrict__ qkv,
-                                                                 float* __restrict__ out, int heads, int ablate) {
+typedef float att_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                 int heads, int total_items, int ablate,
+                                                                 unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;
-    float* Vs = smem + KPAD * KV_LD;
-    float* rowsum = Vs + KPAD * KV_LD;
+    float* KV = smem;
+    float* rowsum = smem + KPAD * KV_LD;
     const int tid = threadIdx.x;
-    const int img = blockIdx.x / heads, head = blockIdx.x % heads;
-    const int dim = heads * 64;
-    const int ld = 3 * dim;
-    const float* base = qkv + (int64_t)img * NTOK * ld + head * 64;
-
-    // All global loads of the workgroup's K, V and Q go out together (KPAD*16 float4 per matrix = 8 per thread), then
-    // the LDS image is written: one memory latency per workgroup instead of eight dependent load->store rounds.
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    constexpr int STAGE_ITERS = KPAD * 16 / ATT_THREADS;   // 8
-    static_assert(KPAD * 16 % ATT_THREADS == 0, "K/V staging must divide evenly over the workgroup");
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 kreg[STAGE_ITERS], vreg[STAGE_ITERS];
-#pragma unroll
-    for (int it = 0; it < STAGE_ITERS; ++it) {
-        const int idx = it * ATT_THREADS + tid;
-        const int row = idx >> 4, c = idx & 15;
-        kreg[it] = zero4;
-        vreg[it] = zero4;
-        if (row < NTOK) {
-            kreg[it] = *reinterpret_cast<const f32x4*>(base + (int64_t)row * ld + dim + c * 4);
-            vreg[it] = *reinterpret_cast<const f32x4*>(base + (int64_t)row * ld + 2 * dim + c * 4);
-        }
-    }
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 31, half = lane >> 5;
-    const int qrow = wave * 32 + li;
-    const int qclamped = qrow < NTOK ? qrow : NTOK - 1;
-    const float* qp = base + (int64_t)qclamped * ld + 4 * half;
-    f32x4 qf[8];
-#pragma unroll
-    for (int q8 = 0; q8 < 8; ++q8) qf[q8] = *reinterpret_cast<const f32x4*>(qp + 8 * q8) * 0.125f;  // head_dim^-0.5, exact
-#pragma unroll
-    for (int it = 0; it < STAGE_ITERS; ++it) {
-        const int idx = it * ATT_THREADS + tid;
-        const int row = idx >> 4, c = idx & 15;
-        *reinterpret_cast<f32x4*>(Ks + row * KV_LD + c * 4) = kreg[it];
-        *reinterpret_cast<f32x4*>(Vs + row * KV_LD + c * 4) = vreg[it];
-    }
-    __syncthreads();
+    const int dim = heads * 64;
+    const int ld = 3 * dim;
+    const att_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int item = blockIdx.x;
+    if (item >= total_items) return;   // workgroup-uniform
 
-    floatx16 sacc[KTILES];
-#pragma unroll
-    for (int kt = 0; kt < KTILES; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
-        const float* kp = Ks + (kt * 32 + li) * KV_LD + 4 * half;
-#pragma unroll
-        for (int q8 = 0; q8 < ((ablate & 32) ? 1 : 8); ++q8) {
-            const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 8 * q8);
-            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[q8].x, sacc[kt], 0, 0, 0);
-            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[q8].y, sacc[kt], 0, 0, 0);
-            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[q8].z, sacc[kt], 0, 0, 0);
-            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[q8].w, sacc[kt], 0, 0, 0);
-        }
+    att_f32x4 kv[STAGE_ITERS], qf[8];
+#define ATT_LOAD_KV(item_, col_)                                                                                  \
+    {                                                                                                             \
+        const float* b_ = qkv + (int64_t)((item_) / heads) * NTOK * ld + ((item_) % heads) * 64 + (col_);        \
+        _Pragma("unroll") for (int it = 0; it < STAGE_ITERS; ++it) {                                              \
+            const int idx = it * ATT_THREADS + tid;                                                               \
+            const int row = idx >> 4, c = idx & 15;                                                               \
+            kv[it] = zero4;                                                                                       \
+            if (row < NTOK) kv[it] = *reinterpret_cast<const att_f32x4*>(b_ + (int64_t)row * ld + c * 4);         \
+        }                                                                                                         \
     }
-    // sacc[kt][r] = score(query li, key kt*32 + (r&3) + 8*(r>>2) + 4*half)
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < KTILES; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (key >= NTOK) sacc[kt][r] = -INFINITY;
-            mx = fmaxf(mx, sacc[kt][r]);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < KTILES; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = (ablate & 8) ? (sacc[kt][r] - mx) * 0.001f + 1.0f : expf(sacc[kt][r] - mx);
-            sacc[kt][r] = e;
-            sum += e;
-        }
-    sum += __shfl_xor(sum, 32);
-    if (half == 0) rowsum[wave * 32 + li] = sum;
-    __syncthreads();
+#define ATT_STORE_KV()                                                                                            \
+    _Pragma("unroll") for (int it = 0; it < STAGE_ITERS; ++it) {                                                  \
+        const int idx = it * ATT_THREADS + tid;                                                                   \
+        *reinterpret_cast<att_f32x4*>(KV + (idx >> 4) * KV_LD + (idx & 15) * 4) = kv[it];                          \
+    }
+#define ATT_LOAD_Q(item_)                                                                                         \
+    {                                                                                                             \
+        const int qrow_ = wave * 32 + li;                                                                         \
+        const float* q_ = qkv + (int64_t)((item_) / heads) * NTOK * ld + ((item_) % heads) * 64 +                 \
+                          (int64_t)(qrow_ < NTOK ? qrow_ : NTOK - 1) * ld + 4 * half;                              \
+        _Pragma("unroll") for (int q8 = 0; q8 < 8; ++q8)                                                          \
+            qf[q8] = *reinterpret_cast<const att_f32x4*>(q_ + 8 * q8) * (0.125f * 1.44269504088896341f);         \
+    }
 
-    floatx16 oacc[2];
+    // diagnostic build only (RELAX_GEMM_ABLATE bit 64): per-wave cycle shares of the phases of one item
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0;
+#define ATT_STAMP(i_)                                                  \
+    if (stamps) {                                                      \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
+        seg[i_] += t_ - t_prev;                                        \
+        t_prev = t_;                                                   \
+    }
+    ATT_LOAD_KV(item, dim);
+    ATT_LOAD_Q(item);
+    ATT_STORE_KV();
+    __syncthreads();
+    if (stamps) t_prev = __builtin_amdgcn_s_memtime();
+
+    while (true) {
+        ATT_LOAD_KV(item, 2 * dim);   // V of this item: in flight during the score phase
+        floatx16 sacc[KTILES];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+        for (int kt = 0; kt < KTILES; ++kt) {
 #pragma unroll
-    for (int kt = 0; kt < ((ablate & 16) ? 1 : KTILES); ++kt)
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+            const float* kp = KV + (kt * 32 + li) * KV_LD + 4 * half;
+#pragma unroll
+            for (int q8 = 0; q8 < ((ablate & 32) ? 1 : 8); ++q8) {
+                const att_f32x4 kf = *reinterpret_cast<const att_f32x4*>(kp + 8 * q8);
+                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[q8].x, sacc[kt], 0, 0, 0);
+                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[q8].y, sacc[kt], 0, 0, 0);
+                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[q8].z, sacc[kt], 0, 0, 0);
+                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[q8].w, sacc[kt], 0, 0, 0);
+            }
+        }
+        ATT_STAMP(0);   // score MFMAs
+        // sacc[kt][r] = score(query li, key kt*32 + (r&3) + 8*(r>>2) + 4*half)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KTILES; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= NTOK) sacc[kt][r] = -INFINITY;
+                mx = fmaxf(mx, sacc[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KTILES; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // scores carry log2(e) (folded into the Q scale with head_dim^-0.5), so exp() is one v_exp_f32
+                const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - mx);
+                sacc[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        if (half == 0) rowsum[wave * 32 + li] = sum;
+        ATT_STAMP(1);   // softmax
+        __syncthreads();          // every wave is done with K
+        ATT_STORE_KV();           // V takes its place
+        __syncthreads();
+        const int next = item + gridDim.x;
+        if (next < total_items) ATT_LOAD_KV(next, dim);   // K of the next item: in flight during the P V phase
+        ATT_STAMP(2);   // barrier + V store + barrier + issue K loads
+
+        floatx16 oacc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+#pragma unroll
+        for (int kt = 0; kt < ((ablate & 16) ? 1 : KTILES); ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v0 = KV[key * KV_LD + li];
+                const float v1 = KV[key * KV_LD + 32 + li];
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r], v0, oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r], v1, oacc[1], 0, 0, 0);
+            }
+        ATT_STAMP(3);   // P V MFMAs
+        // oacc[dt][r] = O(query wave*32 + (r&3)+8*(r>>2)+4*half, d = dt*32 + li)
+        float* ob = out + (int64_t)(item / heads) * NTOK * dim + (item % heads) * 64 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float v0 = Vs[key * KV_LD + li];
-            const float v1 = Vs[key * KV_LD + 32 + li];
-            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r], v0, oacc[0], 0, 0, 0);
-            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r], v1, oacc[1], 0, 0, 0);
+            const int qt = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int q = wave * 32 + qt;
+            if (q < NTOK) {
+                const float inv = 1.0f / rowsum[wave * 32 + qt];
+                ob[(int64_t)q * dim] = oacc[0][r] * inv;
+                ob[(int64_t)q * dim + 32] = oacc[1][r] * inv;
+            }
         }
-    // oacc[dt][r] = O(query wave*32 + (r&3)+8*(r>>2)+4*half, d = dt*32 + li)
-    float* ob = out + (int64_t)img * NTOK * dim + head * 64 + li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int qt = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int q = wave * 32 + qt;
-        if (q < NTOK) {
-            const float inv = 1.0f / rowsum[wave * 32 + qt];
-            ob[(int64_t)q * dim] = oacc[0][r] * inv;
-            ob[(int64_t)q * dim + 32] = oacc[1][r] * inv;
-        }
+        ATT_STAMP(4);   // output stores
+        if (next >= total_items) break;
+        ATT_LOAD_Q(next);
+        __syncthreads();          // every wave is done with V (and with rowsum)
+        ATT_STORE_KV();           // next item's K
+        __syncthreads();
+        item = next;
+        ATT_STAMP(5);   // Q loads + barrier + K store + barrier
     }
+    if (stamps && lane == 0) {
+        for (int i = 0; i < 6; ++i) stamps[((size_t)blockIdx.x * KTILES + wave) * 6 + i] = seg[i];
+    }
+#undef ATT_STAMP
+#undef ATT_LOAD_KV
+#undef ATT_STORE_KV
+#undef ATT_LOAD_Q
 }
 
 int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s) {
@@ -200,8 +242,27 @@ int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, in
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_197x64, dim3(Nimg * heads), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, h->gemm.ablate & 56);
+    const int total = Nimg * heads;
+    // one persistent workgroup (7 waves, ~250 VGPRs) per CU
+    const int grid = total < 256 ? total : 256;
+    unsigned long long* stamps = nullptr;
+    if (h->gemm.ablate & 64) {   // diagnostic: phase shares, printed after a sync (never in a timed or product run)
+        RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * (size_t)grid * KTILES * 6));
+        stamps = static_cast<unsigned long long*>(h->scratch.p);
+    }
+    hipLaunchKernelGGL(attention_197x64, dim3(grid), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, total,
+                       h->gemm.ablate & 56, stamps);
     RELAX_HIP_CHECK(h, hipGetLastError());
+    if (stamps) {
+        RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
+        std::vector<unsigned long long> hs((size_t)grid * KTILES * 6);
+        RELAX_HIP_CHECK(h, hipMemcpy(hs.data(), stamps, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
+        double tot[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t i = 0; i < hs.size(); ++i) tot[i % 6] += (double)hs[i];
+        const double n = (double)grid * KTILES * ((total + grid - 1) / grid);
+        fprintf(stderr, "attention phase cycles per wave per item: S %.0f softmax %.0f sync+Vstore %.0f PV %.0f stores %.0f Q+sync+Kstore %.0f\n",
+                tot[0] / n, tot[1] / n, tot[2] / n, tot[3] / n, tot[4] / n, tot[5] / n);
+    }
     return RELAX_OK;
 }
 
