@@ -125,7 +125,7 @@ def main():
     def step(i):
         batch = [clips[(i * B + j) % n_resident] for j in range(B)]
         if full:
-            vecs = torch.stack([eng.full_clip_vector(c, flow=True) for c in batch])
+            vecs = eng.full_clip_vectors(batch, flow=True)
         else:
             vecs = eng.clip_vectors(batch, resnet=True, vit=use_vit)          # [B, feat_dim]
         if world > 1:

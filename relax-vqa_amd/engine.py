@@ -349,6 +349,27 @@ class RelaxEngine:
         ls, vp = self.whole_frame_features(frames[:, 0])
         return torch.cat([ls.mean(dim=0), vp.mean(dim=0), f["resnet"].mean(dim=0), f["vit"].mean(dim=0)])
 
+    def full_clip_vectors(self, clips, flow=True, flow_images=None):
+        """Several clips -> fp32 [len(clips), 35203] in ONE batched pass of each backbone (3*T fragments / frames per
+        clip: original fragment, residual fragment, whole frame).  Same layout as full_clip_vector."""
+        ori, res, bil, lan, counts = [], [], [], [], []
+        for i, c in enumerate(clips):
+            fr = self.fragment_pairs(c)
+            r = fr["diff_frag"]
+            fimg = None if flow_images is None else flow_images[i]
+            if flow and fimg is None:
+                _, fimg = self.optical_flow(c)
+            if fimg is not None:
+                r = self.merge_fragments(r, self.fragment_image(fimg)["frag"])
+            b, l = self.resize_frames(c[:, 0])
+            ori.append(fr["ori_frag"]); res.append(r); bil.append(b); lan.append(l)
+            counts.append(r.shape[0])
+        n = sum(counts)
+        ls, pool = self.resnet50_features(torch.cat(ori + res + bil, dim=0), layer_stack=True, pool=True)
+        _, vp = self.vit_features(torch.cat(ori + res + lan, dim=0), tokens=False, pooled=True)
+        per_frame = torch.cat([ls[2 * n:], vp[2 * n:], ls[:n], pool[n:2 * n], vp[:n], vp[n:2 * n]], dim=1)
+        return torch.stack([chunk.mean(dim=0) for chunk in torch.split(per_frame, counts, dim=0)])
+
     def clip_vector(self, frames, **kw):
         """Per-clip mean over frames of the concatenated features (src/demo_test.py:171-175)."""
         f = self.extract_clip(frames, **kw)

@@ -124,3 +124,15 @@ def test_full_35203_vector(api):
     rn_in = np.stack([resize_ref.resize(clip[t, 0], 224, 224, resize_ref.BILINEAR) for t in range(2)])
     want = resnet50_ref.layer_stack_features(resnet50_ref.to_torch_state_dict(rn), rn_in).mean(axis=0)
     assert_close(vec[:13120], want, "full vector: whole-frame ResNet block")
+
+
+def test_batched_full_vectors_match_single(api):
+    from relax_vqa_amd import runtime
+    import torch
+    eng = runtime.get_engine()
+    a = torch.from_numpy(synth.synthetic_clip(2, 272, 400, clip_id=13)).cuda()
+    b = torch.from_numpy(synth.synthetic_clip(1, 240, 320, clip_id=14)).cuda()
+    both = eng.full_clip_vectors([a, b], flow=True)
+    alone = torch.stack([eng.full_clip_vector(a, flow=True), eng.full_clip_vector(b, flow=True)])
+    assert both.shape == (2, 35203)
+    assert_close(both, alone.cpu().numpy(), "batched vs single full vectors", rtol=1e-4, atol_frac=1e-5)
