@@ -67,6 +67,69 @@ __global__ __launch_bounds__(256) void gauss_pass(const float* __restrict__ src,
     dst[i] = acc;
 }
 
+// Coarse pyramid levels (scale 1/4, 1/8): cv::resize only samples the blurred frame at 2 columns x 2 rows per output
+// pixel, so the blur is evaluated at those samples only - same taps, same order, same interpolation arithmetic as
+// gauss_pass + resize_linear_f32 (bit-identical), a fraction of the work.
+__device__ inline void linear_tap(int d, double scale, int n_in, int* s0, int* s1, float* f) {
+    float fx = (float)((d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= n_in - 1) { fx = 0.f; sx = n_in - 1; }
+    *s0 = sx;
+    *s1 = sx + 1 < n_in ? sx + 1 : n_in - 1;
+    *f = fx;
+}
+
+// horizontal blur at the two sample columns of every output column: src [B][H][W] -> tmp [B][H][w][2]
+__global__ __launch_bounds__(256) void gauss_h_sampled(const float* __restrict__ src, float* __restrict__ tmp, int H, int W,
+                                                       int w, double scale_x, GaussKernel gk, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H*w*2
+    if (i >= total) return;
+    const int j = (int)(i & 1);
+    const int dx = (int)((i >> 1) % w);
+    const int64_t row = (i >> 1) / w;                                    // b*H + y
+    int s0, s1;
+    float f;
+    linear_tap(dx, scale_x, W, &s0, &s1, &f);
+    const int x = j ? s1 : s0;
+    const float* r_ = src + row * W;
+    const int r = gk.ksize / 2;
+    float acc = 0.f;
+    for (int t = 0; t < gk.ksize; ++t) acc += gk.k[t] * r_[reflect101(x + t - r, W)];
+    tmp[i] = acc;
+}
+
+// vertical blur at the two sample rows + the bilinear combine: tmp [B][H][w][2] -> dst [B][h][w]
+__global__ __launch_bounds__(256) void gauss_v_sampled_resize(const float* __restrict__ tmp, float* __restrict__ dst, int H,
+                                                              int W, int h, int w, double scale_y, double scale_x,
+                                                              GaussKernel gk, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*h*w
+    if (i >= total) return;
+    const int dx = (int)(i % w);
+    const int dy = (int)((i / w) % h);
+    const int64_t b = i / ((int64_t)w * h);
+    int sy0, sy1, sx0, sx1;
+    float fy, fx;
+    linear_tap(dy, scale_y, H, &sy0, &sy1, &fy);
+    linear_tap(dx, scale_x, W, &sx0, &sx1, &fx);
+    const float* img = tmp + b * ((int64_t)H * w * 2) + dx * 2;
+    const int r = gk.ksize / 2;
+    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;   // blurred (row sy0|sy1, col sx0|sx1)
+    for (int t = 0; t < gk.ksize; ++t) {
+        const float k = gk.k[t];
+        const float* p0 = img + (int64_t)reflect101(sy0 + t - r, H) * w * 2;
+        const float* p1 = img + (int64_t)reflect101(sy1 + t - r, H) * w * 2;
+        a00 += k * p0[0];
+        a01 += k * p0[1];
+        a10 += k * p1[0];
+        a11 += k * p1[1];
+    }
+    const float r0 = a00 * (1.f - fx) + a01 * fx;
+    const float r1 = a10 * (1.f - fx) + a11 * fx;
+    dst[i] = r0 * (1.f - fy) + r1 * fy;
+}
+
 // cv::resize INTER_LINEAR on float [B][H][W][C] -> [B][h][w][C], result scaled by mul (flow upsampling: 1/pyr_scale)
 __global__ __launch_bounds__(256) void resize_linear_f32(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
                                                          int h, int w, int C, double scale_y, double scale_x, float mul,
@@ -458,14 +521,23 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
         }
         GaussKernel gk;
         make_gauss(smooth, sigma, &gk);
-        hipLaunchKernelGGL(gauss_pass<false>, dim3(nblocks(tot_px2)), dim3(256), 0, s, gray, tmp, H, W, gk, tot_px2);
-        hipLaunchKernelGGL(gauss_pass<true>, dim3(nblocks(tot_px2)), dim3(256), 0, s, tmp, blur, H, W, gk, tot_px2);
-        const float* Isrc = blur;
+        const float* Isrc;
         const int64_t tot_l2 = (int64_t)P * 2 * hw;
-        if (w != W || hh != H) {
-            hipLaunchKernelGGL(resize_linear_f32, dim3(nblocks(tot_l2)), dim3(256), 0, s, blur, I, H, W, hh, w, 1,
-                               (double)H / hh, (double)W / w, 1.0f, tot_l2);
+        if (k >= 2) {   // coarse levels: blur only where the resize samples
+            const int64_t tot_h = (int64_t)P * 2 * H * w * 2;
+            hipLaunchKernelGGL(gauss_h_sampled, dim3(nblocks(tot_h)), dim3(256), 0, s, gray, tmp, H, W, w, (double)W / w, gk, tot_h);
+            hipLaunchKernelGGL(gauss_v_sampled_resize, dim3(nblocks(tot_l2)), dim3(256), 0, s, tmp, I, H, W, hh, w,
+                               (double)H / hh, (double)W / w, gk, tot_l2);
             Isrc = I;
+        } else {
+            hipLaunchKernelGGL(gauss_pass<false>, dim3(nblocks(tot_px2)), dim3(256), 0, s, gray, tmp, H, W, gk, tot_px2);
+            hipLaunchKernelGGL(gauss_pass<true>, dim3(nblocks(tot_px2)), dim3(256), 0, s, tmp, blur, H, W, gk, tot_px2);
+            Isrc = blur;
+            if (w != W || hh != H) {
+                hipLaunchKernelGGL(resize_linear_f32, dim3(nblocks(tot_l2)), dim3(256), 0, s, blur, I, H, W, hh, w, 1,
+                                   (double)H / hh, (double)W / w, 1.0f, tot_l2);
+                Isrc = I;
+            }
         }
         hipLaunchKernelGGL(poly_vertical, dim3(nblocks(tot_l2)), dim3(256), 0, s, Isrc, T, hh, w, pc, tot_l2);
         hipLaunchKernelGGL(poly_horizontal, dim3(nblocks(tot_l2)), dim3(256), 0, s, T, R, hh, w, pc, tot_l2);
