@@ -50,22 +50,40 @@ HBM_PEAK_GBPS = 8000.0
 
 def cpu_baseline(H, W, T, use_vit, rn_sd, vit_sd, sample_pairs):
     """Oracle timed on this host's cores (kind 'port'): reference-faithful schedule on `sample_pairs` pairs of the
-    same workload, extrapolated to a clip; the de-duplicated schedule is reported beside it."""
+    same workload, extrapolated to a clip; the de-duplicated schedule is reported beside it.  Batch size 1 does not
+    scale to every core of a big host, so the thread count is calibrated first (one pair per candidate) and the CPU is
+    timed at its best; the default-thread-count figure (what the reference would use as shipped) is reported too."""
     from oracle import pipeline_ref
     frames = synth.synthetic_clip(sample_pairs, H, W, clip_id=99)
     vit = vit_sd if use_vit else None
+    default_threads = torch.get_num_threads()
     pipeline_ref.clip_features(frames[:1], rn_sd, vit, schedule="dedup")   # warm the thread pool / allocator
+    candidates = sorted({t for t in (8, 16, 32, 64, default_threads) if t <= default_threads})
+    timing = {}
+    for t in candidates:
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        pipeline_ref.clip_features(frames[:1], rn_sd, vit, schedule="dedup")
+        timing[t] = time.perf_counter() - t0
+    best = min(timing, key=timing.get)
+    torch.set_num_threads(best)
     t0 = time.perf_counter()
     pipeline_ref.clip_features(frames, rn_sd, vit, schedule="faithful")
     t_faithful = (time.perf_counter() - t0) / sample_pairs * T
     t0 = time.perf_counter()
     pipeline_ref.clip_features(frames, rn_sd, vit, schedule="dedup")
     t_dedup = (time.perf_counter() - t0) / sample_pairs * T
+    torch.set_num_threads(default_threads)
+    t0 = time.perf_counter()
+    pipeline_ref.clip_features(frames[:1], rn_sd, vit, schedule="faithful")
+    t_faithful_default = (time.perf_counter() - t0) * T
     return {
-        "value": 1.0 / t_faithful, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+        "value": 1.0 / t_faithful, "unit": "clips/s", "cores": best, "kind": "port",
         "sample": f"{sample_pairs} of {T} pairs of one {W}x{H} clip, reference-faithful schedule "
-                  f"(15+1 ResNet-50 forwards/pair, python patch loop, ViT rebuilt per call), bs 1, fp32, torch CPU",
+                  f"(15+1 ResNet-50 forwards/pair, python patch loop, ViT rebuilt per call), bs 1, fp32, torch CPU at its "
+                  f"best thread count ({best}, calibrated over {candidates})",
         "dedup_value": 1.0 / t_dedup, "sec_per_clip_faithful": t_faithful, "sec_per_clip_dedup": t_dedup,
+        "default_threads": default_threads, "value_at_default_threads": 1.0 / t_faithful_default,
         "host_cpus": os.cpu_count(),
     }
 
