@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=4)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=16)
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 measurement")
     ap.add_argument("--clips-per-step", type=int, default=8,
                     help="clips each rank pushes through the engine per step (one batched pass: B*2*T fragments)")
