@@ -61,3 +61,15 @@ def test_rccl_all_gather_single_rank():
         assert torch.equal(out, local)
     finally:
         dist.destroy_process_group()
+
+
+def test_pinned_feeder_overlaps_and_preserves_data():
+    from relax_vqa_amd.feeder import PinnedClipFeeder
+    clips = [torch.from_numpy(synth.synthetic_clip(2, 64, 96, clip_id=50 + i)).pin_memory() for i in range(3)]
+    feeder = PinnedClipFeeder(clips, 2, torch.device("cuda", 0))
+    seen = []
+    feeder.run(4, lambda batch: seen.append([b.clone() for b in batch]))
+    torch.cuda.synchronize()
+    for k, batch in enumerate(seen):
+        for j, b in enumerate(batch):
+            assert torch.equal(b.cpu(), clips[(k * 2 + j) % 3]), (k, j)
