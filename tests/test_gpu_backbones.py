@@ -83,6 +83,23 @@ def test_vit_base_oracle_batch():
     assert_close(pooled, vit_ref.pool_features(tsd, frags, 12), "vit_base pooled")
 
 
+def test_config1_eight_224_frames_pool_path():
+    """BASELINE config 1: 8 sampled frames already 224x224 -> every one of the 14x14 patches is kept, in raster order,
+    so the original fragment IS the frame; ResNet-50 `pool` path -> [8, 2051]."""
+    sd = rn50_weights()
+    clip = synth.synthetic_clip(8, 224, 224, clip_id=11)
+    frag = engine().fragment_pairs(torch.from_numpy(clip).cuda())
+    assert frag["counts"].tolist() == [196] * 8
+    raster = np.stack(np.divmod(np.arange(196), 14), 1).astype(np.int32)
+    assert np.array_equal(frag["positions"].cpu().numpy(), np.broadcast_to(raster, (8, 196, 2)))
+    assert np.array_equal(frag["ori_frag"].cpu().numpy(), clip[:, 0])
+    assert np.array_equal(frag["diff_frag"].cpu().numpy(), fragment_ref.absdiff(clip[:, 0], clip[:, 1]))
+    _, pool = engine().resnet50_features(frag["ori_frag"], layer_stack=False, pool=True)
+    want = resnet50_ref.pool_features(resnet50_ref.to_torch_state_dict(sd), clip[:, 0])
+    assert pool.shape == (8, 2051)
+    assert_close(pool, want, "config 1 pool features")
+
+
 def test_extract_clip_config2_shape_720p():
     """BASELINE config 2 (720p, residual-fragment + RN50 layer-stack) on a short clip, against the oracle."""
     sd = rn50_weights()
