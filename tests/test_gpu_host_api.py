@@ -136,3 +136,47 @@ def test_batched_full_vectors_match_single(api):
     alone = torch.stack([eng.full_clip_vector(a, flow=True), eng.full_clip_vector(b, flow=True)])
     assert both.shape == (2, 35203)
     assert_close(both, alone.cpu().numpy(), "batched vs single full vectors", rtol=1e-4, atol_frac=1e-5)
+
+
+def test_variant_drivers_keep_their_own_signatures(api, tmp_path):
+    """main_residual_fragment / main_fragment_pool / main_layer_stack: the arities and layer names of those reference
+    files (src/main_residual_fragment.py:83-214, src/main_fragment_pool.py:83-143, src/main_layer_stack.py:81-151)."""
+    from relax_vqa_amd import main_fragment_pool as mp
+    from relax_vqa_amd import main_layer_stack as ml
+    from relax_vqa_amd import main_residual_fragment as mr
+    m, rn, vit = api
+    o, nx = synth.synthetic_pair(272, 400, 31)
+    ref = fragment_ref.fragment_pair(o, nx)
+    residual = fragment_ref.absdiff(nx, o)
+    # residual-fragment driver: image only / path only; the fragment travels under its path name, not through a PNG
+    assert np.array_equal(mr.extract_important_patches(residual, mr.get_patch_diff(residual, 16)), ref["diff_frag"])
+    path = mr.process_patches(str(tmp_path / "a_1.png"), "frame_diff", residual, 16, 224, 196)
+    assert isinstance(path, str) and path.endswith("a_1_residual_imp.png") and not os.path.exists(path)
+    _, _, act = mr.get_deep_feature("resnet50", "a", path, "original", "pool")
+    _, _, last = mr.get_deep_feature("resnet50", "a", ref["diff_frag"], "original", "last_layer")
+    _, _, tok = mr.get_deep_feature("vit", "a", ref["diff_frag"], "original", "pool")
+    assert act.shape == (2048, 1, 1) and last.shape == (2048, 7, 7) and tok.shape == (196, 768)
+    tr = resnet50_ref.to_torch_state_dict(rn)
+    assert_close(mr.process_video_feature([act], "resnet50"), resnet50_ref.pool_features(tr, ref["diff_frag"][None]),
+                 "residual-fragment driver pool")
+    assert_close(last.mean(axis=(1, 2)), np.asarray(act).reshape(-1), "last_layer tap vs avgpool")
+    assert_close(mp.process_video_feature([tok], "vit"),
+                 vit_ref.pool_features(vit_ref.to_torch_state_dict(vit), ref["diff_frag"][None], 12), "pool driver vit")
+    with pytest.raises(NotImplementedError):
+        mr.process_video_feature([last], "resnet50")
+    with pytest.raises(ValueError):
+        mr.get_deep_feature("resnet50", "a", ref["diff_frag"], "original", "layer_stack")
+    # the pool driver returns triples like main_fragment_layerstack
+    p2, frag2, pos2 = mp.process_patches(str(tmp_path / "a_1.png"), "optical_flow", residual, 16, 224, 196)
+    assert p2.endswith("a_1_residual_of_imp.png") and np.array_equal(frag2, ref["diff_frag"])
+    assert pos2 == [tuple(p) for p in ref["positions"].tolist()]
+    # whole-frame driver: four / two arguments
+    _, _, taps = ml.get_deep_feature("resnet50", "a", o, "original")
+    rn_in = np.ascontiguousarray(np.asarray(Image.fromarray(np.ascontiguousarray(o[..., ::-1]))
+                                            .resize((224, 224), Image.BILINEAR))[..., ::-1])[None]
+    assert_close(ml.process_video_feature([taps], "resnet50"), resnet50_ref.layer_stack_features(tr, rn_in),
+                 "whole-frame driver")
+    _, _, wtok = ml.get_deep_feature("vit", "a", o, "original")
+    assert ml.process_video_feature([wtok], "vit").shape == (1, 2304)
+    with pytest.raises(NotImplementedError):
+        ml.get_deep_feature("vgg16", "a", o, "original")
