@@ -198,12 +198,14 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
             uint2* B8_ = reinterpret_cast<uint2*>(Bs_);                                                 \
             _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                     \
                 uint2 hi_, lo_;                                                                       \
+                if (p.ablate & 8) { hi_.x = __float_as_uint(ra[i].x); hi_.y = __float_as_uint(ra[i].y); lo_.x = __float_as_uint(ra[i].z); lo_.y = __float_as_uint(ra[i].w); } else \
                 split_bf16x4(ra[i], &hi_, &lo_);                                                      \
                 A8_[(i * PASS + lrow) * 18 + c4] = hi_;                                               \
                 A8_[(i * PASS + lrow) * 18 + 8 + c4] = lo_;                                           \
             }                                                                                         \
             _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                     \
                 uint2 hi_, lo_;                                                                       \
+                if (p.ablate & 16) { hi_.x = __float_as_uint(rb[i].x); hi_.y = __float_as_uint(rb[i].y); lo_.x = __float_as_uint(rb[i].z); lo_.y = __float_as_uint(rb[i].w); } else \
                 split_bf16x4(rb[i], &hi_, &lo_);                                                      \
                 B8_[(i * PASS + lrow) * 18 + c4] = hi_;                                               \
                 B8_[(i * PASS + lrow) * 18 + 8 + c4] = lo_;                                           \
@@ -542,7 +544,11 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     if (p.N % 128 != 0) variant = h->gemm.variant_n64 >= 0 ? h->gemm.variant_n64 : 10;
     int rc;
     if (h->gemm.precision == 1) {   // opt-in bf16x3
-        rc = (p.N % 128 == 0) ? RELAX_DISPATCH_X3(128, 128, 2, 2, 2, 2) : RELAX_DISPATCH_X3(128, 64, 2, 2, 2, 2);
+        // plain GEMMs with enough rows take a 256x256 tile on 8 waves (128x64 per wave, one workgroup per CU): half the
+        // L2 -> LDS bytes per MFMA of the 128x128 tile, +15 % on the ViT shapes (tools/gemm_bench.py --precision bf16x3)
+        const bool big = !taps && p.N % 256 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 256) >= 256 && h->gemm.variant != 1;
+        if (big) rc = launch_variant<256, 256, 2, 4, 32, 1, false, 1>(h, p, 1, s);
+        else rc = (p.N % 128 == 0) ? RELAX_DISPATCH_X3(128, 128, 2, 2, 2, 2) : RELAX_DISPATCH_X3(128, 64, 2, 2, 2, 2);
         RELAX_TRY(rc);
         RELAX_TRY(prof_end(h, s, span));
         return RELAX_OK;

@@ -137,3 +137,15 @@ def test_conv_bf16x3_accuracy(bf16x3, Nimg, H, Cin, Cout, k, stride, pad):
     got = engine().op_conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), torch.from_numpy(pack_conv_weight(w.numpy())).cuda(),
                                   b.cuda(), None, Cout, k, k, stride, pad, act=1).permute(0, 3, 1, 2).cpu().numpy()
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-5
+
+
+def test_gemm_bf16x3_large_tile_path(bf16x3):
+    """Enough 256x256 tiles (>= 256) to take the 8-wave large-tile kernel: ragged M, tail split-K, fused epilogue."""
+    M, N, K = 25001, 768, 768
+    A, W, b, r = _rand(M, K, seed=11), _rand(N, K, seed=12, scale=K ** -0.5), _rand(N, seed=13), _rand(M, N, seed=14)
+    want = F.gelu((A.double().cuda() @ W.double().cuda().T) + b.double().cuda() + r.double().cuda()).float().cpu().numpy()
+    got = engine().op_gemm(A.cuda(), W.cuda(), b.cuda(), r.cuda(), act=2).cpu().numpy()
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-5
+    assert_close(got, want, "bf16x3 large-tile gemm", rtol=1e-3, atol_frac=2e-4)
+    fp32_rows = engine().op_gemm(A[:300].cuda(), W.cuda(), b.cuda(), r[:300].cuda(), act=2).cpu().numpy()   # small-tile path
+    assert np.linalg.norm(fp32_rows - got[:300]) / np.linalg.norm(got[:300]) < 2e-5

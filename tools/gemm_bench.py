@@ -30,12 +30,19 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default=None)
     ap.add_argument("--residual", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"])
+    ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--clips", type=int, default=1, help="scale M by this many clips")
     args = ap.parse_args()
     eng = RelaxEngine(0)
+    eng.set_precision(args.precision)
+    if args.variant >= 0:
+        eng.set_option("gemm_variant", args.variant)
     dev = torch.device("cuda")
     for name, (M, N, K) in GEMMS.items():
         if args.only and args.only not in name:
             continue
+        M *= args.clips
         A = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) * K ** -0.5
         b = torch.randn(N, device=dev)
