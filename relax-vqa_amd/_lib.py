@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librelax_hip.so")
+LIB_PATH = os.environ.get("RELAX_HIP_LIB") or os.path.join(_HERE, "csrc", "librelax_hip.so")   # override: another build of it
 
 c_u8p = C.POINTER(C.c_uint8)
 c_i32p = C.POINTER(C.c_int32)

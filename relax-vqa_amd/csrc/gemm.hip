@@ -78,7 +78,7 @@ __device__ inline float apply_act(float v, int act) {
 // relative error per product (features stay within ~1e-5 of the fp32 path, bar 1e-3) at 3/16 of the fp32 MFMA cycles.
 template <int BM, int BN, int WM, int WN, int BK, int OCC, bool TAPS, int PREC>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmParams p) {
-    static_assert(PREC == 0 || BK == 32, "bf16x3 stages 32-deep K steps (one 144-byte LDS row: 32 hi + 32 lo + pad)");
+    static_assert(PREC == 0 || BK == 32 || BK == 16, "bf16x3 LDS row image: [BK x bf16 hi][BK x bf16 lo][16 B pad]");
     constexpr int NT = WM * WN * 64;
     constexpr int LDK = BK + 4;   // padded LDS row: conflict-free b128 writes and reads for BK = 32 (36) and 16 (20)
     constexpr int KL = BK / 4;    // lanes (float4) per K step of a row
@@ -176,7 +176,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
         } else {                                                                                      \
             _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                     \
                 f32x4 v_ = zero4;                                                                     \
-                if (a_ok[i]) v_ = *reinterpret_cast<const f32x4*>(p.in + a_base[i] + k_);             \
+                /* rows past M were clamped to row 0: loading them unconditionally keeps the loop branch-free */ \
+                if (PREC == 1 || a_ok[i]) v_ = *reinterpret_cast<const f32x4*>(p.in + a_base[i] + k_); \
                 ra[i] = v_;                                                                           \
             }                                                                                         \
         }                                                                                             \
@@ -193,22 +194,22 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
             _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i)                                       \
                 *reinterpret_cast<f32x4*>(Bs_ + (i * PASS + lrow) * LDK + c4 * 4) = rb[i];            \
         } else {                                                                                      \
-            /* row image: [32 x bf16 hi][32 x bf16 lo][16 B pad] = 144 B = 18 x 8-byte slots */         \
+            /* row image: [BK x bf16 hi][BK x bf16 lo][16 B pad] = LDK * 4 bytes = LDK / 2 8-byte slots */ \
             uint2* A8_ = reinterpret_cast<uint2*>(As_);                                                 \
             uint2* B8_ = reinterpret_cast<uint2*>(Bs_);                                                 \
             _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                     \
                 uint2 hi_, lo_;                                                                       \
                 if (p.ablate & 8) { hi_.x = __float_as_uint(ra[i].x); hi_.y = __float_as_uint(ra[i].y); lo_.x = __float_as_uint(ra[i].z); lo_.y = __float_as_uint(ra[i].w); } else \
                 split_bf16x4(ra[i], &hi_, &lo_);                                                      \
-                A8_[(i * PASS + lrow) * 18 + c4] = hi_;                                               \
-                A8_[(i * PASS + lrow) * 18 + 8 + c4] = lo_;                                           \
+                A8_[(i * PASS + lrow) * (LDK / 2) + c4] = hi_;                                               \
+                A8_[(i * PASS + lrow) * (LDK / 2) + BK / 4 + c4] = lo_;                                           \
             }                                                                                         \
             _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                     \
                 uint2 hi_, lo_;                                                                       \
                 if (p.ablate & 16) { hi_.x = __float_as_uint(rb[i].x); hi_.y = __float_as_uint(rb[i].y); lo_.x = __float_as_uint(rb[i].z); lo_.y = __float_as_uint(rb[i].w); } else \
                 split_bf16x4(rb[i], &hi_, &lo_);                                                      \
-                B8_[(i * PASS + lrow) * 18 + c4] = hi_;                                               \
-                B8_[(i * PASS + lrow) * 18 + 8 + c4] = lo_;                                           \
+                B8_[(i * PASS + lrow) * (LDK / 2) + c4] = hi_;                                               \
+                B8_[(i * PASS + lrow) * (LDK / 2) + BK / 4 + c4] = lo_;                                           \
             }                                                                                         \
         }                                                                                             \
     }
@@ -253,17 +254,17 @@ _Pragma("unroll")  \
             const char* Ab = reinterpret_cast<const char*>(smem + (cur_) * STAGE + (wm * TM * 32 + (lane & 31)) * LDK) + 16 * (lane >> 5);  \
             const char* Bb = reinterpret_cast<const char*>(smem + (cur_) * STAGE + BM * LDK + (wn * TN * 32 + (lane & 31)) * LDK) + 16 * (lane >> 5);  \
 _Pragma("unroll")  \
-            for (int ks = 0; ks < 2; ++ks) {  \
+            for (int ks = 0; ks < BK / 16; ++ks) {  \
                 bf16x8 ah[TM], al[TM], bh[TN], bl[TN];  \
 _Pragma("unroll")  \
                 for (int i = 0; i < TM; ++i) {  \
                     ah[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + ks * 32);  \
-                    al[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + 64 + ks * 32);  \
+                    al[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + BK * 2 + ks * 32);  \
                 }  \
 _Pragma("unroll")  \
                 for (int j = 0; j < TN; ++j) {  \
                     bh[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + ks * 32);  \
-                    bl[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + 64 + ks * 32);  \
+                    bl[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + BK * 2 + ks * 32);  \
                 }  \
 _Pragma("unroll")  \
                 for (int i = 0; i < TM; ++i)  \
@@ -276,6 +277,60 @@ _Pragma("unroll")  \
             }  \
         }  \
         if (p.prio) __builtin_amdgcn_s_setprio(0);  \
+    }
+
+    // bf16x3 steady-state step: MFMAs on LDS buffer cur_, with the staged registers (ra, rb) of the NEXT tile split and
+    // stored to buffer nxt_ piece by piece between the accumulator blocks
+#define RELAX_COMPUTE_STORE_X3(cur_, nxt_, ra, rb)  \
+    {  \
+        constexpr int PIECES = A_LOADS + B_LOADS;  \
+        constexpr int BLOCKS = (BK / 16) * TM * TN;  \
+        const char* Ab = reinterpret_cast<const char*>(smem + (cur_) * STAGE + (wm * TM * 32 + (lane & 31)) * LDK) + 16 * (lane >> 5);  \
+        const char* Bb = reinterpret_cast<const char*>(smem + (cur_) * STAGE + BM * LDK + (wn * TN * 32 + (lane & 31)) * LDK) + 16 * (lane >> 5);  \
+        uint2* A8_ = reinterpret_cast<uint2*>(smem + (nxt_) * STAGE) + lrow * (LDK / 2) + c4;  \
+        uint2* B8_ = A8_ + BM * (LDK / 2);  \
+_Pragma("unroll")  \
+        for (int ks = 0; ks < BK / 16; ++ks) {  \
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];  \
+_Pragma("unroll")  \
+            for (int i = 0; i < TM; ++i) {  \
+                ah[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + ks * 32);  \
+                al[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + BK * 2 + ks * 32);  \
+            }  \
+_Pragma("unroll")  \
+            for (int j = 0; j < TN; ++j) {  \
+                bh[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + ks * 32);  \
+                bl[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + BK * 2 + ks * 32);  \
+            }  \
+_Pragma("unroll")  \
+            for (int i = 0; i < TM; ++i)  \
+_Pragma("unroll")  \
+                for (int j = 0; j < TN; ++j) {  \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);  \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);  \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);  \
+                    const int g_ = (ks * TM + i) * TN + j;  \
+_Pragma("unroll")  \
+                    for (int pc = 0; pc < PIECES; ++pc)  \
+                        if (pc * BLOCKS >= g_ * PIECES && pc * BLOCKS < (g_ + 1) * PIECES) {  \
+                            uint2 hi_, lo_;  \
+                            const f32x4 src_ = pc < A_LOADS ? ra[pc < A_LOADS ? pc : 0] : rb[pc >= A_LOADS ? pc - A_LOADS : 0];  \
+                            if (RELAX_X3_ABLATE & 8) {  \
+                                hi_.x = __float_as_uint(src_.x); hi_.y = __float_as_uint(src_.y);  \
+                                lo_.x = __float_as_uint(src_.z); lo_.y = __float_as_uint(src_.w);  \
+                            } else {  \
+                                split_bf16x4(src_, &hi_, &lo_);  \
+                            }  \
+                            uint2* dst_ = pc < A_LOADS ? A8_ + pc * PASS * (LDK / 2) : B8_ + (pc - A_LOADS) * PASS * (LDK / 2);  \
+                            if (RELAX_X3_ABLATE & 4) {  \
+                                asm volatile("" ::"v"(hi_.x), "v"(hi_.y), "v"(lo_.x), "v"(lo_.y));  \
+                            } else {  \
+                                dst_[0] = hi_;  \
+                                dst_[BK / 4] = lo_;  \
+                            }  \
+                        }  \
+                }  \
+        }  \
     }
 
     if constexpr (PREC == 0) {
@@ -297,7 +352,21 @@ _Pragma("unroll")  \
         RELAX_STORE_TILE_R(0, ra0, rb0);
         if (kt_begin + 1 < kt_end) RELAX_LOAD_TILE_R((kt_begin + 1) * BK, ra1, rb1);
         __syncthreads();
-        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+        int kt = kt_begin;
+        // steady state, branch-free: the split + LDS stores of tile k+1 are emitted between the MFMA blocks of tile k
+        // so that one basic block holds both and the VALU work runs under the matrix pipe
+#ifndef RELAX_X3_ABLATE
+#define RELAX_X3_ABLATE 0   // build-time timing experiments (WRONG results): 1 no barrier, 2 no global loads, 4 no LDS stores, 8 no split
+#endif
+        for (; kt + 3 < kt_end; kt += 2) {
+            if (!(RELAX_X3_ABLATE & 2)) RELAX_LOAD_TILE_R((kt + 2) * BK, ra0, rb0);
+            RELAX_COMPUTE_STORE_X3(0, 1, ra1, rb1);
+            if (!(RELAX_X3_ABLATE & 1)) __syncthreads();
+            if (!(RELAX_X3_ABLATE & 2)) RELAX_LOAD_TILE_R((kt + 3) * BK, ra1, rb1);
+            RELAX_COMPUTE_STORE_X3(1, 0, ra0, rb0);
+            if (!(RELAX_X3_ABLATE & 1)) __syncthreads();
+        }
+        for (; kt < kt_end; kt += 2) {
             if (kt + 2 < kt_end) RELAX_LOAD_TILE_R((kt + 2) * BK, ra0, rb0);
             RELAX_COMPUTE(0);
             if (kt + 1 < kt_end) RELAX_STORE_TILE_R(1, ra1, rb1);
@@ -311,14 +380,15 @@ _Pragma("unroll")  \
         }
     }
 #undef RELAX_COMPUTE
+#undef RELAX_COMPUTE_STORE_X3
 
     // ---- epilogue, staged through LDS -----------------------------------------------------------------------
     // The accumulators hold one column per lane and rows in registers (C/D map of the 32x32 MFMA:
     // col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); stored directly that is 64 dword stores per
     // lane.  Instead each 64-row chunk of the tile goes through the (now free) staging LDS and leaves as whole
     // 512-byte row segments: 16-byte loads/stores, 4x fewer memory instructions, bias/residual/activation fused.
-    constexpr int EP_ROWS = BM < 64 ? BM : 64;
     constexpr int LDC = BN + 4;
+    constexpr int EP_ROWS = BM < 64 ? BM : (64 * LDC <= 2 * STAGE ? 64 : 32);
     constexpr int C4 = BN / 4;                       // float4 per tile row
     constexpr int EP_ITERS = EP_ROWS * C4 / NT;
     static_assert(EP_ROWS * LDC <= 2 * STAGE, "epilogue chunk must fit the staging LDS");
@@ -547,7 +617,8 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
         // plain GEMMs with enough rows take a 256x256 tile on 8 waves (128x64 per wave, one workgroup per CU): half the
         // L2 -> LDS bytes per MFMA of the 128x128 tile, +15 % on the ViT shapes (tools/gemm_bench.py --precision bf16x3)
         const bool big = !taps && p.N % 256 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 256) >= 256 && h->gemm.variant != 1;
-        if (big) rc = launch_variant<256, 256, 2, 4, 32, 1, false, 1>(h, p, 1, s);
+        if (!taps && p.N % 256 == 0 && h->gemm.variant == 22) rc = launch_variant<128, 256, 1, 4, 16, 2, false, 1>(h, p, 2, s);
+        else if (big) rc = launch_variant<256, 256, 2, 4, 32, 1, false, 1>(h, p, 1, s);
         else rc = (p.N % 128 == 0) ? RELAX_DISPATCH_X3(128, 128, 2, 2, 2, 2) : RELAX_DISPATCH_X3(128, 64, 2, 2, 2, 2);
         RELAX_TRY(rc);
         RELAX_TRY(prof_end(h, s, span));
