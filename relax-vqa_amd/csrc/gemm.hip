@@ -18,6 +18,16 @@
 // neighbouring tiles: all column tiles of an activation row-tile run on the same XCD.
 #include "relax_internal.h"
 
+#ifndef RELAX_X3_ABLATE
+#define RELAX_X3_ABLATE 0   // build-time timing experiments on the bf16x3 loop (WRONG results): 1 no barrier, 2 no global loads,
+#endif                      // 4 no LDS stores, 8 no split, 16 half the fragment reads (tools/build_ablations.sh)
+
+#ifdef RELAX_GEMM_STAMPS   // diagnostic build (tools/build_ablations.sh stamps): wave 0 records 100 MHz timestamps per phase
+#define RELAX_STAMP(i_) if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i_)] = wall_clock64()
+#else
+#define RELAX_STAMP(i_)
+#endif
+
 namespace relax {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -41,6 +51,7 @@ struct GemmParams {
     int nsplit;      // tiles [full_tiles, ntiles) are cut into nsplit K slices (raw partial sums)
     int prio;        // experiment knob: raise wave priority around the MFMA cluster
     int ablate;      // timing-only experiment knob (wrong results): 1 no barrier, 2 no global loads, 4 no LDS stores
+    unsigned long long* stamps;   // RELAX_GEMM_STAMPS builds only: per-workgroup phase timestamps
 };
 
 __device__ inline int xcd_remap(int b, int nwg) {
@@ -127,6 +138,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
     }
     const int m0 = tm * BM;
     const int n0 = tn * BN;
+    RELAX_STAMP(0);
 
     // per-thread row descriptors of the A operand (fixed for the whole K loop)
     int64_t a_base[A_LOADS];
@@ -267,13 +279,12 @@ _Pragma("unroll")  \
                     bl[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + BK * 2 + ks * 32);  \
                 }  \
 _Pragma("unroll")  \
+                for (int t = 0; t < 3; ++t)  \
+_Pragma("unroll")  \
                 for (int i = 0; i < TM; ++i)  \
 _Pragma("unroll")  \
-                    for (int j = 0; j < TN; ++j) {  \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);  \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);  \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);  \
-                    }  \
+                    for (int j = 0; j < TN; ++j)  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? al[i] : ah[i], t == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);  \
             }  \
         }  \
         if (p.prio) __builtin_amdgcn_s_setprio(0);  \
@@ -284,7 +295,7 @@ _Pragma("unroll")  \
 #define RELAX_COMPUTE_STORE_X3(cur_, nxt_, ra, rb)  \
     {  \
         constexpr int PIECES = A_LOADS + B_LOADS;  \
-        constexpr int BLOCKS = (BK / 16) * TM * TN;  \
+        constexpr int BLOCKS = 3 * (BK / 16) * TM * TN;  /* MFMA slots of the step */  \
         const char* Ab = reinterpret_cast<const char*>(smem + (cur_) * STAGE + (wm * TM * 32 + (lane & 31)) * LDK) + 16 * (lane >> 5);  \
         const char* Bb = reinterpret_cast<const char*>(smem + (cur_) * STAGE + BM * LDK + (wn * TN * 32 + (lane & 31)) * LDK) + 16 * (lane >> 5);  \
         uint2* A8_ = reinterpret_cast<uint2*>(smem + (nxt_) * STAGE) + lrow * (LDK / 2) + c4;  \
@@ -295,21 +306,25 @@ _Pragma("unroll")  \
 _Pragma("unroll")  \
             for (int i = 0; i < TM; ++i) {  \
                 ah[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + ks * 32);  \
+                if (RELAX_X3_ABLATE & 16) al[i] = ah[i]; else  \
                 al[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + BK * 2 + ks * 32);  \
             }  \
 _Pragma("unroll")  \
             for (int j = 0; j < TN; ++j) {  \
                 bh[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + ks * 32);  \
+                if (RELAX_X3_ABLATE & 16) bl[j] = bh[j]; else  \
                 bl[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + BK * 2 + ks * 32);  \
             }  \
+            /* product type outermost: 8 independent accumulators between two MFMAs on the same one; per accumulator the  \
+               order lo*hi, hi*lo, hi*hi is unchanged */  \
+_Pragma("unroll")  \
+            for (int t = 0; t < 3; ++t)  \
 _Pragma("unroll")  \
             for (int i = 0; i < TM; ++i)  \
 _Pragma("unroll")  \
                 for (int j = 0; j < TN; ++j) {  \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);  \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);  \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);  \
-                    const int g_ = (ks * TM + i) * TN + j;  \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? al[i] : ah[i], t == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);  \
+                    const int g_ = ((ks * 3 + t) * TM + i) * TN + j;  \
 _Pragma("unroll")  \
                     for (int pc = 0; pc < PIECES; ++pc)  \
                         if (pc * BLOCKS >= g_ * PIECES && pc * BLOCKS < (g_ + 1) * PIECES) {  \
@@ -352,12 +367,10 @@ _Pragma("unroll")  \
         RELAX_STORE_TILE_R(0, ra0, rb0);
         if (kt_begin + 1 < kt_end) RELAX_LOAD_TILE_R((kt_begin + 1) * BK, ra1, rb1);
         __syncthreads();
+        RELAX_STAMP(1);
         int kt = kt_begin;
         // steady state, branch-free: the split + LDS stores of tile k+1 are emitted between the MFMA blocks of tile k
         // so that one basic block holds both and the VALU work runs under the matrix pipe
-#ifndef RELAX_X3_ABLATE
-#define RELAX_X3_ABLATE 0   // build-time timing experiments (WRONG results): 1 no barrier, 2 no global loads, 4 no LDS stores, 8 no split
-#endif
         for (; kt + 3 < kt_end; kt += 2) {
             if (!(RELAX_X3_ABLATE & 2)) RELAX_LOAD_TILE_R((kt + 2) * BK, ra0, rb0);
             RELAX_COMPUTE_STORE_X3(0, 1, ra1, rb1);
@@ -379,6 +392,7 @@ _Pragma("unroll")  \
             }
         }
     }
+    RELAX_STAMP(2);
 #undef RELAX_COMPUTE
 #undef RELAX_COMPUTE_STORE_X3
 
@@ -403,9 +417,28 @@ _Pragma("unroll")  \
         outp = p.out + (int64_t)m0 * p.N + n0;
         ldo = p.N;
     }
+    // a thread keeps its column group through every iteration and pass (NT is a multiple of the float4s per row), so its
+    // bias is ONE load, issued here, ahead of the first barrier (8 dependent L2 round trips per pass before: 6 us each)
+    static_assert(NT % C4 == 0, "a thread must keep its column group");
+    constexpr int EP_STEP = NT / C4;                 // tile rows covered per iteration
+    const int lc = (tid % C4) * 4;
+    const int lr0 = tid / C4;
+    f32x4 bias4 = zero4;
+    if (slice < 0 && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
+    const float act_floor = p.act == 1 ? 0.f : -INFINITY;   // ReLU / identity as one v_max
+    const bool interior = m0 + BM <= p.M;  // workgroup-uniform: interior tiles skip the per-row guards
 #pragma unroll
     for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
+        if (pass == 1) { RELAX_STAMP(4); }
         if (pass > 0) __syncthreads();
+        if (pass == 1) { RELAX_STAMP(5); }
+        f32x4 rv[EP_ITERS];
+        if (slice < 0 && interior) {
+#pragma unroll
+            for (int it = 0; it < EP_ITERS; ++it)   // residual rows of this pass: in flight under the LDS staging below
+                rv[it] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + (int64_t)(m0 + pass * EP_ROWS + it * EP_STEP + lr0) * p.N + n0 + lc)
+                                    : zero4;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int rb = (wm * TM + i) * 32;  // first tile row of this accumulator block (wave-uniform)
@@ -419,50 +452,44 @@ _Pragma("unroll")  \
             }
         }
         __syncthreads();
-        const bool interior = m0 + BM <= p.M;  // workgroup-uniform: interior tiles skip the per-row guards
+        if (pass == 0) { RELAX_STAMP(3); }
         if (slice >= 0) {
 #pragma unroll
             for (int it = 0; it < EP_ITERS; ++it) {
-                const int idx = it * NT + tid;
-                const int lr = idx / C4, lc = (idx % C4) * 4;
+                const int lr = it * EP_STEP + lr0;
                 *reinterpret_cast<f32x4*>(outp + (int64_t)(pass * EP_ROWS + lr) * ldo + lc) =
                     *reinterpret_cast<const f32x4*>(smem + lr * LDC + lc);
             }
         } else if (interior) {
-            f32x4 v[EP_ITERS], rv[EP_ITERS];
-#pragma unroll
-            for (int it = 0; it < EP_ITERS; ++it) {  // all residual loads in flight together
-                const int idx = it * NT + tid;
-                const int lr = idx / C4, lc = (idx % C4) * 4;
-                rv[it] = p.residual ? *reinterpret_cast<const f32x4*>(p.residual + (int64_t)(m0 + pass * EP_ROWS + lr) * p.N + n0 + lc)
-                                    : zero4;
-            }
+            f32x4 v[EP_ITERS];
 #pragma unroll
             for (int it = 0; it < EP_ITERS; ++it) {
-                const int idx = it * NT + tid;
-                const int lr = idx / C4, lc = (idx % C4) * 4;
-                v[it] = *reinterpret_cast<const f32x4*>(smem + lr * LDC + lc);
-                if (p.bias) v[it] += *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
+                v[it] = *reinterpret_cast<const f32x4*>(smem + (it * EP_STEP + lr0) * LDC + lc);
+                v[it] += bias4;
                 v[it] += rv[it];  // (acc + bias) + residual: the same order on every path, so bits do not depend on the tile
             }
+            if (p.act == 2) {
 #pragma unroll
-            for (int it = 0; it < EP_ITERS; ++it) {
-                const int idx = it * NT + tid;
-                const int lr = idx / C4, lc = (idx % C4) * 4;
-                f32x4 w = {apply_act(v[it].x, p.act), apply_act(v[it].y, p.act), apply_act(v[it].z, p.act),
-                           apply_act(v[it].w, p.act)};
-                *reinterpret_cast<f32x4*>(outp + (int64_t)(pass * EP_ROWS + lr) * ldo + lc) = w;
+                for (int it = 0; it < EP_ITERS; ++it) {
+                    f32x4 w = {apply_act(v[it].x, 2), apply_act(v[it].y, 2), apply_act(v[it].z, 2), apply_act(v[it].w, 2)};
+                    *reinterpret_cast<f32x4*>(outp + (int64_t)(pass * EP_ROWS + it * EP_STEP + lr0) * ldo + lc) = w;
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < EP_ITERS; ++it) {
+                    f32x4 w = {fmaxf(v[it].x, act_floor), fmaxf(v[it].y, act_floor), fmaxf(v[it].z, act_floor), fmaxf(v[it].w, act_floor)};
+                    *reinterpret_cast<f32x4*>(outp + (int64_t)(pass * EP_ROWS + it * EP_STEP + lr0) * ldo + lc) = w;
+                }
             }
         } else {
 #pragma unroll
             for (int it = 0; it < EP_ITERS; ++it) {
-                const int idx = it * NT + tid;
-                const int lr = idx / C4, lc = (idx % C4) * 4;
+                const int lr = it * EP_STEP + lr0;
                 const int trow = pass * EP_ROWS + lr;
                 if (m0 + trow < p.M) {
                     const int64_t o = (int64_t)trow * ldo + lc;
                     f32x4 v = *reinterpret_cast<const f32x4*>(smem + lr * LDC + lc);
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
+                    v += bias4;
                     if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)m0 * p.N + n0 + o);
                     f32x4 w = {apply_act(v.x, p.act), apply_act(v.y, p.act), apply_act(v.z, p.act), apply_act(v.w, p.act)};
                     *reinterpret_cast<f32x4*>(outp + o) = w;
@@ -470,6 +497,7 @@ _Pragma("unroll")  \
             }
         }
     }
+    RELAX_STAMP(7);
 }
 
 #undef RELAX_LOAD_TILE
@@ -555,7 +583,32 @@ static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hip
         attr_set = true;
     }
     const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
+#ifdef RELAX_GEMM_STAMPS
+    RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * 8 * (size_t)units));
+    p.stamps = static_cast<unsigned long long*>(h->scratch.p);
+#endif
     hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, BK, OCC, TAPS, PREC>), dim3(units), dim3(NT), lds, s, p);
+#ifdef RELAX_GEMM_STAMPS
+    {
+        RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
+        std::vector<unsigned long long> hs(8 * (size_t)units);
+        RELAX_HIP_CHECK(h, hipMemcpy(hs.data(), p.stamps, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
+        double d[6] = {0, 0, 0, 0, 0, 0};
+        for (int u = 0; u < p.full_tiles; ++u) {
+            const unsigned long long* t = &hs[8 * (size_t)u];
+            d[0] += (double)(t[1] - t[0]);   // prologue
+            d[1] += (double)(t[2] - t[1]);   // K loop
+            d[2] += (double)(t[3] - t[2]);   // accumulators of pass 0 -> LDS + barrier
+            d[3] += (double)(t[4] - t[3]);   // pass 0: LDS -> bias/residual/act -> global stores issued
+            d[4] += (double)(t[5] - t[4]);   // barrier before pass 1
+            d[5] += (double)(t[7] - t[5]);   // remaining passes
+        }
+        const double n = (p.full_tiles > 0 ? p.full_tiles : 1) * 100.0;
+        fprintf(stderr, "gemm %dx%dx%d tile %dx%d act %d res %d: per tile (us) prologue %.2f loop %.2f (%d steps) | epilogue: acc->LDS %.2f, "
+                "pass-0 out %.2f, barrier %.2f, other passes %.2f\n", p.M, p.N, p.Kpad, BM, BN, p.act, p.residual != nullptr,
+                d[0] / n, d[1] / n, p.Kpad / BK, d[2] / n, d[3] / n, d[4] / n, d[5] / n);
+    }
+#endif
     if (p.nsplit > 1)
         hipLaunchKernelGGL((splitk_finish<BM, BN>), dim3(BM * BN / 4 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
     RELAX_HIP_CHECK(h, hipGetLastError());
