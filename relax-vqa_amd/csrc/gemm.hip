@@ -352,6 +352,7 @@ _Pragma("unroll")  \
         RELAX_LOAD_TILE(kt_begin * BK);
         RELAX_STORE_TILE(0);
         __syncthreads();
+        RELAX_STAMP(1);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int cur = (kt - kt_begin) & 1;
             if (kt + 1 < kt_end && !(p.ablate & 2)) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
