@@ -212,9 +212,7 @@ def main():
                           "test_bf16x3_mode_meets_the_feature_tolerance"}
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = rdist.all_reduce_max(elapsed, "cuda")
 
     if rank == 0:
         clips_total = args.steps * world * B

@@ -18,11 +18,26 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            # RELAX_DIST_BACKEND=gloo: several ranks sharing ONE GPU (RCCL refuses duplicate devices) to rehearse the
+            # multi-rank control flow on a single-GPU box; collectives are then staged through host memory
+            backend = os.environ.get("RELAX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def _host_staged(t):
+    """gloo has no device collectives for every op: stage CUDA tensors through host memory under that backend."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce_max(value, device):
+    """max over ranks of a python float (the timing reduction of bench.py)."""
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def shard_clips(n_clips, rank, world):
@@ -41,8 +56,13 @@ def gather_clip_vectors(local, n_clips, rank, world, group=None):
     F = local.shape[1]
     padded = torch.zeros((per, F), dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
-    out = torch.empty((world * per, F), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
+    if _host_staged(padded):
+        out_h = torch.empty((world * per, F), dtype=local.dtype)
+        dist.all_gather_into_tensor(out_h, padded.cpu(), group=group)
+        out = out_h.to(local.device)
+    else:
+        out = torch.empty((world * per, F), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, padded, group=group)
     rows = []
     for r in range(world):
         n_r = len(shard_clips(n_clips, r, world))

@@ -73,3 +73,27 @@ def test_pinned_feeder_overlaps_and_preserves_data():
     for k, batch in enumerate(seen):
         for j, b in enumerate(batch):
             assert torch.equal(b.cpu(), clips[(k * 2 + j) % 3]), (k, j)
+
+
+def test_bench_two_ranks_sharing_the_gpu():
+    """The driver's N > 1 launch line on a 1-GPU box: two ranks under torch.distributed.run share the device (gloo, host-
+    staged collective, since RCCL refuses duplicate devices).  Checks the multi-rank control flow of bench.py end to end:
+    one JSON line from rank 0, n_gpus = world, every rank's clips in the gathered matrix."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RELAX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--workload", "config2", "--clips-per-step", "1"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert "roofline" in out and "cpu_baseline" not in out          # the CPU baseline is an N = 1 leg
