@@ -32,12 +32,15 @@ def main():
     ap.add_argument("--residual", action="store_true")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"])
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--group-m", type=int, default=0)
     ap.add_argument("--clips", type=int, default=1, help="scale M by this many clips")
     args = ap.parse_args()
     eng = RelaxEngine(0)
     eng.set_precision(args.precision)
     if args.variant >= 0:
         eng.set_option("gemm_variant", args.variant)
+    if args.group_m > 0:
+        eng.set_option("gemm_group_m", args.group_m)
     dev = torch.device("cuda")
     for name, (M, N, K) in GEMMS.items():
         if args.only and args.only not in name:
