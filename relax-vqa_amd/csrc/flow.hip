@@ -22,6 +22,7 @@ constexpr int POLY_N = 5;
 constexpr int WINSIZE = 15;
 constexpr int ITERS = 3;
 constexpr int MAX_GAUSS = 32;
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: 16-byte loads / stores of the 4-pixel kernels
 
 struct PolyConsts {
     float g[POLY_N + 1], xg[POLY_N + 1], xxg[POLY_N + 1];
@@ -41,30 +42,63 @@ __device__ inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > 
 
 // uint8 BGR frame pair -> float gray [P][2][H][W]; (B*1868 + G*9617 + R*4899 + 2^13) >> 14
 __global__ __launch_bounds__(256) void flow_gray(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ next,
-                                                 int64_t pair_stride, int HW, float* __restrict__ gray, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int pix = (int)(i % HW);
-    const int64_t img = i / HW;            // pair * 2 + which
-    const uint8_t* src = ((img & 1) ? next : orig) + (img >> 1) * pair_stride + (int64_t)pix * 3;
-    gray[i] = (float)(((int)src[0] * 1868 + (int)src[1] * 9617 + (int)src[2] * 4899 + (1 << 13)) >> 14);
+                                                 int64_t pair_stride, int HW, float* __restrict__ gray) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;      // grid (HW / 256, 1, P * 2): no 64-bit div / mod per pixel
+    if (pix >= HW) return;
+    const int img = blockIdx.z;                           // pair * 2 + which
+    const uint8_t* src = ((img & 1) ? next : orig) + (int64_t)(img >> 1) * pair_stride + (int64_t)pix * 3;
+    gray[(int64_t)img * HW + pix] = (float)(((int)src[0] * 1868 + (int)src[1] * 9617 + (int)src[2] * 4899 + (1 << 13)) >> 14);
+}
+
+// The taps arrive by value in the kernel argument; indexing that with a loop counter costs one dependent scalar load per tap,
+// so every block first copies them into LDS (and the common 3-tap blur of the two finest levels is unrolled from registers).
+__device__ inline void stage_taps(const GaussKernel& gk, float* sk) {
+    if (threadIdx.x < MAX_GAUSS) sk[threadIdx.x] = gk.k[threadIdx.x];
+    __syncthreads();
 }
 
 template <bool VERTICAL>
 __global__ __launch_bounds__(256) void gauss_pass(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
-                                                  GaussKernel gk, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int x = (int)(i % W);
-    const int y = (int)((i / W) % H);
-    const float* img = src + (i / ((int64_t)W * H)) * ((int64_t)W * H);
+                                                  GaussKernel gk) {
+    __shared__ float sk[MAX_GAUSS];
+    stage_taps(gk, sk);
+    const int x = blockIdx.x * 256 + threadIdx.x;         // grid (W / 256, H, images)
+    if (x >= W) return;
+    const int y = blockIdx.y;
+    const float* img = src + (int64_t)blockIdx.z * ((int64_t)W * H);
     const int r = gk.ksize / 2;
     float acc = 0.f;
     for (int t = 0; t < gk.ksize; ++t) {
         const float v = VERTICAL ? img[(int64_t)reflect101(y + t - r, H) * W + x] : img[(int64_t)y * W + reflect101(x + t - r, W)];
-        acc += gk.k[t] * v;
+        acc += sk[t] * v;
     }
-    dst[i] = acc;
+    dst[(int64_t)blockIdx.z * ((int64_t)W * H) + (int64_t)y * W + x] = acc;
+}
+
+// 3-tap blur (pyramid levels 0 and 1), both passes in one kernel, 4 pixels per thread: reads the 3 rows once with 16-byte
+// loads, same products and order as gauss_pass<false> then gauss_pass<true> (horizontal first, rounded to float, then vertical).
+__global__ __launch_bounds__(256) void gauss3_v4(const float* __restrict__ src, float* __restrict__ dst, int H, int W, float k0,
+                                                 float k1, float k2) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // grid (W / 1024, H, images)
+    if (x0 >= W) return;
+    const int y = blockIdx.y;
+    const float* img = src + (int64_t)blockIdx.z * ((int64_t)W * H);
+    f32x4 hrow[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const float* row = img + (int64_t)reflect101(y + t - 1, H) * W;
+        const f32x4 c = *reinterpret_cast<const f32x4*>(row + x0);
+        const float l = row[reflect101(x0 - 1, W)], rr = row[reflect101(x0 + 4, W)];
+        // acc = 0 + k0*v(-1); acc += k1*v(0); acc += k2*v(+1)
+        f32x4 a = (f32x4){l, c.x, c.y, c.z} * k0;
+        a += k1 * c;
+        a += k2 * (f32x4){c.y, c.z, c.w, rr};
+        hrow[t] = a;
+    }
+    f32x4 o = hrow[0] * k0;
+    o += k1 * hrow[1];
+    o += k2 * hrow[2];
+    *reinterpret_cast<f32x4*>(dst + (int64_t)blockIdx.z * ((int64_t)W * H) + (int64_t)y * W + x0) = o;
 }
 
 // Coarse pyramid levels (scale 1/4, 1/8): cv::resize only samples the blurred frame at 2 columns x 2 rows per output
@@ -83,12 +117,14 @@ __device__ inline void linear_tap(int d, double scale, int n_in, int* s0, int* s
 
 // horizontal blur at the two sample columns of every output column: src [B][H][W] -> tmp [B][H][w][2]
 __global__ __launch_bounds__(256) void gauss_h_sampled(const float* __restrict__ src, float* __restrict__ tmp, int H, int W,
-                                                       int w, double scale_x, GaussKernel gk, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H*w*2
-    if (i >= total) return;
-    const int j = (int)(i & 1);
-    const int dx = (int)((i >> 1) % w);
-    const int64_t row = (i >> 1) / w;                                    // b*H + y
+                                                       int w, double scale_x, GaussKernel gk) {
+    __shared__ float sk[MAX_GAUSS];
+    stage_taps(gk, sk);
+    const int e = blockIdx.x * 256 + threadIdx.x;        // grid (2w / 256, H, images): e = dx * 2 + j
+    if (e >= 2 * w) return;
+    const int j = e & 1;
+    const int dx = e >> 1;
+    const int64_t row = (int64_t)blockIdx.z * H + blockIdx.y;            // b*H + y
     int s0, s1;
     float f;
     linear_tap(dx, scale_x, W, &s0, &s1, &f);
@@ -96,19 +132,20 @@ __global__ __launch_bounds__(256) void gauss_h_sampled(const float* __restrict__
     const float* r_ = src + row * W;
     const int r = gk.ksize / 2;
     float acc = 0.f;
-    for (int t = 0; t < gk.ksize; ++t) acc += gk.k[t] * r_[reflect101(x + t - r, W)];
-    tmp[i] = acc;
+    for (int t = 0; t < gk.ksize; ++t) acc += sk[t] * r_[reflect101(x + t - r, W)];
+    tmp[row * (2 * w) + e] = acc;
 }
 
 // vertical blur at the two sample rows + the bilinear combine: tmp [B][H][w][2] -> dst [B][h][w]
 __global__ __launch_bounds__(256) void gauss_v_sampled_resize(const float* __restrict__ tmp, float* __restrict__ dst, int H,
                                                               int W, int h, int w, double scale_y, double scale_x,
-                                                              GaussKernel gk, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*h*w
-    if (i >= total) return;
-    const int dx = (int)(i % w);
-    const int dy = (int)((i / w) % h);
-    const int64_t b = i / ((int64_t)w * h);
+                                                              GaussKernel gk) {
+    __shared__ float sk[MAX_GAUSS];
+    stage_taps(gk, sk);
+    const int dx = blockIdx.x * 256 + threadIdx.x;       // grid (w / 256, h, images)
+    if (dx >= w) return;
+    const int dy = blockIdx.y;
+    const int64_t b = blockIdx.z;
     int sy0, sy1, sx0, sx1;
     float fy, fx;
     linear_tap(dy, scale_y, H, &sy0, &sy1, &fy);
@@ -117,7 +154,7 @@ __global__ __launch_bounds__(256) void gauss_v_sampled_resize(const float* __res
     const int r = gk.ksize / 2;
     float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;   // blurred (row sy0|sy1, col sx0|sx1)
     for (int t = 0; t < gk.ksize; ++t) {
-        const float k = gk.k[t];
+        const float k = sk[t];
         const float* p0 = img + (int64_t)reflect101(sy0 + t - r, H) * w * 2;
         const float* p1 = img + (int64_t)reflect101(sy1 + t - r, H) * w * 2;
         a00 += k * p0[0];
@@ -127,19 +164,19 @@ __global__ __launch_bounds__(256) void gauss_v_sampled_resize(const float* __res
     }
     const float r0 = a00 * (1.f - fx) + a01 * fx;
     const float r1 = a10 * (1.f - fx) + a11 * fx;
-    dst[i] = r0 * (1.f - fy) + r1 * fy;
+    dst[(b * h + dy) * w + dx] = r0 * (1.f - fy) + r1 * fy;
 }
 
 // cv::resize INTER_LINEAR on float [B][H][W][C] -> [B][h][w][C], result scaled by mul (flow upsampling: 1/pyr_scale)
+template <int C>
 __global__ __launch_bounds__(256) void resize_linear_f32(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
-                                                         int h, int w, int C, double scale_y, double scale_x, float mul,
-                                                         int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    const int dx = (int)((i / C) % w);
-    const int dy = (int)((i / ((int64_t)C * w)) % h);
-    const int64_t b = i / ((int64_t)C * w * h);
+                                                         int h, int w, double scale_y, double scale_x, float mul) {
+    const int e = blockIdx.x * 256 + threadIdx.x;        // grid (w * C / 256, h, images): e = dx * C + c
+    if (e >= w * C) return;
+    const int c = e % C;
+    const int dx = e / C;
+    const int dy = blockIdx.y;
+    const int64_t b = blockIdx.z;
     float fx = (float)((dx + 0.5) * scale_x - 0.5);
     int sx = (int)floorf(fx);
     fx -= (float)sx;
@@ -155,17 +192,16 @@ __global__ __launch_bounds__(256) void resize_linear_f32(const float* __restrict
     const float* im = src + b * ((int64_t)H * W * C);
     const float r0 = im[((int64_t)sy * W + sx) * C + c] * (1.f - fx) + im[((int64_t)sy * W + sx1) * C + c] * fx;
     const float r1 = im[((int64_t)sy1 * W + sx) * C + c] * (1.f - fx) + im[((int64_t)sy1 * W + sx1) * C + c] * fx;
-    dst[i] = (r0 * (1.f - fy) + r1 * fy) * mul;
+    dst[((b * h + dy) * w) * C + e] = (r0 * (1.f - fy) + r1 * fy) * mul;
 }
 
 // FarnebackPolyExp, vertical part: I [B][h][w] -> T [B][h][w][3]
 __global__ __launch_bounds__(256) void poly_vertical(const float* __restrict__ I, float* __restrict__ T, int h, int w,
-                                                     PolyConsts pc, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int x = (int)(i % w);
-    const int y = (int)((i / w) % h);
-    const float* img = I + (i / ((int64_t)w * h)) * ((int64_t)w * h);
+                                                     PolyConsts pc) {
+    const int x = blockIdx.x * 256 + threadIdx.x;        // grid (w / 256, h, images)
+    if (x >= w) return;
+    const int y = blockIdx.y;
+    const float* img = I + (int64_t)blockIdx.z * ((int64_t)w * h);
     float t0 = img[(int64_t)y * w + x] * pc.g[0], t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int k = 1; k <= POLY_N; ++k) {
@@ -176,18 +212,19 @@ __global__ __launch_bounds__(256) void poly_vertical(const float* __restrict__ I
         t1 += pc.xg[k] * (dn - up);
         t2 += pc.xxg[k] * p;
     }
-    T[i * 3] = t0;
-    T[i * 3 + 1] = t1;
-    T[i * 3 + 2] = t2;
+    float* o = T + (((int64_t)blockIdx.z * h + y) * w + x) * 3;
+    o[0] = t0;
+    o[1] = t1;
+    o[2] = t2;
 }
 
 // horizontal part (replicated border), double accumulators as in OpenCV: T -> R [B][h][w][5]
 __global__ __launch_bounds__(256) void poly_horizontal(const float* __restrict__ T, float* __restrict__ R, int h, int w,
-                                                       PolyConsts pc, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int x = (int)(i % w);
-    const float* row = T + (i - x) * 3;
+                                                       PolyConsts pc) {
+    const int x = blockIdx.x * 256 + threadIdx.x;        // grid (w / 256, h, images)
+    if (x >= w) return;
+    const int64_t rowpx = ((int64_t)blockIdx.z * h + blockIdx.y) * w;
+    const float* row = T + rowpx * 3;
     double b1 = row[x * 3] * pc.g[0], b2 = 0, b3 = row[x * 3 + 1] * pc.g[0], b4 = 0, b5 = row[x * 3 + 2] * pc.g[0], b6 = 0;
 #pragma unroll
     for (int k = 1; k <= POLY_N; ++k) {
@@ -201,7 +238,7 @@ __global__ __launch_bounds__(256) void poly_horizontal(const float* __restrict__
         b6 += (p[1] - m[1]) * pc.xg[k];
         b5 += (p[2] + m[2]) * pc.g[k];
     }
-    float* o = R + i * 5;
+    float* o = R + (rowpx + x) * 5;
     o[1] = (float)(b2 * pc.ig11);
     o[0] = (float)(b3 * pc.ig11);
     o[3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
@@ -209,15 +246,88 @@ __global__ __launch_bounds__(256) void poly_horizontal(const float* __restrict__
     o[4] = (float)(b6 * pc.ig55);
 }
 
+// 4 adjacent pixels per thread, 16-byte loads and stores; per pixel the arithmetic and its order are those of the scalar
+// kernels above (bit-identical), only the memory instructions change (rows a multiple of 4 long, see vec4_ok).
+__global__ __launch_bounds__(256) void poly_vertical_v4(const float* __restrict__ I, float* __restrict__ T, int h, int w,
+                                                        PolyConsts pc) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // grid (w / 1024, h, images)
+    if (x0 >= w) return;
+    const int y = blockIdx.y;
+    const float* img = I + (int64_t)blockIdx.z * ((int64_t)w * h) + x0;
+    const f32x4 c = *reinterpret_cast<const f32x4*>(img + (int64_t)y * w);
+    f32x4 t0 = c * pc.g[0], t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 1; k <= POLY_N; ++k) {
+        const f32x4 up = *reinterpret_cast<const f32x4*>(img + (int64_t)(y - k < 0 ? 0 : y - k) * w);
+        const f32x4 dn = *reinterpret_cast<const f32x4*>(img + (int64_t)(y + k > h - 1 ? h - 1 : y + k) * w);
+        const f32x4 p = up + dn;
+        t0 += pc.g[k] * p;
+        t1 += pc.xg[k] * (dn - up);
+        t2 += pc.xxg[k] * p;
+    }
+    float* o = T + (((int64_t)blockIdx.z * h + y) * w + x0) * 3;
+    *reinterpret_cast<f32x4*>(o) = (f32x4){t0.x, t1.x, t2.x, t0.y};
+    *reinterpret_cast<f32x4*>(o + 4) = (f32x4){t1.y, t2.y, t0.z, t1.z};
+    *reinterpret_cast<f32x4*>(o + 8) = (f32x4){t2.z, t0.w, t1.w, t2.w};
+}
+
+__global__ __launch_bounds__(256) void poly_horizontal_v4(const float* __restrict__ T, float* __restrict__ R, int h, int w,
+                                                          PolyConsts pc) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // grid (w / 1024, h, images)
+    if (x0 >= w) return;
+    const int64_t rowpx = ((int64_t)blockIdx.z * h + blockIdx.y) * w;
+    const float* row = T + rowpx * 3;
+    float v[60];   // pixels x0 - 8 .. x0 + 11, 3 floats each
+    if (x0 >= 8 && x0 + 12 <= w) {
+#pragma unroll
+        for (int q = 0; q < 15; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(row + (x0 - 8) * 3 + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 20; ++j) {
+            const float* px = row + clampi(x0 - 8 + j, 0, w - 1) * 3;
+            v[3 * j] = px[0]; v[3 * j + 1] = px[1]; v[3 * j + 2] = px[2];
+        }
+    }
+    float o[20];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float* cpx = v + (8 + e) * 3;
+        double b1 = cpx[0] * pc.g[0], b2 = 0, b3 = cpx[1] * pc.g[0], b4 = 0, b5 = cpx[2] * pc.g[0], b6 = 0;
+#pragma unroll
+        for (int k = 1; k <= POLY_N; ++k) {
+            const float* pp = cpx + 3 * k;     // clamped fetches above reproduce the replicated border
+            const float* mm = cpx - 3 * k;
+            const double tg = pp[0] + mm[0];
+            b1 += tg * pc.g[k];
+            b4 += tg * pc.xxg[k];
+            b2 += (pp[0] - mm[0]) * pc.xg[k];
+            b3 += (pp[1] + mm[1]) * pc.g[k];
+            b6 += (pp[1] - mm[1]) * pc.xg[k];
+            b5 += (pp[2] + mm[2]) * pc.g[k];
+        }
+        o[5 * e + 1] = (float)(b2 * pc.ig11);
+        o[5 * e] = (float)(b3 * pc.ig11);
+        o[5 * e + 3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+        o[5 * e + 2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+        o[5 * e + 4] = (float)(b6 * pc.ig55);
+    }
+    float* dst = R + (rowpx + x0) * 5;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = (f32x4){o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+}
+
 // FarnebackUpdateMatrices: R [P][2][h][w][5], flow [P][h][w][2] -> M [P][h][w][5]
 __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict__ R, const float* __restrict__ flow,
-                                                         float* __restrict__ M, int h, int w, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int x = (int)(i % w);
-    const int y = (int)((i / w) % h);
-    const int64_t pair = i / ((int64_t)w * h);
+                                                         float* __restrict__ M, int h, int w) {
+    const int x = blockIdx.x * 256 + threadIdx.x;        // grid (w / 256, h, pairs)
+    if (x >= w) return;
+    const int y = blockIdx.y;
+    const int64_t pair = blockIdx.z;
     const int64_t hw = (int64_t)w * h;
+    const int64_t i = pair * hw + (int64_t)y * w + x;
     const float* R0 = R + (pair * 2) * hw * 5 + ((int64_t)y * w + x) * 5;
     const float* R1 = R + (pair * 2 + 1) * hw * 5;
     const float dx = flow[i * 2], dy = flow[i * 2 + 1];
@@ -267,12 +377,11 @@ __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict
 // column with a running double sum (2 loads per output instead of 15); lanes are adjacent columns (coalesced).
 constexpr int BOX_SEG = 64;
 __global__ __launch_bounds__(256) void box_vertical(const float* __restrict__ M, float* __restrict__ VS, int h, int w,
-                                                    int nseg, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over planes * nseg * w
-    if (i >= total) return;
-    const int x = (int)(i % w);
-    const int seg = (int)((i / w) % nseg);
-    const int64_t plane = i / ((int64_t)w * nseg);
+                                                    int nseg) {
+    const int x = blockIdx.x * 256 + threadIdx.x;        // grid (w / 256, nseg, planes)
+    if (x >= w) return;
+    const int seg = blockIdx.y;
+    const int64_t plane = blockIdx.z;
     const float* img = M + plane * ((int64_t)h * w) + x;
     float* out = VS + plane * ((int64_t)h * w) + x;
     const int y0 = seg * BOX_SEG;
@@ -290,13 +399,13 @@ __global__ __launch_bounds__(256) void box_vertical(const float* __restrict__ M,
 
 // 15-column box sum + the 2x2 solve: planar VS -> flow [P][h][w][2]
 __global__ __launch_bounds__(256) void box_horizontal_solve(const float* __restrict__ VS, float* __restrict__ flow, int h,
-                                                            int w, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over P*h*w
-    if (i >= total) return;
-    const int x = (int)(i % w);
+                                                            int w) {
+    const int x = blockIdx.x * 256 + threadIdx.x;        // grid (w / 256, h, pairs)
+    if (x >= w) return;
     const int64_t hw = (int64_t)h * w;
-    const int64_t pair = i / hw;
-    const float* row = VS + pair * 5 * hw + (i - pair * hw - x);
+    const int64_t pair = blockIdx.z;
+    const int64_t i = pair * hw + (int64_t)blockIdx.y * w + x;
+    const float* row = VS + pair * 5 * hw + (int64_t)blockIdx.y * w;
     double acc[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = -WINSIZE / 2; j <= WINSIZE / 2; ++j) {
@@ -309,6 +418,56 @@ __global__ __launch_bounds__(256) void box_horizontal_solve(const float* __restr
     const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
     flow[i * 2] = (float)((g11 * h2 - g12 * h1) * idet);
     flow[i * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+}
+
+// Same result as box_horizontal_solve for rows whose length is a multiple of 4: one thread owns 4 adjacent pixels, fetches the
+// 20 values x0-8 .. x0+11 of each plane with five 16-byte loads (75 dword loads per pixel before) and slides the 15-wide
+// window in double (sums of at most 15 floats are exact in double, so the order does not change them).
+__global__ __launch_bounds__(256) void box_horizontal_solve_v4(const float* __restrict__ VS, float* __restrict__ flow, int h,
+                                                               int w) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // grid (w / 1024, h, pairs)
+    if (x0 >= w) return;
+    const int64_t hw = (int64_t)h * w;
+    const int64_t pair = blockIdx.z;
+    const float* row = VS + pair * 5 * hw + (int64_t)blockIdx.y * w;
+    constexpr int m = WINSIZE / 2;
+    double acc[5][4];
+    const bool interior = x0 >= 8 && x0 + 12 <= w;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        float v[20];   // v[j] = plane c at x0 - 8 + j
+        if (interior) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(row + c * hw + x0 - 8 + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 20; ++j) v[j] = row[c * hw + clampi(x0 - 8 + j, 0, w - 1)];
+        }
+        double s0 = 0;
+#pragma unroll
+        for (int j = 8 - m; j <= 8 + m; ++j) s0 += v[j];
+        acc[c][0] = s0;
+#pragma unroll
+        for (int e = 1; e < 4; ++e) {
+            s0 += (double)v[8 + m + e] - (double)v[8 - m - 1 + e];
+            acc[c][e] = s0;
+        }
+    }
+    const double sc = 1.0 / (WINSIZE * WINSIZE);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double g11 = acc[0][e] * sc, g12 = acc[1][e] * sc, g22 = acc[2][e] * sc, h1 = acc[3][e] * sc, h2 = acc[4][e] * sc;
+        const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
+        o[2 * e] = (float)((g11 * h2 - g12 * h1) * idet);
+        o[2 * e + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+    }
+    float* dst = flow + (pair * hw + (int64_t)blockIdx.y * w + x0) * 2;
+    *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
 }
 
 // ---- flow_to_rgb ------------------------------------------------------------------------------------------------
@@ -367,10 +526,11 @@ __device__ inline void minmax_affine(double smin, double smax, float* scale, flo
 }
 
 __global__ __launch_bounds__(256) void flow_visualise(const float* __restrict__ flow, const unsigned* __restrict__ mm, int P, int HW,
-                                                      uint8_t* __restrict__ bgr, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int pair = (int)(i / HW);
+                                                      uint8_t* __restrict__ bgr) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;      // grid (HW / 256, 1, pairs)
+    if (pix >= HW) return;
+    const int pair = blockIdx.z;
+    const int64_t i = (int64_t)pair * HW + pix;
     const float x = flow[i * 2], y = flow[i * 2 + 1];
     float mag = sqrtf(x * x + y * y);
     const float ang = fast_atan2_deg(y, x) * (float)(M_PI / 180);
@@ -458,13 +618,16 @@ static void make_gauss(int ksize, double sigma, GaussKernel* gk) {
 }
 
 static inline unsigned nblocks(int64_t total) { return (unsigned)((total + 255) / 256); }
+// the 4-pixel kernels use 16-byte loads / stores: row length a multiple of 4 and 16-byte aligned planes
+static inline bool vec4_ok(int w, int64_t plane_elems, const void* a, const void* b) {
+    return w % 4 == 0 && plane_elems % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+}
 
 static int visualise(relax_handle* h, const float* flow, int P, int HW, uint8_t* bgr, unsigned* mm, hipStream_t s) {
     RELAX_HIP_CHECK(h, hipMemsetAsync(mm, 0xff, sizeof(unsigned) * P, s));       // running minima
     RELAX_HIP_CHECK(h, hipMemsetAsync(mm + P, 0, sizeof(unsigned) * P, s));       // running maxima
-    hipLaunchKernelGGL(mag_minmax, dim3(64, P), dim3(256), 0, s, flow, HW, mm);
-    const int64_t tot = (int64_t)P * HW;
-    hipLaunchKernelGGL(flow_visualise, dim3(nblocks(tot)), dim3(256), 0, s, flow, mm, P, HW, bgr, tot);
+    hipLaunchKernelGGL(mag_minmax, dim3(HW / 4096 > 64 ? (HW / 4096 < 1024 ? HW / 4096 : 1024) : 64, P), dim3(256), 0, s, flow, HW, mm);
+    hipLaunchKernelGGL(flow_visualise, dim3(nblocks(HW), 1, P), dim3(256), 0, s, flow, mm, P, HW, bgr);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }
@@ -489,8 +652,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
 
     PolyConsts pc;
     prepare_poly(&pc);
-    const int64_t tot_px2 = (int64_t)P * 2 * HW;
-    hipLaunchKernelGGL(flow_gray, dim3(nblocks(tot_px2)), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray, tot_px2);
+    hipLaunchKernelGGL(flow_gray, dim3(nblocks(HW), 1, P * 2), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray);
 
     int levels = 0;
     {
@@ -515,41 +677,50 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
         if (!prev_flow) {
             RELAX_HIP_CHECK(h, hipMemsetAsync(cur, 0, sizeof(float) * P * 2 * hw, s));
         } else {
-            const int64_t tot = (int64_t)P * hw * 2;
-            hipLaunchKernelGGL(resize_linear_f32, dim3(nblocks(tot)), dim3(256), 0, s, prev_flow, cur, ph, pw, hh, w, 2,
-                               (double)ph / hh, (double)pw / w, 2.0f, tot);
+            hipLaunchKernelGGL(resize_linear_f32<2>, dim3(nblocks(w * 2), hh, P), dim3(256), 0, s, prev_flow, cur, ph, pw, hh, w,
+                               (double)ph / hh, (double)pw / w, 2.0f);
         }
         GaussKernel gk;
         make_gauss(smooth, sigma, &gk);
         const float* Isrc;
-        const int64_t tot_l2 = (int64_t)P * 2 * hw;
+        const dim3 g_full(nblocks(W), H, P * 2), g_lvl2(nblocks(w), hh, P * 2), g_lvl(nblocks(w), hh, P);
         if (k >= 2) {   // coarse levels: blur only where the resize samples
-            const int64_t tot_h = (int64_t)P * 2 * H * w * 2;
-            hipLaunchKernelGGL(gauss_h_sampled, dim3(nblocks(tot_h)), dim3(256), 0, s, gray, tmp, H, W, w, (double)W / w, gk, tot_h);
-            hipLaunchKernelGGL(gauss_v_sampled_resize, dim3(nblocks(tot_l2)), dim3(256), 0, s, tmp, I, H, W, hh, w,
-                               (double)H / hh, (double)W / w, gk, tot_l2);
+            hipLaunchKernelGGL(gauss_h_sampled, dim3(nblocks(2 * w), H, P * 2), dim3(256), 0, s, gray, tmp, H, W, w, (double)W / w, gk);
+            hipLaunchKernelGGL(gauss_v_sampled_resize, g_lvl2, dim3(256), 0, s, tmp, I, H, W, hh, w, (double)H / hh,
+                               (double)W / w, gk);
             Isrc = I;
         } else {
-            hipLaunchKernelGGL(gauss_pass<false>, dim3(nblocks(tot_px2)), dim3(256), 0, s, gray, tmp, H, W, gk, tot_px2);
-            hipLaunchKernelGGL(gauss_pass<true>, dim3(nblocks(tot_px2)), dim3(256), 0, s, tmp, blur, H, W, gk, tot_px2);
+            if (gk.ksize == 3 && vec4_ok(W, HW, gray, blur)) {
+                hipLaunchKernelGGL(gauss3_v4, dim3(nblocks((W + 3) / 4), H, P * 2), dim3(256), 0, s, gray, blur, H, W, gk.k[0], gk.k[1],
+                                   gk.k[2]);
+            } else {
+                hipLaunchKernelGGL(gauss_pass<false>, g_full, dim3(256), 0, s, gray, tmp, H, W, gk);
+                hipLaunchKernelGGL(gauss_pass<true>, g_full, dim3(256), 0, s, tmp, blur, H, W, gk);
+            }
             Isrc = blur;
             if (w != W || hh != H) {
-                hipLaunchKernelGGL(resize_linear_f32, dim3(nblocks(tot_l2)), dim3(256), 0, s, blur, I, H, W, hh, w, 1,
-                                   (double)H / hh, (double)W / w, 1.0f, tot_l2);
+                hipLaunchKernelGGL(resize_linear_f32<1>, g_lvl2, dim3(256), 0, s, blur, I, H, W, hh, w, (double)H / hh,
+                                   (double)W / w, 1.0f);
                 Isrc = I;
             }
         }
-        hipLaunchKernelGGL(poly_vertical, dim3(nblocks(tot_l2)), dim3(256), 0, s, Isrc, T, hh, w, pc, tot_l2);
-        hipLaunchKernelGGL(poly_horizontal, dim3(nblocks(tot_l2)), dim3(256), 0, s, T, R, hh, w, pc, tot_l2);
-        const int64_t tot_l = (int64_t)P * hw;
+        if (vec4_ok(w, hw, Isrc, T) && vec4_ok(w, hw, R, T)) {
+            const dim3 g4(nblocks((w + 3) / 4), hh, P * 2);
+            hipLaunchKernelGGL(poly_vertical_v4, g4, dim3(256), 0, s, Isrc, T, hh, w, pc);
+            hipLaunchKernelGGL(poly_horizontal_v4, g4, dim3(256), 0, s, T, R, hh, w, pc);
+        } else {
+            hipLaunchKernelGGL(poly_vertical, g_lvl2, dim3(256), 0, s, Isrc, T, hh, w, pc);
+            hipLaunchKernelGGL(poly_horizontal, g_lvl2, dim3(256), 0, s, T, R, hh, w, pc);
+        }
         const int nseg = (hh + BOX_SEG - 1) / BOX_SEG;
-        hipLaunchKernelGGL(update_matrices_k, dim3(nblocks(tot_l)), dim3(256), 0, s, R, cur, M, hh, w, tot_l);
+        hipLaunchKernelGGL(update_matrices_k, g_lvl, dim3(256), 0, s, R, cur, M, hh, w);
         for (int it = 0; it < ITERS; ++it) {
-            hipLaunchKernelGGL(box_vertical, dim3(nblocks((int64_t)P * 5 * nseg * w)), dim3(256), 0, s, M, VS, hh, w, nseg,
-                               (int64_t)P * 5 * nseg * w);
-            hipLaunchKernelGGL(box_horizontal_solve, dim3(nblocks(tot_l)), dim3(256), 0, s, VS, cur, hh, w, tot_l);
-            if (it < ITERS - 1)
-                hipLaunchKernelGGL(update_matrices_k, dim3(nblocks(tot_l)), dim3(256), 0, s, R, cur, M, hh, w, tot_l);
+            hipLaunchKernelGGL(box_vertical, dim3(nblocks(w), nseg, P * 5), dim3(256), 0, s, M, VS, hh, w, nseg);
+            if (vec4_ok(w, hw, VS, cur))
+                hipLaunchKernelGGL(box_horizontal_solve_v4, dim3(nblocks((w + 3) / 4), hh, P), dim3(256), 0, s, VS, cur, hh, w);
+            else
+                hipLaunchKernelGGL(box_horizontal_solve, g_lvl, dim3(256), 0, s, VS, cur, hh, w);
+            if (it < ITERS - 1) hipLaunchKernelGGL(update_matrices_k, g_lvl, dim3(256), 0, s, R, cur, M, hh, w);
         }
         prev_flow = cur;
         ph = hh;
