@@ -319,18 +319,10 @@ __global__ __launch_bounds__(256) void poly_horizontal_v4(const float* __restric
     for (int q = 0; q < 5; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = (f32x4){o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
 }
 
-// FarnebackUpdateMatrices: R [P][2][h][w][5], flow [P][h][w][2] -> M [P][h][w][5]
-__global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict__ R, const float* __restrict__ flow,
-                                                         float* __restrict__ M, int h, int w) {
-    const int x = blockIdx.x * 256 + threadIdx.x;        // grid (w / 256, h, pairs)
-    if (x >= w) return;
-    const int y = blockIdx.y;
-    const int64_t pair = blockIdx.z;
-    const int64_t hw = (int64_t)w * h;
-    const int64_t i = pair * hw + (int64_t)y * w + x;
-    const float* R0 = R + (pair * 2) * hw * 5 + ((int64_t)y * w + x) * 5;
-    const float* R1 = R + (pair * 2 + 1) * hw * 5;
-    const float dx = flow[i * 2], dy = flow[i * 2 + 1];
+// FarnebackUpdateMatrices for one pixel: R0 = its 5 expansion coefficients in frame 0, R1 = frame 1's coefficient image,
+// (dx, dy) = current flow.  out = the 5 entries of the pixel's G matrix / h vector.
+__device__ inline void matrix_entries(const float* __restrict__ R0, const float* __restrict__ R1, int x, int y, float dx, float dy,
+                                      int h, int w, float out[5]) {
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     fx -= x1;
@@ -365,109 +357,118 @@ __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict
                          (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
         r2 *= sc; r3 *= sc; r4 *= sc; r5 *= sc; r6 *= sc;
     }
-    float* o = M + pair * 5 * hw + ((int64_t)y * w + x);   // planar [P][5][h][w]: the box filters stream it coalesced
-    o[0] = r4 * r4 + r6 * r6;
-    o[hw] = (r4 + r5) * r6;
-    o[2 * hw] = r5 * r5 + r6 * r6;
-    o[3 * hw] = r4 * r2 + r6 * r3;
-    o[4 * hw] = r6 * r2 + r5 * r3;
+    out[0] = r4 * r4 + r6 * r6;
+    out[1] = (r4 + r5) * r6;
+    out[2] = r5 * r5 + r6 * r6;
+    out[3] = r4 * r2 + r6 * r3;
+    out[4] = r6 * r2 + r5 * r3;
 }
 
-// 15-row box sum (replicated border): planar M [P*5][h][w] -> VS [P*5][h][w].  One thread walks a 64-row segment of one
-// column with a running double sum (2 loads per output instead of 15); lanes are adjacent columns (coalesced).
-constexpr int BOX_SEG = 64;
-__global__ __launch_bounds__(256) void box_vertical(const float* __restrict__ M, float* __restrict__ VS, int h, int w,
-                                                    int nseg) {
-    const int x = blockIdx.x * 256 + threadIdx.x;        // grid (w / 256, nseg, planes)
-    if (x >= w) return;
-    const int seg = blockIdx.y;
-    const int64_t plane = blockIdx.z;
-    const float* img = M + plane * ((int64_t)h * w) + x;
-    float* out = VS + plane * ((int64_t)h * w) + x;
-    const int y0 = seg * BOX_SEG;
-    const int y1 = y0 + BOX_SEG < h ? y0 + BOX_SEG : h;
-    constexpr int m = WINSIZE / 2;
-    double s = 0;
-#pragma unroll
-    for (int j = -m; j <= m; ++j) s += img[(int64_t)clampi(y0 + j, 0, h - 1) * w];
-    out[(int64_t)y0 * w] = (float)s;
-    for (int y = y0 + 1; y < y1; ++y) {
-        s += (double)img[(int64_t)clampi(y + m, 0, h - 1) * w] - (double)img[(int64_t)clampi(y - m - 1, 0, h - 1) * w];
-        out[(int64_t)y * w] = (float)s;
-    }
-}
-
-// 15-column box sum + the 2x2 solve: planar VS -> flow [P][h][w][2]
-__global__ __launch_bounds__(256) void box_horizontal_solve(const float* __restrict__ VS, float* __restrict__ flow, int h,
-                                                            int w) {
+// R [P][2][h][w][5], flow [P][h][w][2] -> M [P][5][h][w] (planar: the box filters stream it coalesced)
+__global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict__ R, const float* __restrict__ flow,
+                                                         float* __restrict__ M, int h, int w) {
     const int x = blockIdx.x * 256 + threadIdx.x;        // grid (w / 256, h, pairs)
     if (x >= w) return;
-    const int64_t hw = (int64_t)h * w;
+    const int y = blockIdx.y;
     const int64_t pair = blockIdx.z;
-    const int64_t i = pair * hw + (int64_t)blockIdx.y * w + x;
-    const float* row = VS + pair * 5 * hw + (int64_t)blockIdx.y * w;
-    double acc[5] = {0, 0, 0, 0, 0};
+    const int64_t hw = (int64_t)w * h;
+    const int64_t i = pair * hw + (int64_t)y * w + x;
+    float e[5];
+    matrix_entries(R + (pair * 2) * hw * 5 + ((int64_t)y * w + x) * 5, R + (pair * 2 + 1) * hw * 5, x, y, flow[i * 2], flow[i * 2 + 1],
+                   h, w, e);
+    float* o = M + pair * 5 * hw + ((int64_t)y * w + x);
 #pragma unroll
-    for (int j = -WINSIZE / 2; j <= WINSIZE / 2; ++j) {
-        const int xx = clampi(x + j, 0, w - 1);
-#pragma unroll
-        for (int c = 0; c < 5; ++c) acc[c] += row[c * hw + xx];
-    }
-    const double sc = 1.0 / (WINSIZE * WINSIZE);
-    const double g11 = acc[0] * sc, g12 = acc[1] * sc, g22 = acc[2] * sc, h1 = acc[3] * sc, h2 = acc[4] * sc;
-    const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
-    flow[i * 2] = (float)((g11 * h2 - g12 * h1) * idet);
-    flow[i * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+    for (int c = 0; c < 5; ++c) o[c * hw] = e[c];
 }
 
-// Same result as box_horizontal_solve for rows whose length is a multiple of 4: one thread owns 4 adjacent pixels, fetches the
-// 20 values x0-8 .. x0+11 of each plane with five 16-byte loads (75 dword loads per pixel before) and slides the 15-wide
-// window in double (sums of at most 15 floats are exact in double, so the order does not change them).
-__global__ __launch_bounds__(256) void box_horizontal_solve_v4(const float* __restrict__ VS, float* __restrict__ flow, int h,
-                                                               int w) {
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // grid (w / 1024, h, pairs)
-    if (x0 >= w) return;
+// The 15x15 box blur and the 2x2 solve of one Farneback iteration in ONE pass over M (no intermediate plane of row sums).
+// A block owns a band of 242 output columns (256 threads = 242 + the 7-column halo on each side) and a segment
+// of rows, and walks down the rows:
+//   * every thread owns ONE column: the last 15 rows of the 5 planes live in a register ring (static indices: the row loop is
+//     unrolled over the ring period), so each M element is loaded once per segment and the running sums (double, as in
+//     the reference) cost one add and one subtract per row; the next row's 5 loads are issued before the current row is used;
+//   * the column sums go through LDS in double (OpenCV's FarnebackUpdateFlow_Blur and the oracle keep them in double too), one
+//     barrier per row (two buffers), then the 15-column window (double) and the solve.
+// HBM traffic per pixel: ~24 bytes of M + 8 of flow instead of 68 with a separate vertical pass that stores its row sums (the
+// first version of this file, which also rounded them to float on the way).
+// (Appending FarnebackUpdateMatrices to the row loop was measured too: its dependent gather between two barriers makes the
+// fused kernel slower than this kernel followed by update_matrices_k, 1034 vs 892 us per iteration at 2160p x 4 pairs.)
+constexpr int FUSE_OUT = 256 - 2 * (WINSIZE / 2);   // 242 output columns per block
+__global__ __launch_bounds__(256) void box_solve_fused(const float* __restrict__ M, float* __restrict__ flow, int h, int w,
+                                                       int seg) {
+    __shared__ double lds[2][5][256];
+    constexpr int m = WINSIZE / 2;
+    const int tid = threadIdx.x;
+    const int x = blockIdx.x * FUSE_OUT - m + tid;            // this thread's column (halo threads: clamped = replicated border)
+    const int xc = clampi(x, 0, w - 1);
+    const int y0 = blockIdx.y * seg;
+    const int y1 = y0 + seg < h ? y0 + seg : h;
     const int64_t hw = (int64_t)h * w;
     const int64_t pair = blockIdx.z;
-    const float* row = VS + pair * 5 * hw + (int64_t)blockIdx.y * w;
-    constexpr int m = WINSIZE / 2;
-    double acc[5][4];
-    const bool interior = x0 >= 8 && x0 + 12 <= w;
+    const float* col = M + pair * 5 * hw + xc;
+    const bool writer = tid >= m && tid < 256 - m && x < w;
+
+    float ring[5][WINSIZE];   // the 15 rows of the window; slot of row r = (r - y0 + 7) % 15
+    double s[5];
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
-        float v[20];   // v[j] = plane c at x0 - 8 + j
-        if (interior) {
+        s[c] = 0;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(row + c * hw + x0 - 8 + 4 * q);
-                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        for (int k = 0; k < WINSIZE; ++k) {                   // rows y0-7 .. y0+7 in order
+            ring[c][k] = col[c * hw + (int64_t)clampi(y0 - m + k, 0, h - 1) * w];
+            s[c] += ring[c][k];
+        }
+    }
+    float nxt[5];                                             // row y0+8: enters the window at y0+1
+#pragma unroll
+    for (int c = 0; c < 5; ++c) nxt[c] = col[c * hw + (int64_t)clampi(y0 + m + 1, 0, h - 1) * w];
+
+    for (int yb = y0; yb < y1; yb += WINSIZE) {
+#pragma unroll
+        for (int k = 0; k < WINSIZE; ++k) {                   // ring slot k holds row y - 8 when row y = yb + k is processed (k >= 1)
+            const int y = yb + k;
+            if (y < y1) {                                     // uniform over the block
+                if (y > y0) {
+                    float cur[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) cur[c] = nxt[c];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c)               // prefetch the row that enters at y + 1
+                        nxt[c] = col[c * hw + (int64_t)clampi(y + m + 1, 0, h - 1) * w];
+                    // slot of row r = (r - y0 + 7) % 15: the row that leaves (y - 8) and the row that enters (y + 7) share slot
+                    // (y - y0 - 1) % 15 = (k - 1) mod 15, static because yb - y0 is a multiple of the ring period
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const int slot = (k + WINSIZE - 1) % WINSIZE;
+                        s[c] += (double)cur[c] - (double)ring[c][slot];
+                        ring[c][slot] = cur[c];
+                    }
+                }
+                const int bsel = ((yb - y0) / WINSIZE + k) & 1;   // alternate buffers row by row across ring periods too
+#pragma unroll
+                for (int c = 0; c < 5; ++c) lds[bsel][c][tid] = s[c];
+                __syncthreads();   // one barrier per row: the other buffer is rewritten only after every reader passed this point
+                if (writer) {
+                    double acc[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        double a = 0;
+#pragma unroll
+                        for (int j = -m; j <= m; ++j) a += lds[bsel][c][tid + j];
+                        acc[c] = a;
+                    }
+                    const double sc = 1.0 / (WINSIZE * WINSIZE);
+                    const double g11 = acc[0] * sc, g12 = acc[1] * sc, g22 = acc[2] * sc, h1 = acc[3] * sc, h2 = acc[4] * sc;
+                    const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
+                    const float fdx = (float)((g11 * h2 - g12 * h1) * idet);
+                    const float fdy = (float)((g22 * h1 - g12 * h2) * idet);
+                    const int64_t px = (int64_t)y * w + x;
+                    flow[(pair * hw + px) * 2] = fdx;
+                    flow[(pair * hw + px) * 2 + 1] = fdy;
+                }
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 20; ++j) v[j] = row[c * hw + clampi(x0 - 8 + j, 0, w - 1)];
-        }
-        double s0 = 0;
-#pragma unroll
-        for (int j = 8 - m; j <= 8 + m; ++j) s0 += v[j];
-        acc[c][0] = s0;
-#pragma unroll
-        for (int e = 1; e < 4; ++e) {
-            s0 += (double)v[8 + m + e] - (double)v[8 - m - 1 + e];
-            acc[c][e] = s0;
         }
     }
-    const double sc = 1.0 / (WINSIZE * WINSIZE);
-    float o[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const double g11 = acc[0][e] * sc, g12 = acc[1][e] * sc, g22 = acc[2][e] * sc, h1 = acc[3][e] * sc, h2 = acc[4][e] * sc;
-        const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
-        o[2 * e] = (float)((g11 * h2 - g12 * h1) * idet);
-        o[2 * e + 1] = (float)((g22 * h1 - g12 * h2) * idet);
-    }
-    float* dst = flow + (pair * hw + (int64_t)blockIdx.y * w + x0) * 2;
-    *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
-    *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
 }
 
 // ---- flow_to_rgb ------------------------------------------------------------------------------------------------
@@ -636,7 +637,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
                       float* flow_out, uint8_t* bgr_out, hipStream_t s) {
     const int64_t HW = (int64_t)H * W;
     // workspace carve (floats unless noted), all sized for level 0
-    const size_t per_pair = (size_t)HW * (2 + 2 + 2 + 2 + 6 + 10 + 5 + 5 + 2 + 2) * sizeof(float) + 16;
+    const size_t per_pair = (size_t)HW * (2 + 2 + 2 + 2 + 6 + 10 + 5 + 2 + 2) * sizeof(float) + 16;
     RELAX_TRY(ensure_buf(h, h->flow_ws, per_pair * P));
     float* gray = static_cast<float*>(h->flow_ws.p);
     float* tmp = gray + (size_t)P * 2 * HW;
@@ -647,8 +648,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
     float* M = R + (size_t)P * 10 * HW;        // [P][h][w][5]
     float* flowA = M + (size_t)P * 5 * HW;     // [P][h][w][2]
     float* flowB = flowA + (size_t)P * 2 * HW;
-    float* VS = flowB + (size_t)P * 2 * HW;    // [P][5][h][w]
-    unsigned* mm = reinterpret_cast<unsigned*>(VS + (size_t)P * 5 * HW);
+    unsigned* mm = reinterpret_cast<unsigned*>(flowB + (size_t)P * 2 * HW);
 
     PolyConsts pc;
     prepare_poly(&pc);
@@ -712,15 +712,16 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
             hipLaunchKernelGGL(poly_vertical, g_lvl2, dim3(256), 0, s, Isrc, T, hh, w, pc);
             hipLaunchKernelGGL(poly_horizontal, g_lvl2, dim3(256), 0, s, T, R, hh, w, pc);
         }
-        const int nseg = (hh + BOX_SEG - 1) / BOX_SEG;
         hipLaunchKernelGGL(update_matrices_k, g_lvl, dim3(256), 0, s, R, cur, M, hh, w);
-        for (int it = 0; it < ITERS; ++it) {
-            hipLaunchKernelGGL(box_vertical, dim3(nblocks(w), nseg, P * 5), dim3(256), 0, s, M, VS, hh, w, nseg);
-            if (vec4_ok(w, hw, VS, cur))
-                hipLaunchKernelGGL(box_horizontal_solve_v4, dim3(nblocks((w + 3) / 4), hh, P), dim3(256), 0, s, VS, cur, hh, w);
-            else
-                hipLaunchKernelGGL(box_horizontal_solve, g_lvl, dim3(256), 0, s, VS, cur, hh, w);
-            if (it < ITERS - 1) hipLaunchKernelGGL(update_matrices_k, g_lvl, dim3(256), 0, s, R, cur, M, hh, w);
+        {
+            int seg = 135;   // a multiple of the 15-row ring period
+            const int bands = (w + FUSE_OUT - 1) / FUSE_OUT;
+            while (seg > 30 && (int64_t)bands * ((hh + seg - 1) / seg) * P < 1024) seg -= 15;   // enough blocks to fill the chip
+            const dim3 gf(bands, (hh + seg - 1) / seg, P);
+            for (int it = 0; it < ITERS; ++it) {
+                hipLaunchKernelGGL(box_solve_fused, gf, dim3(256), 0, s, M, cur, hh, w, seg);
+                if (it < ITERS - 1) hipLaunchKernelGGL(update_matrices_k, g_lvl, dim3(256), 0, s, R, cur, M, hh, w);
+            }
         }
         prev_flow = cur;
         ph = hh;
