@@ -195,128 +195,55 @@ __global__ __launch_bounds__(256) void resize_linear_f32(const float* __restrict
     dst[((b * h + dy) * w) * C + e] = (r0 * (1.f - fy) + r1 * fy) * mul;
 }
 
-// FarnebackPolyExp, vertical part: I [B][h][w] -> T [B][h][w][3]
-__global__ __launch_bounds__(256) void poly_vertical(const float* __restrict__ I, float* __restrict__ T, int h, int w,
-                                                     PolyConsts pc) {
-    const int x = blockIdx.x * 256 + threadIdx.x;        // grid (w / 256, h, images)
-    if (x >= w) return;
+// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][h][w][5].  A block owns one row of a band of 246 output
+// columns (256 threads = 246 + the 5-column halo on each side, replicated border): every thread applies the vertical 11-tap
+// filters to ITS column (float, as OpenCV), the three results go through LDS, and the horizontal 11-tap part (double
+// accumulators, as OpenCV) reads its neighbours there.  The intermediate [h][w][3] plane never goes to HBM: 4 + 20 bytes per
+// pixel instead of 48 (the 11 rows a block reads are shared with the blocks of the neighbouring rows through L2).
+constexpr int POLY_OUT = 256 - 2 * POLY_N;   // 246
+__global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ I, float* __restrict__ R, int h, int w,
+                                                      PolyConsts pc) {
+    __shared__ float lt[3][256];
+    const int tid = threadIdx.x;
+    const int x = blockIdx.x * POLY_OUT - POLY_N + tid;     // grid (w / 246, h, images)
+    const int xc = clampi(x, 0, w - 1);
     const int y = blockIdx.y;
-    const float* img = I + (int64_t)blockIdx.z * ((int64_t)w * h);
-    float t0 = img[(int64_t)y * w + x] * pc.g[0], t1 = 0.f, t2 = 0.f;
+    const float* img = I + (int64_t)blockIdx.z * ((int64_t)w * h) + xc;
+    float t0 = img[(int64_t)y * w] * pc.g[0], t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int k = 1; k <= POLY_N; ++k) {
-        const float up = img[(int64_t)(y - k < 0 ? 0 : y - k) * w + x];
-        const float dn = img[(int64_t)(y + k > h - 1 ? h - 1 : y + k) * w + x];
+        const float up = img[(int64_t)(y - k < 0 ? 0 : y - k) * w];
+        const float dn = img[(int64_t)(y + k > h - 1 ? h - 1 : y + k) * w];
         const float p = up + dn;
         t0 += pc.g[k] * p;
         t1 += pc.xg[k] * (dn - up);
         t2 += pc.xxg[k] * p;
     }
-    float* o = T + (((int64_t)blockIdx.z * h + y) * w + x) * 3;
-    o[0] = t0;
-    o[1] = t1;
-    o[2] = t2;
-}
-
-// horizontal part (replicated border), double accumulators as in OpenCV: T -> R [B][h][w][5]
-__global__ __launch_bounds__(256) void poly_horizontal(const float* __restrict__ T, float* __restrict__ R, int h, int w,
-                                                       PolyConsts pc) {
-    const int x = blockIdx.x * 256 + threadIdx.x;        // grid (w / 256, h, images)
-    if (x >= w) return;
-    const int64_t rowpx = ((int64_t)blockIdx.z * h + blockIdx.y) * w;
-    const float* row = T + rowpx * 3;
-    double b1 = row[x * 3] * pc.g[0], b2 = 0, b3 = row[x * 3 + 1] * pc.g[0], b4 = 0, b5 = row[x * 3 + 2] * pc.g[0], b6 = 0;
+    lt[0][tid] = t0;
+    lt[1][tid] = t1;
+    lt[2][tid] = t2;
+    __syncthreads();
+    if (tid < POLY_N || tid >= 256 - POLY_N || x >= w) return;
+    double b1 = t0 * pc.g[0], b2 = 0, b3 = t1 * pc.g[0], b4 = 0, b5 = t2 * pc.g[0], b6 = 0;
 #pragma unroll
     for (int k = 1; k <= POLY_N; ++k) {
-        const float* p = row + (x + k > w - 1 ? w - 1 : x + k) * 3;
-        const float* m = row + (x - k < 0 ? 0 : x - k) * 3;
-        const double tg = p[0] + m[0];
+        const float p0 = lt[0][tid + k], m0 = lt[0][tid - k];
+        const float p1 = lt[1][tid + k], m1 = lt[1][tid - k];
+        const float p2 = lt[2][tid + k], m2 = lt[2][tid - k];
+        const double tg = p0 + m0;
         b1 += tg * pc.g[k];
         b4 += tg * pc.xxg[k];
-        b2 += (p[0] - m[0]) * pc.xg[k];
-        b3 += (p[1] + m[1]) * pc.g[k];
-        b6 += (p[1] - m[1]) * pc.xg[k];
-        b5 += (p[2] + m[2]) * pc.g[k];
+        b2 += (p0 - m0) * pc.xg[k];
+        b3 += (p1 + m1) * pc.g[k];
+        b6 += (p1 - m1) * pc.xg[k];
+        b5 += (p2 + m2) * pc.g[k];
     }
-    float* o = R + (rowpx + x) * 5;
+    float* o = R + (((int64_t)blockIdx.z * h + y) * w + x) * 5;
     o[1] = (float)(b2 * pc.ig11);
     o[0] = (float)(b3 * pc.ig11);
     o[3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
     o[2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
     o[4] = (float)(b6 * pc.ig55);
-}
-
-// 4 adjacent pixels per thread, 16-byte loads and stores; per pixel the arithmetic and its order are those of the scalar
-// kernels above (bit-identical), only the memory instructions change (rows a multiple of 4 long, see vec4_ok).
-__global__ __launch_bounds__(256) void poly_vertical_v4(const float* __restrict__ I, float* __restrict__ T, int h, int w,
-                                                        PolyConsts pc) {
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // grid (w / 1024, h, images)
-    if (x0 >= w) return;
-    const int y = blockIdx.y;
-    const float* img = I + (int64_t)blockIdx.z * ((int64_t)w * h) + x0;
-    const f32x4 c = *reinterpret_cast<const f32x4*>(img + (int64_t)y * w);
-    f32x4 t0 = c * pc.g[0], t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 1; k <= POLY_N; ++k) {
-        const f32x4 up = *reinterpret_cast<const f32x4*>(img + (int64_t)(y - k < 0 ? 0 : y - k) * w);
-        const f32x4 dn = *reinterpret_cast<const f32x4*>(img + (int64_t)(y + k > h - 1 ? h - 1 : y + k) * w);
-        const f32x4 p = up + dn;
-        t0 += pc.g[k] * p;
-        t1 += pc.xg[k] * (dn - up);
-        t2 += pc.xxg[k] * p;
-    }
-    float* o = T + (((int64_t)blockIdx.z * h + y) * w + x0) * 3;
-    *reinterpret_cast<f32x4*>(o) = (f32x4){t0.x, t1.x, t2.x, t0.y};
-    *reinterpret_cast<f32x4*>(o + 4) = (f32x4){t1.y, t2.y, t0.z, t1.z};
-    *reinterpret_cast<f32x4*>(o + 8) = (f32x4){t2.z, t0.w, t1.w, t2.w};
-}
-
-__global__ __launch_bounds__(256) void poly_horizontal_v4(const float* __restrict__ T, float* __restrict__ R, int h, int w,
-                                                          PolyConsts pc) {
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // grid (w / 1024, h, images)
-    if (x0 >= w) return;
-    const int64_t rowpx = ((int64_t)blockIdx.z * h + blockIdx.y) * w;
-    const float* row = T + rowpx * 3;
-    float v[60];   // pixels x0 - 8 .. x0 + 11, 3 floats each
-    if (x0 >= 8 && x0 + 12 <= w) {
-#pragma unroll
-        for (int q = 0; q < 15; ++q) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(row + (x0 - 8) * 3 + 4 * q);
-            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 20; ++j) {
-            const float* px = row + clampi(x0 - 8 + j, 0, w - 1) * 3;
-            v[3 * j] = px[0]; v[3 * j + 1] = px[1]; v[3 * j + 2] = px[2];
-        }
-    }
-    float o[20];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float* cpx = v + (8 + e) * 3;
-        double b1 = cpx[0] * pc.g[0], b2 = 0, b3 = cpx[1] * pc.g[0], b4 = 0, b5 = cpx[2] * pc.g[0], b6 = 0;
-#pragma unroll
-        for (int k = 1; k <= POLY_N; ++k) {
-            const float* pp = cpx + 3 * k;     // clamped fetches above reproduce the replicated border
-            const float* mm = cpx - 3 * k;
-            const double tg = pp[0] + mm[0];
-            b1 += tg * pc.g[k];
-            b4 += tg * pc.xxg[k];
-            b2 += (pp[0] - mm[0]) * pc.xg[k];
-            b3 += (pp[1] + mm[1]) * pc.g[k];
-            b6 += (pp[1] - mm[1]) * pc.xg[k];
-            b5 += (pp[2] + mm[2]) * pc.g[k];
-        }
-        o[5 * e + 1] = (float)(b2 * pc.ig11);
-        o[5 * e] = (float)(b3 * pc.ig11);
-        o[5 * e + 3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-        o[5 * e + 2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-        o[5 * e + 4] = (float)(b6 * pc.ig55);
-    }
-    float* dst = R + (rowpx + x0) * 5;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = (f32x4){o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
 }
 
 // FarnebackUpdateMatrices for one pixel: R0 = its 5 expansion coefficients in frame 0, R1 = frame 1's coefficient image,
@@ -637,14 +564,13 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
                       float* flow_out, uint8_t* bgr_out, hipStream_t s) {
     const int64_t HW = (int64_t)H * W;
     // workspace carve (floats unless noted), all sized for level 0
-    const size_t per_pair = (size_t)HW * (2 + 2 + 2 + 2 + 6 + 10 + 5 + 2 + 2) * sizeof(float) + 16;
+    const size_t per_pair = (size_t)HW * (2 + 2 + 2 + 2 + 10 + 5 + 2 + 2) * sizeof(float) + 16;
     RELAX_TRY(ensure_buf(h, h->flow_ws, per_pair * P));
     float* gray = static_cast<float*>(h->flow_ws.p);
     float* tmp = gray + (size_t)P * 2 * HW;
     float* blur = tmp + (size_t)P * 2 * HW;
     float* I = blur + (size_t)P * 2 * HW;
-    float* T = I + (size_t)P * 2 * HW;         // [P*2][h][w][3]
-    float* R = T + (size_t)P * 6 * HW;         // [P][2][h][w][5]
+    float* R = I + (size_t)P * 2 * HW;         // [P][2][h][w][5]
     float* M = R + (size_t)P * 10 * HW;        // [P][h][w][5]
     float* flowA = M + (size_t)P * 5 * HW;     // [P][h][w][2]
     float* flowB = flowA + (size_t)P * 2 * HW;
@@ -704,14 +630,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
                 Isrc = I;
             }
         }
-        if (vec4_ok(w, hw, Isrc, T) && vec4_ok(w, hw, R, T)) {
-            const dim3 g4(nblocks((w + 3) / 4), hh, P * 2);
-            hipLaunchKernelGGL(poly_vertical_v4, g4, dim3(256), 0, s, Isrc, T, hh, w, pc);
-            hipLaunchKernelGGL(poly_horizontal_v4, g4, dim3(256), 0, s, T, R, hh, w, pc);
-        } else {
-            hipLaunchKernelGGL(poly_vertical, g_lvl2, dim3(256), 0, s, Isrc, T, hh, w, pc);
-            hipLaunchKernelGGL(poly_horizontal, g_lvl2, dim3(256), 0, s, T, R, hh, w, pc);
-        }
+        hipLaunchKernelGGL(poly_expansion, dim3((w + POLY_OUT - 1) / POLY_OUT, hh, P * 2), dim3(256), 0, s, Isrc, R, hh, w, pc);
         hipLaunchKernelGGL(update_matrices_k, g_lvl, dim3(256), 0, s, R, cur, M, hh, w);
         {
             int seg = 135;   // a multiple of the 15-row ring period
