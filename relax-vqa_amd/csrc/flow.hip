@@ -309,90 +309,120 @@ __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict
 }
 
 // The 15x15 box blur and the 2x2 solve of one Farneback iteration in ONE pass over M (no intermediate plane of row sums).
-// A block owns a band of 242 output columns (256 threads = 242 + the 7-column halo on each side) and a segment
-// of rows, and walks down the rows:
-//   * every thread owns ONE column: the last 15 rows of the 5 planes live in a register ring (static indices: the row loop is
-//     unrolled over the ring period), so each M element is loaded once per segment and the running sums (double, as in
-//     the reference) cost one add and one subtract per row; the next row's 5 loads are issued before the current row is used;
-//   * the column sums go through LDS in double (OpenCV's FarnebackUpdateFlow_Blur and the oracle keep them in double too), one
-//     barrier per row (two buffers), then the 15-column window (double) and the solve.
-// HBM traffic per pixel: ~24 bytes of M + 8 of flow instead of 68 with a separate vertical pass that stores its row sums (the
-// first version of this file, which also rounded them to float on the way).
-// (Appending FarnebackUpdateMatrices to the row loop was measured too: its dependent gather between two barriers makes the
-// fused kernel slower than this kernel followed by update_matrices_k, 1034 vs 892 us per iteration at 2160p x 4 pairs.)
-constexpr int FUSE_OUT = 256 - 2 * (WINSIZE / 2);   // 242 output columns per block
+// A block owns a band of 240 output columns (254 threads = 240 + the 7-column halo on each side) and a segment of rows, and
+// walks down the rows three at a time:
+//   * vertical part, one COLUMN per thread: the last 15 rows of the 5 planes live in a register ring (static indices: the
+//     row loop is unrolled over the ring period), so each M element is loaded once per segment and the running sums (double,
+//     as OpenCV's FarnebackUpdateFlow_Blur and the oracle keep them) cost one add and one subtract per row; the three rows that
+//     enter the window next are requested a group ahead;
+//   * the column sums of the 3 rows go through LDS in double; then 180 threads each take a strip of 4 adjacent outputs of one
+//     row: 9 16-byte LDS reads per plane, the 15-column window slid in double (sums of 15 doubles that are sums of 15 floats
+//     are exact, so sliding does not change them), the 2x2 solve.  (One output per lane needed 75 LDS reads and adds per
+//     pixel and was LDS-bound: 597 us for 4 pairs of 2160p; appending FarnebackUpdateMatrices to the row loop puts a dependent
+//     gather between two barriers and was slower than a separate update_matrices_k.)
+// HBM traffic per pixel: ~24 bytes of M + 8 of flow instead of 68 with a separate vertical pass that stores its row sums.
+constexpr int FUSE_ROWS = 3;                          // divides the ring period
+constexpr int FUSE_OUT = 240;                         // output columns per block
+constexpr int FUSE_STRIPS = FUSE_OUT / 4;             // 60 strips per row, 180 strip threads per group
+static_assert(WINSIZE % FUSE_ROWS == 0 && FUSE_OUT + WINSIZE - 1 <= 256 && FUSE_ROWS * FUSE_STRIPS <= 256, "fused box geometry");
 __global__ __launch_bounds__(256) void box_solve_fused(const float* __restrict__ M, float* __restrict__ flow, int h, int w,
                                                        int seg) {
-    __shared__ double lds[2][5][256];
+    __shared__ __attribute__((aligned(16))) double lds[FUSE_ROWS][5][256];
     constexpr int m = WINSIZE / 2;
     const int tid = threadIdx.x;
-    const int x = blockIdx.x * FUSE_OUT - m + tid;            // this thread's column (halo threads: clamped = replicated border)
-    const int xc = clampi(x, 0, w - 1);
+    const int c0 = blockIdx.x * FUSE_OUT;                     // first output column of the band
+    const int xc = clampi(c0 - m + tid, 0, w - 1);            // this thread's column (clamped = replicated border)
+    const bool vert = tid < FUSE_OUT + 2 * m;
     const int y0 = blockIdx.y * seg;
     const int y1 = y0 + seg < h ? y0 + seg : h;
     const int64_t hw = (int64_t)h * w;
     const int64_t pair = blockIdx.z;
     const float* col = M + pair * 5 * hw + xc;
-    const bool writer = tid >= m && tid < 256 - m && x < w;
+    // strip role
+    const int sr = tid / FUSE_STRIPS, sq = tid - sr * FUSE_STRIPS;
+    const int x0 = c0 + 4 * sq;
+    const bool strip = tid < FUSE_ROWS * FUSE_STRIPS && x0 < w;
 
     float ring[5][WINSIZE];   // the 15 rows of the window; slot of row r = (r - y0 + 7) % 15
     double s[5];
+    float nxt[FUSE_ROWS][5];  // rows entering the window at the rows of the next group
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
         s[c] = 0;
 #pragma unroll
         for (int k = 0; k < WINSIZE; ++k) {                   // rows y0-7 .. y0+7 in order
-            ring[c][k] = col[c * hw + (int64_t)clampi(y0 - m + k, 0, h - 1) * w];
+            ring[c][k] = vert ? col[c * hw + (int64_t)clampi(y0 - m + k, 0, h - 1) * w] : 0.f;
             s[c] += ring[c][k];
         }
-    }
-    float nxt[5];                                             // row y0+8: enters the window at y0+1
 #pragma unroll
-    for (int c = 0; c < 5; ++c) nxt[c] = col[c * hw + (int64_t)clampi(y0 + m + 1, 0, h - 1) * w];
+        for (int r = 0; r < FUSE_ROWS; ++r) nxt[r][c] = vert ? col[c * hw + (int64_t)clampi(y0 + r + m, 0, h - 1) * w] : 0.f;
+    }
 
     for (int yb = y0; yb < y1; yb += WINSIZE) {
 #pragma unroll
-        for (int k = 0; k < WINSIZE; ++k) {                   // ring slot k holds row y - 8 when row y = yb + k is processed (k >= 1)
-            const int y = yb + k;
-            if (y < y1) {                                     // uniform over the block
-                if (y > y0) {
-                    float cur[5];
+        for (int g = 0; g < WINSIZE / FUSE_ROWS; ++g) {
+            const int yg = yb + g * FUSE_ROWS;
+            if (yg < y1) {                                    // uniform over the block
+                float cur[FUSE_ROWS][5];
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) cur[c] = nxt[c];
-#pragma unroll
-                    for (int c = 0; c < 5; ++c)               // prefetch the row that enters at y + 1
-                        nxt[c] = col[c * hw + (int64_t)clampi(y + m + 1, 0, h - 1) * w];
-                    // slot of row r = (r - y0 + 7) % 15: the row that leaves (y - 8) and the row that enters (y + 7) share slot
-                    // (y - y0 - 1) % 15 = (k - 1) mod 15, static because yb - y0 is a multiple of the ring period
+                for (int r = 0; r < FUSE_ROWS; ++r)
 #pragma unroll
                     for (int c = 0; c < 5; ++c) {
-                        const int slot = (k + WINSIZE - 1) % WINSIZE;
-                        s[c] += (double)cur[c] - (double)ring[c][slot];
-                        ring[c][slot] = cur[c];
+                        cur[r][c] = nxt[r][c];
+                        nxt[r][c] = vert ? col[c * hw + (int64_t)clampi(yg + FUSE_ROWS + r + m, 0, h - 1) * w] : 0.f;
                     }
-                }
-                const int bsel = ((yb - y0) / WINSIZE + k) & 1;   // alternate buffers row by row across ring periods too
 #pragma unroll
-                for (int c = 0; c < 5; ++c) lds[bsel][c][tid] = s[c];
-                __syncthreads();   // one barrier per row: the other buffer is rewritten only after every reader passed this point
-                if (writer) {
-                    double acc[5];
+                for (int r = 0; r < FUSE_ROWS; ++r) {
+                    const int k = g * FUSE_ROWS + r;          // row y = yb + k; the leaving and the entering row share slot (k - 1) mod 15
+                    const int y = yb + k;
+                    if (y > y0 && y < y1) {
+                        const int slot = (k + WINSIZE - 1) % WINSIZE;
+#pragma unroll
+                        for (int c = 0; c < 5; ++c) {
+                            s[c] += (double)cur[r][c] - (double)ring[c][slot];
+                            ring[c][slot] = cur[r][c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) lds[r][c][tid] = s[c];
+                }
+                __syncthreads();
+                const int y = yg + sr;
+                if (strip && y < y1) {
+                    double acc[5][4];
 #pragma unroll
                     for (int c = 0; c < 5; ++c) {
+                        double v[18];   // column sums at band columns 4*sq .. 4*sq + 17 (output o uses o .. o + 14)
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) {
+                            const double2 t = *reinterpret_cast<const double2*>(&lds[sr][c][4 * sq + 2 * j]);
+                            v[2 * j] = t.x;
+                            v[2 * j + 1] = t.y;
+                        }
                         double a = 0;
 #pragma unroll
-                        for (int j = -m; j <= m; ++j) a += lds[bsel][c][tid + j];
-                        acc[c] = a;
+                        for (int j = 0; j < WINSIZE; ++j) a += v[j];
+                        acc[c][0] = a;
+#pragma unroll
+                        for (int e = 1; e < 4; ++e) {
+                            a += v[WINSIZE - 1 + e] - v[e - 1];
+                            acc[c][e] = a;
+                        }
                     }
                     const double sc = 1.0 / (WINSIZE * WINSIZE);
-                    const double g11 = acc[0] * sc, g12 = acc[1] * sc, g22 = acc[2] * sc, h1 = acc[3] * sc, h2 = acc[4] * sc;
-                    const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
-                    const float fdx = (float)((g11 * h2 - g12 * h1) * idet);
-                    const float fdy = (float)((g22 * h1 - g12 * h2) * idet);
-                    const int64_t px = (int64_t)y * w + x;
-                    flow[(pair * hw + px) * 2] = fdx;
-                    flow[(pair * hw + px) * 2 + 1] = fdy;
+                    float* dst = flow + (pair * hw + (int64_t)y * w + x0) * 2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (x0 + e < w) {
+                            const double g11 = acc[0][e] * sc, g12 = acc[1][e] * sc, g22 = acc[2][e] * sc, h1 = acc[3][e] * sc,
+                                         h2 = acc[4][e] * sc;
+                            const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
+                            dst[2 * e] = (float)((g11 * h2 - g12 * h1) * idet);
+                            dst[2 * e + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+                        }
+                    }
                 }
+                __syncthreads();   // the next group overwrites the three rows
             }
         }
     }
