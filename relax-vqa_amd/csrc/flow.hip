@@ -115,24 +115,35 @@ __device__ inline void linear_tap(int d, double scale, int n_in, int* s0, int* s
     *f = fx;
 }
 
-// horizontal blur at the two sample columns of every output column: src [B][H][W] -> tmp [B][H][w][2]
+// horizontal blur at the two sample columns of every output column: src [B][H][W] -> tmp [B][H][w][2].  A block first copies
+// the stretch of the source row its 256 outputs tap (reflected at the borders while copying) into LDS with coalesced loads;
+// the 9 / 19 taps per output then come from LDS instead of strided global loads.
+constexpr int GH_SEG = 1280;   // floats of source row per block: 128 output columns x scale <= 8, plus the taps
 __global__ __launch_bounds__(256) void gauss_h_sampled(const float* __restrict__ src, float* __restrict__ tmp, int H, int W,
                                                        int w, double scale_x, GaussKernel gk) {
     __shared__ float sk[MAX_GAUSS];
-    stage_taps(gk, sk);
-    const int e = blockIdx.x * 256 + threadIdx.x;        // grid (2w / 256, H, images): e = dx * 2 + j
-    if (e >= 2 * w) return;
-    const int j = e & 1;
-    const int dx = e >> 1;
+    __shared__ float seg[GH_SEG];
+    const int e0 = blockIdx.x * 256;                      // grid (2w / 256, H, images): e = dx * 2 + j
     const int64_t row = (int64_t)blockIdx.z * H + blockIdx.y;            // b*H + y
-    int s0, s1;
-    float f;
-    linear_tap(dx, scale_x, W, &s0, &s1, &f);
-    const int x = j ? s1 : s0;
     const float* r_ = src + row * W;
     const int r = gk.ksize / 2;
+    int a0, a1, b0, b1;
+    float f;
+    linear_tap(e0 >> 1, scale_x, W, &a0, &a1, &f);
+    const int dx_last = (e0 + 255) >> 1 < w ? (e0 + 255) >> 1 : w - 1;
+    linear_tap(dx_last, scale_x, W, &b0, &b1, &f);
+    const int xlo = a0 - r;
+    const int n = b1 + r - xlo + 1;                       // <= GH_SEG (checked by the launcher)
+    if (threadIdx.x < MAX_GAUSS) sk[threadIdx.x] = gk.k[threadIdx.x];
+    for (int i = threadIdx.x; i < n; i += 256) seg[i] = r_[reflect101(xlo + i, W)];
+    __syncthreads();
+    const int e = e0 + threadIdx.x;
+    if (e >= 2 * w) return;
+    int s0, s1;
+    linear_tap(e >> 1, scale_x, W, &s0, &s1, &f);
+    const int x = (e & 1) ? s1 : s0;
     float acc = 0.f;
-    for (int t = 0; t < gk.ksize; ++t) acc += sk[t] * r_[reflect101(x + t - r, W)];
+    for (int t = 0; t < gk.ksize; ++t) acc += sk[t] * seg[x + t - r - xlo];
     tmp[row * (2 * w) + e] = acc;
 }
 
@@ -629,6 +640,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
         int smooth = (int)lrint(sigma * 5) | 1;
         if (smooth < 3) smooth = 3;
         RELAX_REQUIRE(h, smooth <= MAX_GAUSS, "optical flow: smoothing kernel %d too large", smooth);
+        RELAX_REQUIRE(h, k < 2 || 129.0 / scale + smooth + 4 <= GH_SEG, "optical flow: pyramid scale %g too coarse for the row stage", scale);
         const int w = (int)lrint(W * scale), hh = (int)lrint(H * scale);
         const int64_t hw = (int64_t)w * hh;
         if (!prev_flow) {
