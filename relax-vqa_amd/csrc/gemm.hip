@@ -7,15 +7,14 @@
 //   k = (dy*KW + dx)*Cin + c, gathered on the fly from the NHWC input (never materialised)
 //   n = output channel; W is stored [Cout][Kpad] (K fastest) so A and W tiles stage identically
 //
-// Tiling for 64-wide wavefronts: a workgroup of 4 waves owns a BM x BN tile, each wave a
-// (TM*32) x (TN*32) sub-tile held in TM*TN 32x32 MFMA accumulators.  The K loop runs BK = 32
-// deep steps through two LDS buffers (register-staged prefetch of step k+1 under the MFMAs of
-// step k, one barrier per step).  LDS rows are padded to 36 floats so both the ds_write_b128
-// staging writes and the ds_read_b128 fragment reads are bank-conflict free.  Because the MFMA
-// sums over k, the k order inside a step is free: lane (i, h) reads the 4 consecutive floats
-// k = 8q+4h .. 8q+4h+3 of row i with ONE 128-bit LDS read and feeds them to 4 MFMAs.
-// Workgroup ids are remapped so that the workgroups sharing one XCD (and its L2) walk
-// neighbouring tiles: all column tiles of an activation row-tile run on the same XCD.
+// Tiling for 64-wide wavefronts: a workgroup of WM x WN waves owns a BM x BN tile, each wave a (TM*32) x (TN*32) sub-tile
+// held in TM*TN 32x32 MFMA accumulators.  The K loop runs BK-deep steps through two LDS buffers (register-staged prefetch of
+// step k+1 under the MFMAs of step k, one barrier per step).  LDS rows are padded to BK + 4 floats so the ds_read_b128
+// fragment reads are bank-conflict free.  Because the MFMA sums over k, the k order inside a step is free: lane (i, h)
+// reads the 4 consecutive floats k = 8q+4h .. 8q+4h+3 of row i with ONE 128-bit LDS read and feeds them to 4 MFMAs.
+// Workgroup ids are remapped so that the workgroups sharing one XCD (and its L2) walk neighbouring tiles.
+// Defaults (launch_conv): fp32 128x128 tile, 4 waves, BK = 16, three workgroups per CU; 128x64 for N % 128 != 0;
+// opt-in bf16x3 precision: 256x256 tile on 8 waves for large plain GEMMs, 128-wide tiles otherwise.
 #include "relax_internal.h"
 
 #ifndef RELAX_X3_ABLATE
