@@ -621,7 +621,9 @@ static int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
-// tile variants: id -> <BM, BN, WM, WN>, workgroups resident per CU (LDS / VGPR bound)
+// tile variants: id -> <BM, BN, WM, WN, BK>, workgroups resident per CU (LDS / VGPR bound).  7 and 10 are the defaults; 1, 4, 5
+// are the alternatives they were measured against (kept selectable: relax_set_option "gemm_variant", tools/gemm_bench.py).
+// Tried and dropped: 8-wave 128x128 splits, 64x64 tiles, a register cap for 4 workgroups per CU (spilled).
 #define RELAX_DISPATCH(BM_, BN_, WM_, WN_, BK_, OCC_, BPC_)                                  \
     (taps ? launch_variant<BM_, BN_, WM_, WN_, BK_, OCC_, true, 0>(h, p, BPC_, s)            \
           : launch_variant<BM_, BN_, WM_, WN_, BK_, OCC_, false, 0>(h, p, BPC_, s))
@@ -670,8 +672,7 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
         // plain GEMMs with enough rows take a 256x256 tile on 8 waves (128x64 per wave, one workgroup per CU): half the
         // L2 -> LDS bytes per MFMA of the 128x128 tile, +15 % on the ViT shapes (tools/gemm_bench.py --precision bf16x3)
         const bool big = !taps && p.N % 256 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 256) >= 256 && h->gemm.variant != 1;
-        if (!taps && p.N % 256 == 0 && h->gemm.variant == 22) rc = launch_variant<128, 256, 1, 4, 16, 2, false, 1>(h, p, 2, s);
-        else if (big) rc = launch_variant<256, 256, 2, 4, 32, 1, false, 1>(h, p, 1, s);
+        if (big) rc = launch_variant<256, 256, 2, 4, 32, 1, false, 1>(h, p, 1, s);
         else rc = (p.N % 128 == 0) ? RELAX_DISPATCH_X3(128, 128, 2, 2, 2, 2) : RELAX_DISPATCH_X3(128, 64, 2, 2, 2, 2);
         RELAX_TRY(rc);
         RELAX_TRY(prof_end(h, s, span));
@@ -679,14 +680,9 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
     }
     switch (variant) {
         case 1: rc = RELAX_DISPATCH(128, 128, 2, 2, 32, 1, 2); break;   // 4 waves, 64x64 per wave
-        case 2: rc = RELAX_DISPATCH(128, 128, 2, 4, 32, 1, 2); break;   // 8 waves, 64x32 per wave
-        case 3: rc = RELAX_DISPATCH(128, 128, 4, 2, 32, 1, 2); break;   // 8 waves, 32x64 per wave
         case 4: rc = RELAX_DISPATCH(256, 128, 4, 2, 32, 1, 1); break;   // 8 waves, 64x64 per wave, 1 workgroup / CU
         case 5: rc = RELAX_DISPATCH(128, 64, 2, 2, 32, 1, 2); break;   // 4 waves, 64x32 per wave
-        case 6: rc = RELAX_DISPATCH(64, 64, 2, 2, 32, 1, 4); break;
         case 7: rc = RELAX_DISPATCH(128, 128, 2, 2, 16, 1, 3); break;   // BK 16: 36.9 KB LDS -> 3 workgroups / CU
-        case 8: rc = RELAX_DISPATCH(128, 128, 2, 4, 16, 1, 2); break;   // 8 waves, BK 16
-        case 9: rc = RELAX_DISPATCH(128, 128, 2, 2, 16, 4, 4); break;   // BK 16, registers capped for 4 workgroups / CU
         case 10: rc = RELAX_DISPATCH(128, 64, 2, 2, 16, 1, 4); break;   // N = 64 layers, BK 16   // 4 waves, 32x32 per wave
         default:
             set_error(h, "conv/gemm: unknown tile variant %d", variant);

@@ -24,6 +24,24 @@ def test_gemm_plain(M, N, K):
     assert_close(got, want, f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("variant", [1, 4, 5, 7, 10])
+def test_gemm_tile_variants(variant):
+    """Every selectable tile shape of the contraction kernel gives the same answer (N = 192 also exercises the N % 128 != 0 route)."""
+    eng = engine()
+    A, W, b = _rand(700, 256, seed=21), _rand(192, 256, seed=22, scale=1 / 16), _rand(192, seed=23)
+    A2, W2 = _rand(1500, 128, seed=24), _rand(256, 128, seed=25, scale=0.09)
+    want = torch.relu(A.double() @ W.double().T + b.double()).float().numpy()
+    want2 = (A2.double() @ W2.double().T).float().numpy()
+    eng.set_option("gemm_variant", variant)
+    eng.set_option("gemm_variant_n64", variant if variant in (5, 10) else -1)
+    try:
+        assert_close(eng.op_gemm(A.cuda(), W.cuda(), b.cuda(), act=1), want, f"variant {variant} N=192")
+        assert_close(eng.op_gemm(A2.cuda(), W2.cuda()), want2, f"variant {variant} N=256")
+    finally:
+        eng.set_option("gemm_variant", -1)
+        eng.set_option("gemm_variant_n64", -1)
+
+
 def test_gemm_identity_asymmetric():
     # A = I with an asymmetric W catches a transposed C write
     K = N = 64
