@@ -180,3 +180,42 @@ def test_variant_drivers_keep_their_own_signatures(api, tmp_path):
     assert ml.process_video_feature([wtok], "vit").shape == (1, 2304)
     with pytest.raises(NotImplementedError):
         ml.get_deep_feature("vgg16", "a", o, "original")
+
+
+def test_full_35203_vector_every_block_against_the_oracle(api):
+    """The whole demo_test vector, block by block: whole-frame ResNet-50 layer stack | whole-frame ViT stats | fragment
+    layer stack | residual-fragment pool | ViT stats of the original and of the residual fragment (src/demo_test.py:89-175).
+    The flow images come from the GPU and are handed to both sides, so the comparison does not hinge on a near-tie between
+    two flow patches."""
+    import torch
+    from oracle import resize_ref
+    from relax_vqa_amd import runtime
+    m, rn, vit = api
+    eng = runtime.get_engine()
+    clip = synth.synthetic_clip(2, 272, 400, clip_id=21)
+    frames = torch.from_numpy(clip).cuda()
+    _, flow_img = eng.optical_flow(frames)
+    vec = eng.full_clip_vector(frames, flow_images=flow_img).cpu().numpy()
+    fimg = flow_img.cpu().numpy()
+    tr, tv = resnet50_ref.to_torch_state_dict(rn), vit_ref.to_torch_state_dict(vit)
+    ori, res, bil, lan = [], [], [], []
+    for t in range(2):
+        fp = fragment_ref.fragment_pair(clip[t, 0], clip[t, 1])
+        flow_frag, _ = fragment_ref.extract_important_patches(fimg[t], fragment_ref.get_patch_diff(fimg[t]))
+        ori.append(fp["ori_frag"])
+        res.append(fragment_ref.merge_fragments(fp["diff_frag"], flow_frag))
+        bil.append(resize_ref.resize(clip[t, 0], 224, 224, resize_ref.BILINEAR))
+        lan.append(resize_ref.resize(clip[t, 0], 224, 224, resize_ref.LANCZOS))
+    ori, res, bil, lan = (np.stack(a) for a in (ori, res, bil, lan))
+    want = np.concatenate([
+        resnet50_ref.layer_stack_features(tr, bil).mean(axis=0),
+        vit_ref.pool_features(tv, lan, 12).mean(axis=0),
+        resnet50_ref.layer_stack_features(tr, ori).mean(axis=0),
+        resnet50_ref.pool_features(tr, res).mean(axis=0),
+        vit_ref.pool_features(tv, ori, 12).mean(axis=0),
+        vit_ref.pool_features(tv, res, 12).mean(axis=0)])
+    assert want.shape == (35203,)
+    edges = [0, 13120, 15424, 28544, 30595, 32899, 35203]
+    names = ["whole-frame RN50 LS", "whole-frame ViT", "fragment RN50 LS", "residual RN50 pool", "ViT original frag", "ViT residual frag"]
+    for a, b, nm in zip(edges[:-1], edges[1:], names):
+        assert_close(vec[a:b], want[a:b], f"full vector block: {nm}")
