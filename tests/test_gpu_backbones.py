@@ -174,3 +174,25 @@ def test_bf16x3_mode_meets_the_feature_tolerance():
         rel = np.linalg.norm(got - want) / np.linalg.norm(want)
         assert rel < 5e-5, (name, rel)
         assert_close(got, want, f"bf16x3 {name}", rtol=1e-3, atol_frac=2e-4)
+
+
+def test_step_is_graph_capturable():
+    """The C-ABI only enqueues on the caller's stream (no allocation after warm-up, no host sync): a whole clip pass can be
+    captured into a HIP graph and replayed with bit-identical results."""
+    rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    clip = torch.from_numpy(synth.synthetic_clip(2, 240, 320, clip_id=77)).cuda()
+    ref = eng.clip_vectors([clip])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        eng.clip_vectors([clip])
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            out = eng.clip_vectors([clip])
+    torch.cuda.synchronize()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
