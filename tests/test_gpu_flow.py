@@ -49,6 +49,16 @@ def test_flow_matches_oracle():
     assert (img2 == want_img).mean() > 0.999      # hue / value truncation boundaries under FMA contraction
 
 
+@pytest.mark.parametrize("h,w", [(97, 131), (150, 203), (136, 240)])
+def test_flow_odd_sizes_take_the_general_kernels(h, w):
+    """Row lengths that are not a multiple of 4 (and odd pixel counts) cannot use the 16-byte-load kernels: same tolerance."""
+    a, b = _smooth_pair(h, w, 5)
+    flow, _ = engine().optical_flow(torch.from_numpy(np.stack([a, b])[None]).cuda(), want_flow=True, want_image=False)
+    want = flow_ref.farneback(flow_ref.bgr2gray(a), flow_ref.bgr2gray(b))
+    err = np.abs(flow[0].cpu().numpy() - want)
+    assert err.max() < 2e-2 and err.mean() < 1e-4, (err.max(), err.mean())
+
+
 def test_reference_png_pair(golden_dir):
     orig, nxt, want = _load(golden_dir, ""), _load(golden_dir, "_next"), _load(golden_dir, "_residual_of")
     _, img = engine().optical_flow(torch.from_numpy(np.stack([orig, nxt])[None]).cuda())
