@@ -85,8 +85,19 @@ def cpu_baseline(H, W, T, use_vit, rn_sd, vit_sd, sample_pairs):
                   f"best thread count ({best}, calibrated over {candidates})",
         "dedup_value": 1.0 / t_dedup, "sec_per_clip_faithful": t_faithful, "sec_per_clip_dedup": t_dedup,
         "default_threads": default_threads, "value_at_default_threads": 1.0 / t_faithful_default,
-        "host_cpus": os.cpu_count(),
+        "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(),
     }
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def hbm_traffic_per_launch(workload, clips_per_step):
