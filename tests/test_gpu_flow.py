@@ -40,7 +40,7 @@ def test_flow_matches_oracle():
     flow, img = flow[0].cpu().numpy(), img[0].cpu().numpy()
     want = flow_ref.farneback(flow_ref.bgr2gray(a), flow_ref.bgr2gray(b))
     err = np.abs(flow - want)
-    assert err.max() < 2e-2 and err.mean() < 1e-4, (err.max(), err.mean())     # float reassociation only
+    assert err.max() < 1e-3 and err.mean() < 1e-5, (err.max(), err.mean())     # float reassociation only (measured 3e-5 / 6e-7)
     want_img = flow_ref.flow_to_rgb(want)
     d = np.abs(img.astype(np.int32) - want_img.astype(np.int32))
     assert (d == 0).mean() > 0.995 and (d <= 1).mean() > 0.9995, ((d == 0).mean(), (d <= 1).mean())
@@ -56,7 +56,7 @@ def test_flow_odd_sizes_take_the_general_kernels(h, w):
     flow, _ = engine().optical_flow(torch.from_numpy(np.stack([a, b])[None]).cuda(), want_flow=True, want_image=False)
     want = flow_ref.farneback(flow_ref.bgr2gray(a), flow_ref.bgr2gray(b))
     err = np.abs(flow[0].cpu().numpy() - want)
-    assert err.max() < 2e-2 and err.mean() < 1e-4, (err.max(), err.mean())
+    assert err.max() < 1e-3 and err.mean() < 1e-5, (err.max(), err.mean())     # measured <= 2e-5 / 4e-7
 
 
 def test_reference_png_pair(golden_dir):
@@ -64,7 +64,8 @@ def test_reference_png_pair(golden_dir):
     _, img = engine().optical_flow(torch.from_numpy(np.stack([orig, nxt])[None]).cuda())
     img = img[0].cpu().numpy()
     d = np.abs(img.astype(np.int32) - want.astype(np.int32))
-    assert (d == 0).mean() > 0.999 and (d <= 1).mean() > 0.9999, ((d == 0).mean(), (d <= 1).mean())
+    # measured 0.99903 / 0.999992 (the oracle itself reproduces 99.93-99.98 % of the reference's bytes, tests/golden/pin_report.json)
+    assert (d == 0).mean() > 0.998 and (d <= 1).mean() > 0.9999, ((d == 0).mean(), (d <= 1).mean())
     fo = engine().fragment_image(torch.from_numpy(img[None]).cuda())
     n = int(fo["counts"][0])
     got_pos = set(map(tuple, fo["positions"][0, :n].cpu().numpy().tolist()))
