@@ -173,6 +173,7 @@ def test_bf16x3_mode_meets_the_feature_tolerance():
         got = got.cpu().numpy()
         rel = np.linalg.norm(got - want) / np.linalg.norm(want)
         assert rel < 5e-5, (name, rel)
+        assert_close(got, want, f"bf16x3 {name}")   # and the element-wise bar of the fp32 tests (measured: <= 0.38 of it; fp32: <= 0.03)
         assert_close(got, want, f"bf16x3 {name}", rtol=1e-3, atol_frac=2e-4)
 
 
