@@ -50,6 +50,21 @@ __global__ __launch_bounds__(256) void flow_gray(const uint8_t* __restrict__ ori
     gray[(int64_t)img * HW + pix] = (float)(((int)src[0] * 1868 + (int)src[1] * 9617 + (int)src[2] * 4899 + (1 << 13)) >> 14);
 }
 
+// 4 pixels per thread: 12 bytes in as three dwords, one 16-byte store (frames whose pixel count and pointers are multiples of 4)
+__global__ __launch_bounds__(256) void flow_gray_v4(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ next,
+                                                    int64_t pair_stride, int HW, float* __restrict__ gray) {
+    const int pix = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (pix >= HW) return;
+    const int img = blockIdx.z;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(((img & 1) ? next : orig) + (int64_t)(img >> 1) * pair_stride + (int64_t)pix * 3);
+    const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];   // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+#define RELAX_GRAY(b_, g_, r_) (float)(((int)(b_) * 1868 + (int)(g_) * 9617 + (int)(r_) * 4899 + (1 << 13)) >> 14)
+    const f32x4 o = {RELAX_GRAY(w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255), RELAX_GRAY(w0 >> 24, w1 & 255, (w1 >> 8) & 255),
+                     RELAX_GRAY((w1 >> 16) & 255, w1 >> 24, w2 & 255), RELAX_GRAY((w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24)};
+#undef RELAX_GRAY
+    *reinterpret_cast<f32x4*>(gray + (int64_t)img * HW + pix) = o;
+}
+
 // The taps arrive by value in the kernel argument; indexing that with a loop counter costs one dependent scalar load per tap,
 // so every block first copies them into LDS (and the common 3-tap blur of the two finest levels is unrolled from registers).
 __device__ inline void stage_taps(const GaussKernel& gk, float* sk) {
@@ -465,9 +480,16 @@ __global__ __launch_bounds__(256) void mag_minmax(const float* __restrict__ flow
     __shared__ unsigned smin[256], smax[256];
     const int pair = blockIdx.y;
     const float* f = flow + (int64_t)pair * HW * 2;
+    const bool al8 = (reinterpret_cast<uintptr_t>(f) & 7) == 0;   // one 8-byte load per pixel when the pair's plane allows it
     unsigned lo = 0xffffffffu, hi = 0u;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-        const float x = f[i * 2], y = f[i * 2 + 1];
+        float x, y;
+        if (al8) {
+            const float2 v = reinterpret_cast<const float2*>(f)[i];
+            x = v.x; y = v.y;
+        } else {
+            x = f[i * 2]; y = f[i * 2 + 1];
+        }
         const unsigned u = __float_as_uint(sqrtf(x * x + y * y));
         lo = u < lo ? u : lo;
         hi = u > hi ? u : hi;
@@ -495,18 +517,12 @@ __device__ inline void minmax_affine(double smin, double smax, float* scale, flo
     *shift = (float)(0.0 - smin * sc);
 }
 
-__global__ __launch_bounds__(256) void flow_visualise(const float* __restrict__ flow, const unsigned* __restrict__ mm, int P, int HW,
-                                                      uint8_t* __restrict__ bgr) {
-    const int pix = blockIdx.x * 256 + threadIdx.x;      // grid (HW / 256, 1, pairs)
-    if (pix >= HW) return;
-    const int pair = blockIdx.z;
-    const int64_t i = (int64_t)pair * HW + pix;
-    const float x = flow[i * 2], y = flow[i * 2 + 1];
+// one pixel of flow_to_rgb: (x, y) -> packed b | g << 8 | r << 16
+__device__ inline unsigned visualise_pixel(float x, float y, float mn, float mx) {
     float mag = sqrtf(x * x + y * y);
     const float ang = fast_atan2_deg(y, x) * (float)(M_PI / 180);
     // mag = normalize(mag); V = trunc(normalize(mag)): the 2nd min/max are the images of the 1st (monotone affine map)
     float s1, b1, s2, b2;
-    const float mn = __uint_as_float(mm[pair]), mx = __uint_as_float(mm[P + pair]);
     minmax_affine(mn, mx, &s1, &b1);
     mag = mag * s1 + b1;
     minmax_affine((double)(mn * s1 + b1), (double)(mx * s1 + b1), &s2, &b2);
@@ -520,14 +536,46 @@ __global__ __launch_bounds__(256) void flow_visualise(const float* __restrict__ 
     const float f = hh - (float)sector;
     sector %= 6;
     const float s = 255.f * (1.0f / 255.0f), v = (float)Vv * (1.0f / 255.0f);
-    const float tab[4] = {v, v * (1.f - s), v * (1.f - s * f), v * (1.f - s * (1.f - f))};
-    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    const float t0 = v, t1 = v * (1.f - s), t2 = v * (1.f - s * f), t3 = v * (1.f - s * (1.f - f));
+    // OpenCV's sector table {1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0} (B, G, R) as selects: no indexed local arrays
+    const float fb = sector <= 1 ? t1 : (sector == 2 ? t3 : (sector <= 4 ? t0 : t2));
+    const float fg = sector == 0 ? t3 : (sector <= 2 ? t0 : (sector == 3 ? t2 : t1));
+    const float fr = sector == 0 ? t0 : (sector == 1 ? t2 : (sector <= 3 ? t1 : (sector == 4 ? t3 : t0)));
+    float q0 = floorf(fb * 255.f), q1 = floorf(fg * 255.f), q2 = floorf(fr * 255.f);
+    q0 = q0 < 0.f ? 0.f : (q0 > 255.f ? 255.f : q0);
+    q1 = q1 < 0.f ? 0.f : (q1 > 255.f ? 255.f : q1);
+    q2 = q2 < 0.f ? 0.f : (q2 > 255.f ? 255.f : q2);
+    return (unsigned)q0 | ((unsigned)q1 << 8) | ((unsigned)q2 << 16);
+}
+
+__global__ __launch_bounds__(256) void flow_visualise(const float* __restrict__ flow, const unsigned* __restrict__ mm, int P, int HW,
+                                                      uint8_t* __restrict__ bgr) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;      // grid (HW / 256, 1, pairs)
+    if (pix >= HW) return;
+    const int pair = blockIdx.z;
+    const int64_t i = (int64_t)pair * HW + pix;
+    const unsigned c = visualise_pixel(flow[i * 2], flow[i * 2 + 1], __uint_as_float(mm[pair]), __uint_as_float(mm[P + pair]));
     uint8_t* o = bgr + i * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float t = floorf(tab[sd[sector][c]] * 255.f);
-        o[c] = (uint8_t)(t < 0.f ? 0.f : (t > 255.f ? 255.f : t));
-    }
+    o[0] = (uint8_t)c;
+    o[1] = (uint8_t)(c >> 8);
+    o[2] = (uint8_t)(c >> 16);
+}
+
+// 4 pixels per thread: two 16-byte loads, three dword stores (pixel counts and pointers that allow it)
+__global__ __launch_bounds__(256) void flow_visualise_v4(const float* __restrict__ flow, const unsigned* __restrict__ mm, int P,
+                                                         int HW, uint8_t* __restrict__ bgr) {
+    const int pix = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (pix >= HW) return;
+    const int pair = blockIdx.z;
+    const int64_t i = (int64_t)pair * HW + pix;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(flow + i * 2), b = *reinterpret_cast<const f32x4*>(flow + i * 2 + 4);
+    const float mn = __uint_as_float(mm[pair]), mx = __uint_as_float(mm[P + pair]);
+    const unsigned c0 = visualise_pixel(a.x, a.y, mn, mx), c1 = visualise_pixel(a.z, a.w, mn, mx);
+    const unsigned c2 = visualise_pixel(b.x, b.y, mn, mx), c3 = visualise_pixel(b.z, b.w, mn, mx);
+    uint32_t* o = reinterpret_cast<uint32_t*>(bgr + i * 3);
+    o[0] = c0 | (c1 << 24);
+    o[1] = (c1 >> 8) | (c2 << 16);
+    o[2] = (c2 >> 16) | (c3 << 8);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------
@@ -597,7 +645,10 @@ static int visualise(relax_handle* h, const float* flow, int P, int HW, uint8_t*
     RELAX_HIP_CHECK(h, hipMemsetAsync(mm, 0xff, sizeof(unsigned) * P, s));       // running minima
     RELAX_HIP_CHECK(h, hipMemsetAsync(mm + P, 0, sizeof(unsigned) * P, s));       // running maxima
     hipLaunchKernelGGL(mag_minmax, dim3(HW / 4096 > 64 ? (HW / 4096 < 1024 ? HW / 4096 : 1024) : 64, P), dim3(256), 0, s, flow, HW, mm);
-    hipLaunchKernelGGL(flow_visualise, dim3(nblocks(HW), 1, P), dim3(256), 0, s, flow, mm, P, HW, bgr);
+    if (HW % 4 == 0 && (reinterpret_cast<uintptr_t>(flow) & 15) == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0)
+        hipLaunchKernelGGL(flow_visualise_v4, dim3(nblocks(HW / 4), 1, P), dim3(256), 0, s, flow, mm, P, HW, bgr);
+    else
+        hipLaunchKernelGGL(flow_visualise, dim3(nblocks(HW), 1, P), dim3(256), 0, s, flow, mm, P, HW, bgr);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }
@@ -620,7 +671,11 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
 
     PolyConsts pc;
     prepare_poly(&pc);
-    hipLaunchKernelGGL(flow_gray, dim3(nblocks(HW), 1, P * 2), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray);
+    if (HW % 4 == 0 && pair_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(orig) | reinterpret_cast<uintptr_t>(next)) & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(gray) & 15) == 0)
+        hipLaunchKernelGGL(flow_gray_v4, dim3(nblocks(HW / 4), 1, P * 2), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray);
+    else
+        hipLaunchKernelGGL(flow_gray, dim3(nblocks(HW), 1, P * 2), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray);
 
     int levels = 0;
     {
