@@ -766,9 +766,12 @@ int relax_optical_flow(relax_handle* h, const uint8_t* orig, const uint8_t* next
     RELAX_REQUIRE(h, pair_stride >= (int64_t)H * W * 3 || T == 1, "relax_optical_flow: pair stride smaller than a frame");
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // bound the workspace: 152 B per pixel per pair; keep chunks under ~6 GB
+    // bound the workspace: 108 B per pixel per pair; chunks of up to RELAX_FLOW_WS_GB (default 32) GB - 288 GB of HBM make
+    // large chunks cheap, and more pairs per launch fill the chip better at the coarse pyramid levels
     const int64_t HW = (int64_t)H * W;
-    int chunk = (int)((6ll << 30) / (HW * 160));
+    int64_t ws_gb = 32;
+    if (const char* e = getenv("RELAX_FLOW_WS_GB")) ws_gb = atoll(e) > 0 ? atoll(e) : ws_gb;
+    int chunk = (int)((ws_gb << 30) / (HW * 112));
     if (chunk < 1) chunk = 1;
     if (chunk > T) chunk = T;
     for (int t0 = 0; t0 < T; t0 += chunk) {
