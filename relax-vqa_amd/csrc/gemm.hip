@@ -682,7 +682,7 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
         case 1: rc = RELAX_DISPATCH(128, 128, 2, 2, 32, 1, 2); break;   // 4 waves, 64x64 per wave
         case 4: rc = RELAX_DISPATCH(256, 128, 4, 2, 32, 1, 1); break;   // 8 waves, 64x64 per wave, 1 workgroup / CU
         case 5: rc = RELAX_DISPATCH(128, 64, 2, 2, 32, 1, 2); break;   // 4 waves, 64x32 per wave
-        case 7: rc = RELAX_DISPATCH(128, 128, 2, 2, 16, 1, 3); break;   // BK 16: 36.9 KB LDS -> 3 workgroups / CU
+        case 7: rc = RELAX_DISPATCH(128, 128, 2, 2, 16, 1, 3); break;   // BK 16: 40 KB LDS, 101 + 64 registers -> 3 workgroups / CU
         case 10: rc = RELAX_DISPATCH(128, 64, 2, 2, 16, 1, 4); break;   // N = 64 layers, BK 16   // 4 waves, 32x32 per wave
         default:
             set_error(h, "conv/gemm: unknown tile variant %d", variant);
