@@ -86,6 +86,7 @@ static_assert(KPAD * 16 % ATT_THREADS == 0, "K/V staging must divide evenly over
 
 typedef float att_f32x4 __attribute__((ext_vector_type(4)));
 
+template <bool STAMPS>   // STAMPS: diagnostic instantiation (per-wave phase shares); the product kernel carries none of it
 __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  int heads, int total_items, int ablate,
                                                                  unsigned long long* __restrict__ stamps) {
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
 #define ATT_STAMP(i_)                                                  \
-    if (stamps) {                                                      \
+    if (STAMPS) {                                                      \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
         seg[i_] += t_ - t_prev;                                        \
         t_prev = t_;                                                   \
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
     ATT_LOAD_Q(item);
     ATT_STORE_KV();
     __syncthreads();
-    if (stamps) t_prev = __builtin_amdgcn_s_memtime();
+    if (STAMPS) t_prev = __builtin_amdgcn_s_memtime();
 
     while (true) {
         ATT_LOAD_KV(item, 2 * dim);   // V of this item: in flight during the score phase
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
             for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
             const float* kp = KV + (kt * 32 + li) * KV_LD + 4 * half;
 #pragma unroll
-            for (int q8 = 0; q8 < ((ablate & 32) ? 1 : 8); ++q8) {
+            for (int q8 = 0; q8 < ((STAMPS && (ablate & 32)) ? 1 : 8); ++q8) {
                 const att_f32x4 kf = *reinterpret_cast<const att_f32x4*>(kp + 8 * q8);
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[q8].x, sacc[kt], 0, 0, 0);
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[q8].y, sacc[kt], 0, 0, 0);
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
 #pragma unroll
-        for (int kt = 0; kt < ((ablate & 16) ? 1 : KTILES); ++kt)
+        for (int kt = 0; kt < ((STAMPS && (ablate & 16)) ? 1 : KTILES); ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
         item = next;
         ATT_STAMP(5);   // Q loads + barrier + K store + barrier
     }
-    if (stamps && lane == 0) {
+    if (STAMPS && lane == 0) {
         for (int i = 0; i < 6; ++i) stamps[((size_t)blockIdx.x * KTILES + wave) * 6 + i] = seg[i];
     }
 #undef ATT_STAMP
@@ -238,7 +239,9 @@ int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, in
     RELAX_REQUIRE(h, Nimg > 0 && heads > 0, "attention: Nimg=%d heads=%d", Nimg, heads);
     static bool attr_set = false;
     if (!attr_set) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_197x64),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_197x64<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_LDS));
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_197x64<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_LDS));
         attr_set = true;
     }
@@ -250,8 +253,11 @@ int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, in
         RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * (size_t)grid * KTILES * 6));
         stamps = static_cast<unsigned long long*>(h->scratch.p);
     }
-    hipLaunchKernelGGL(attention_197x64, dim3(grid), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, total,
-                       h->gemm.ablate & 56, stamps);
+    if (stamps)
+        hipLaunchKernelGGL(attention_197x64<true>, dim3(grid), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, total,
+                           h->gemm.ablate & 56, stamps);
+    else
+        hipLaunchKernelGGL(attention_197x64<false>, dim3(grid), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, total, 0, stamps);
     RELAX_HIP_CHECK(h, hipGetLastError());
     if (stamps) {
         RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
