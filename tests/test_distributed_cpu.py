@@ -29,7 +29,7 @@ def _worker(rank, world, port, n_clips, q):
     from relax_vqa_amd import distributed as rd2
     r, w, _ = rd2.init_from_env(backend="gloo")
     out = rd2.extract_dataset(_fake_clip_vector, n_clips, r, w)
-    q.put((rank, out))
+    q.put((rank, out.numpy().copy()))   # by value: a shared-memory tensor would die with this process before the parent reads it
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -43,13 +43,13 @@ def test_two_rank_gather_equals_single_rank(n_clips):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=120) for _ in range(world))
+    results = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     want = torch.stack([_fake_clip_vector(i) for i in range(n_clips)])
     for r in range(world):
-        assert torch.equal(results[r], want), "sharding changed values or order"   # bit-for-bit
+        assert torch.equal(torch.from_numpy(results[r]), want), "sharding changed values or order"   # bit-for-bit
 
 
 def test_shards_partition_all_clips():
