@@ -49,6 +49,17 @@ def test_flow_matches_oracle():
     assert (img2 == want_img).mean() > 0.999      # hue / value truncation boundaries under FMA contraction
 
 
+@pytest.mark.parametrize("h,w", [(540, 960), (1080, 1920)])
+def test_flow_matches_oracle_at_video_sizes(h, w):
+    """Many column bands and row segments of the fused kernels, 16-byte paths, all four pyramid levels: the flow itself
+    (not only its visualisation) against the oracle at the sizes of BASELINE configs 3 and 4."""
+    a, b = _smooth_pair(h, w, 3)
+    flow, _ = engine().optical_flow(torch.from_numpy(np.stack([a, b])[None]).cuda(), want_flow=True, want_image=False)
+    want = flow_ref.farneback(flow_ref.bgr2gray(a), flow_ref.bgr2gray(b))
+    err = np.abs(flow[0].cpu().numpy() - want)
+    assert err.max() < 2e-3 and err.mean() < 1e-5, (err.max(), err.mean())
+
+
 @pytest.mark.parametrize("h,w", [(97, 131), (150, 203), (136, 240)])
 def test_flow_odd_sizes_take_the_general_kernels(h, w):
     """Row lengths that are not a multiple of 4 (and odd pixel counts) cannot use the 16-byte-load kernels: same tolerance."""
