@@ -197,3 +197,23 @@ def test_step_is_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_headline_batch_equals_clip_by_clip_at_full_size():
+    """The bench workload itself (BASELINE config 3: 1080p, 32 pairs, 8 clips per pass = 512 fragments through both
+    backbones): with the tail split off, the batched pass gives every clip the bits it gets alone, and two runs agree."""
+    rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    clips = [torch.from_numpy(synth.synthetic_clip(32, 1080, 1920, clip_id=300 + i, distinct=2)).cuda() for i in range(8)]
+    eng.set_option("gemm_split_k", 0)
+    try:
+        both = eng.clip_vectors(clips)
+        again = eng.clip_vectors(clips)
+        assert both.shape == (8, 15171 + 4608) and bool(torch.isfinite(both).all())
+        assert torch.equal(both, again), "not deterministic"
+        for i in (0, 5):
+            assert torch.equal(eng.clip_vectors([clips[i]])[0], both[i]), f"clip {i} depends on its batch"
+    finally:
+        eng.set_option("gemm_split_k", 1)
+    split = eng.clip_vectors(clips)     # default (tail split on): same to fp32 rounding
+    assert_close(split, both.cpu().numpy(), "tail split-K on vs off", rtol=1e-5, atol_frac=1e-5)
