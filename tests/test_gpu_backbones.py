@@ -217,3 +217,20 @@ def test_headline_batch_equals_clip_by_clip_at_full_size():
         eng.set_option("gemm_split_k", 1)
     split = eng.clip_vectors(clips)     # default (tail split on): same to fp32 rounding
     assert_close(split, both.cpu().numpy(), "tail split-K on vs off", rtol=1e-5, atol_frac=1e-5)
+
+
+def test_bf16x3_at_the_headline_batch_uses_the_large_tiles_and_holds_the_bar():
+    """8 clips x 64 fragments: the ViT GEMMs have >= 256 tiles of 256x256, so the opt-in precision runs its 8-wave kernel;
+    clip vectors against the exact-fp32 path of the same engine."""
+    rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    clips = [torch.from_numpy(synth.synthetic_clip(32, 1080, 1920, clip_id=320 + i, distinct=2)).cuda() for i in range(8)]
+    exact = eng.clip_vectors(clips).cpu().numpy()
+    eng.set_precision("bf16x3")
+    try:
+        fast = eng.clip_vectors(clips).cpu().numpy()
+    finally:
+        eng.set_precision("fp32")
+    rel = np.linalg.norm(fast - exact) / np.linalg.norm(exact)
+    assert rel < 5e-5, rel
+    assert_close(fast, exact, "bf16x3 clip vectors vs fp32")
