@@ -219,3 +219,25 @@ def test_full_35203_vector_every_block_against_the_oracle(api):
     names = ["whole-frame RN50 LS", "whole-frame ViT", "fragment RN50 LS", "residual RN50 pool", "ViT original frag", "ViT residual frag"]
     for a, b, nm in zip(edges[:-1], edges[1:], names):
         assert_close(vec[a:b], want[a:b], f"full vector block: {nm}")
+
+
+def test_integration_md_ctypes_stub_runs_as_written(api):
+    """INTEGRATION.md section 3 shows the binding a reference maintainer would add; run that very text (only the library path is
+    made absolute) and compare with the engine."""
+    import re
+    import torch
+    from relax_vqa_amd import _lib, runtime
+    m, rn, vit = api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"## 3\. Option B.*?```python\n(.*?)```", text, re.S).group(1)
+    code = code.replace('C.CDLL("librelax_hip.so")', f'C.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    ns["load_resnet50"]({k: torch.from_numpy(np.asarray(v)) for k, v in rn.items()})
+    frames = torch.from_numpy(synth.synthetic_clip(2, 240, 320, clip_id=44)).cuda()
+    feats, pos = ns["fragment_and_features"](frames)
+    torch.cuda.synchronize()
+    want = runtime.get_engine().extract_clip(frames, vit=False)
+    assert torch.equal(pos, want["positions"])
+    assert_close(feats, want["resnet"].cpu().numpy(), "INTEGRATION.md stub vs engine", rtol=1e-5, atol_frac=1e-5)   # batch compositions differ
