@@ -2,7 +2,8 @@
 """Headline benchmark: clips/sec of ReLaX-VQA feature extraction (BASELINE.json).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU)
+  (N > 1: one rank per GPU under torch.distributed.run; run plainly, bench.py starts that launcher itself as a
+   child process before anything touches a GPU; a WORLD_SIZE that disagrees with --gpus is an error)
 
 One step = one pass of the hot path over one clip per rank, frames already resident in HBM:
   workload "config3": synthetic 1080p, 32 (frame, next) pairs ->
@@ -113,6 +114,49 @@ def hbm_traffic_per_launch(workload, clips_per_step):
     return None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run` (one rank per GPU) as a
+    CHILD process, relay its output and return its exit code.  Called before any GPU call of this process (a process
+    that has initialised the GPU must never exec another program on this pool; a child is fine either way)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print(f"bench.py: --gpus {n_ranks} without WORLD_SIZE: launching {n_ranks} ranks: {' '.join(cmd)}", file=sys.stderr)
+    proc = subprocess.run(cmd, env=env)   # stdout / stderr are inherited: the JSON line of rank 0 goes straight through
+    return proc.returncode
+
+
+def launch_check(rank, world):
+    """--launch-check: the multi-rank control flow of this file without an engine (CPU test of the launcher): rendezvous,
+    barrier, the feature all-gather on stand-in per-clip vectors, the max-over-ranks timing reduction, one JSON line."""
+    dev = "cuda" if torch.cuda.is_available() and dist.is_initialized() and dist.get_backend() != "gloo" else "cpu"
+    local = torch.full((2, 5), float(rank), device=dev)
+    t0 = time.perf_counter()
+    out = rdist.gather_clip_vectors(local, world * 2, rank, world) if world > 1 else local
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = rdist.all_reduce_max(elapsed, dev)
+    want = torch.arange(world, dtype=torch.float32).repeat_interleave(2)[:, None].expand(-1, 5)
+    assert torch.equal(out.cpu(), want), "all-gather returned rows out of clip order"
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": world,
+                          "backend": dist.get_backend() if world > 1 else None, "pids_distinct": True}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,16 +167,30 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=16)
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 measurement")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra pinned-host-to-device measurement")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6"],
                     help="arithmetic of the contraction kernel for the headline loop (default: exact fp32 MFMA; bf16x3 = opt-in split products)")
     ap.add_argument("--clips-per-step", type=int, default=8,
                     help="clips each rank pushes through the engine per step (one batched pass: B*2*T fragments)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only rehearse the N-rank launch + collectives (no engine, no GPU needed): tests/test_bench_launch.py")
     args = ap.parse_args()
 
+    # ---- launcher: nothing above or in this block touches a GPU -------------------------------------------------
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a {env_world}-rank number "
+              f"under an --gpus {args.gpus} command line", file=sys.stderr)
+        sys.exit(2)
+
     rank, world, local_rank = rdist.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    assert world == args.gpus
+    if args.launch_check:
+        launch_check(rank, world)
+        return
     H, W, T, use_vit = WORKLOADS[args.workload]
 
     torch.cuda.set_device(local_rank)
@@ -145,8 +203,8 @@ def main():
     B = args.clips_per_step
     eng.reserve(2 * T * B)
     x3 = args.precision == "bf16x3"
-    if x3:
-        eng.set_precision("bf16x3")
+    eng.set_precision(args.precision)
+    assert eng.precision() == args.precision
 
     # two distinct resident clips per rank, alternated (inputs are in HBM before the timed region starts)
     n_resident = 2
@@ -237,7 +295,7 @@ def main():
         result = {
             "metric": "clips/sec (32 sampled frames, 1080p) feature extraction" if args.workload == "config3"
                       else f"clips/sec feature extraction ({args.workload})",
-            "value": clips_total / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "value": clips_total / elapsed, "unit": "clips/s", "n_gpus": world, "rccl_ranks": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3 (fp32 operands split into two bf16 terms, fp32 accumulate)" if x3 else "f32",
             "data": "synthetic",

@@ -65,7 +65,10 @@ const char* relax_last_error(const relax_handle* h);
  * backbone entry points; call it up front to keep allocation out of timed code. */
 int relax_reserve(relax_handle* h, int max_images);
 
-/* Integer options.  "gemm_precision" (default 0): 0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 1 = "bf16x3":
+/* Integer options.  "gemm_precision": 0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 2 = "bf16x6" (fp32-grade):
+ * every fp32 operand is held as three bf16 numbers hi + mid + lo (exact) and a*b = the six partial products of weight
+ * >= 2^-16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - as close to the exact sum as the fp32 FMA chain
+ * (csrc/gemm_x6.hip, tests/test_gpu_x6.py); used by the ViT / ResNet drivers and by relax_op_gemm; 1 = "bf16x3":
  * every fp32 operand is split on the fly into bf16 hi + lo and a*b = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
  * with fp32 accumulation (about 2^-16 relative error per product; measured features within ~1e-5 of the fp32 path).
  * "gemm_split_k" (default 1): cut the tail tiles of a contraction along K so the last round fills
@@ -74,6 +77,8 @@ int relax_reserve(relax_handle* h, int max_images);
  * "gemm_variant", "gemm_variant_n64", "gemm_group_m", "gemm_prio": tuning knobs (tile variants are listed in csrc/gemm.hip;
  * none of them changes results beyond fp32 rounding). */
 int relax_set_option(relax_handle* h, const char* key, int value);
+/* Reads an option back (bench.py reports the arithmetic the ENGINE is in, not the one its command line asked for). */
+int relax_get_option(relax_handle* h, const char* key, int* value);
 
 /* ---- weights ------------------------------------------------------------------------------- */
 /* Replaces `models.resnet50(pretrained=True)` (src/extractor/visualise_resnet.py:21,

@@ -20,6 +20,7 @@ PROTOTYPES = {
     "relax_last_error": (C.c_char_p, [c_vp]),
     "relax_reserve": (C.c_int, [c_vp, C.c_int]),
     "relax_set_option": (C.c_int, [c_vp, C.c_char_p, C.c_int]),
+    "relax_get_option": (C.c_int, [c_vp, C.c_char_p, C.POINTER(C.c_int)]),
     "relax_load_resnet50": (C.c_int, [c_vp, C.POINTER(c_vp), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int]),
     "relax_load_vit": (C.c_int, [c_vp, C.POINTER(c_vp), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int,
                                  C.c_int, C.c_int, C.c_int]),

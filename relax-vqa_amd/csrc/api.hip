@@ -77,6 +77,14 @@ int prof_end(relax_handle* h, hipStream_t s, int span_idx) {
     return RELAX_OK;
 }
 
+void prof_abort(relax_handle* h, int span_idx) {
+    Profiler& p = h->prof;
+    if (span_idx < 0 || span_idx != static_cast<int>(p.spans.size()) - 1) return;
+    p.pool.push_back(p.spans.back().start);
+    p.pool.push_back(p.spans.back().stop);
+    p.spans.pop_back();
+}
+
 static int prof_drain(relax_handle* h) {
     Profiler& p = h->prof;
     for (ProfSpan& sp : p.spans) {
@@ -114,7 +122,7 @@ int relax_create(int device, relax_handle** out) {
         set_error(nullptr, "relax_create: no HIP device (%s)", hipGetErrorString(e));
         return RELAX_ERR_HIP;
     }
-    if (device < 0 || device >= count) {
+    if (device < 0 || device >= count || device >= kMaxDevices) {
         set_error(nullptr, "relax_create: device %d out of range (have %d)", device, count);
         return RELAX_ERR_INVALID;
     }
@@ -137,12 +145,12 @@ int relax_create(int device, relax_handle** out) {
     relax_handle* h = new relax_handle();
     h->device = device;
     if (const char* e = getenv("RELAX_GEMM_SPLIT")) h->gemm.split_k = atoi(e);
-    if (const char* e = getenv("RELAX_GEMM_PRECISION")) h->gemm.precision = atoi(e) == 1 ? 1 : 0;
+    if (const char* e = getenv("RELAX_GEMM_PRECISION")) h->gemm.precision = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;
     if (const char* e = getenv("RELAX_GEMM_VARIANT")) h->gemm.variant = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_VARIANT_N64")) h->gemm.variant_n64 = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_GROUP_M")) h->gemm.group_m = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = getenv("RELAX_GEMM_PRIO")) h->gemm.prio = atoi(e);
-    if (const char* e = getenv("RELAX_GEMM_ABLATE")) h->gemm.ablate = atoi(e);
+    if (const char* e = getenv("RELAX_GEMM_STAGGER")) h->gemm.stagger = atoi(e) > 0 ? atoi(e) : 0;
     *out = h;
     return RELAX_OK;
 }
@@ -160,6 +168,7 @@ int relax_destroy(relax_handle* h) {
     if (h->arena.p) (void)hipFree(h->arena.p);
     if (h->scratch.p) (void)hipFree(h->scratch.p);
     if (h->splitk_ws.p) (void)hipFree(h->splitk_ws.p);
+    if (h->sp3_ws.p) (void)hipFree(h->sp3_ws.p);
     for (auto& sp : h->prof.spans) {
         (void)hipEventDestroy(sp.start);
         (void)hipEventDestroy(sp.stop);
@@ -192,13 +201,35 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     RELAX_REQUIRE(h, key, "relax_set_option: key is NULL");
     const std::string k(key);
     if (k == "gemm_split_k") h->gemm.split_k = value;
-    else if (k == "gemm_precision") h->gemm.precision = value == 1 ? 1 : 0;
+    else if (k == "gemm_precision") {
+        RELAX_REQUIRE(h, value >= 0 && value <= 2, "relax_set_option: gemm_precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16x6)");
+        h->gemm.precision = value;
+    }
     else if (k == "gemm_variant") h->gemm.variant = value;
     else if (k == "gemm_variant_n64") h->gemm.variant_n64 = value;
     else if (k == "gemm_group_m") h->gemm.group_m = value > 0 ? value : 1;
     else if (k == "gemm_prio") h->gemm.prio = value;
+    else if (k == "gemm_stagger") h->gemm.stagger = value > 0 ? value : 0;
     else {
         set_error(h, "relax_set_option: unknown option '%s'", key);
+        return RELAX_ERR_INVALID;
+    }
+    return RELAX_OK;
+}
+
+int relax_get_option(relax_handle* h, const char* key, int* value) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, key && value, "relax_get_option: NULL argument");
+    const std::string k(key);
+    if (k == "gemm_split_k") *value = h->gemm.split_k;
+    else if (k == "gemm_precision") *value = h->gemm.precision;
+    else if (k == "gemm_variant") *value = h->gemm.variant;
+    else if (k == "gemm_variant_n64") *value = h->gemm.variant_n64;
+    else if (k == "gemm_group_m") *value = h->gemm.group_m;
+    else if (k == "gemm_prio") *value = h->gemm.prio;
+    else if (k == "gemm_stagger") *value = h->gemm.stagger;
+    else {
+        set_error(h, "relax_get_option: unknown option '%s'", key);
         return RELAX_ERR_INVALID;
     }
     return RELAX_OK;

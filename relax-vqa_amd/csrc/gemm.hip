@@ -17,6 +17,9 @@
 // opt-in bf16x3 precision: 256x256 tile on 8 waves for large plain GEMMs, 128-wide tiles otherwise.
 #include "relax_internal.h"
 
+#ifndef RELAX_F32_ABLATE
+#define RELAX_F32_ABLATE 0  // build-time timing experiments on the fp32 loop (WRONG results): 1 no barrier, 2 no global loads,
+#endif                      // 4 no LDS stores.  Never set in the product build (tools/build_ablations.sh f32:<n>)
 #ifndef RELAX_X3_ABLATE
 #define RELAX_X3_ABLATE 0   // build-time timing experiments on the bf16x3 loop (WRONG results): 1 no barrier, 2 no global loads,
 #endif                      // 4 no LDS stores, 8 no split, 16 half the fragment reads (tools/build_ablations.sh)
@@ -49,7 +52,6 @@ struct GemmParams {
     int full_tiles;  // tiles [0, full_tiles) run the whole K loop and the epilogue in-kernel
     int nsplit;      // tiles [full_tiles, ntiles) are cut into nsplit K slices (raw partial sums)
     int prio;        // experiment knob: raise wave priority around the MFMA cluster
-    int ablate;      // timing-only experiment knob (wrong results): 1 no barrier, 2 no global loads, 4 no LDS stores
     unsigned long long* stamps;   // RELAX_GEMM_STAMPS builds only: per-workgroup phase timestamps
 };
 
@@ -210,14 +212,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
             uint2* B8_ = reinterpret_cast<uint2*>(Bs_);                                                 \
             _Pragma("unroll") for (int i = 0; i < A_LOADS; ++i) {                                     \
                 uint2 hi_, lo_;                                                                       \
-                if (p.ablate & 8) { hi_.x = __float_as_uint(ra[i].x); hi_.y = __float_as_uint(ra[i].y); lo_.x = __float_as_uint(ra[i].z); lo_.y = __float_as_uint(ra[i].w); } else \
                 split_bf16x4(ra[i], &hi_, &lo_);                                                      \
                 A8_[(i * PASS + lrow) * (LDK / 2) + c4] = hi_;                                               \
                 A8_[(i * PASS + lrow) * (LDK / 2) + BK / 4 + c4] = lo_;                                           \
             }                                                                                         \
             _Pragma("unroll") for (int i = 0; i < B_LOADS; ++i) {                                     \
                 uint2 hi_, lo_;                                                                       \
-                if (p.ablate & 16) { hi_.x = __float_as_uint(rb[i].x); hi_.y = __float_as_uint(rb[i].y); lo_.x = __float_as_uint(rb[i].z); lo_.y = __float_as_uint(rb[i].w); } else \
                 split_bf16x4(rb[i], &hi_, &lo_);                                                      \
                 B8_[(i * PASS + lrow) * (LDK / 2) + c4] = hi_;                                               \
                 B8_[(i * PASS + lrow) * (LDK / 2) + BK / 4 + c4] = lo_;                                           \
@@ -354,10 +354,10 @@ _Pragma("unroll")  \
         RELAX_STAMP(1);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int cur = (kt - kt_begin) & 1;
-            if (kt + 1 < kt_end && !(p.ablate & 2)) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
+            if (kt + 1 < kt_end && !(RELAX_F32_ABLATE & 2)) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
             RELAX_COMPUTE(cur);
-            if (kt + 1 < kt_end && !(p.ablate & 4)) RELAX_STORE_TILE(cur ^ 1);
-            if (!(p.ablate & 1)) __syncthreads();
+            if (kt + 1 < kt_end && !(RELAX_F32_ABLATE & 4)) RELAX_STORE_TILE(cur ^ 1);
+            if (!(RELAX_F32_ABLATE & 1)) __syncthreads();
         }
     } else {
         // bf16x3: a K step is only 24 MFMAs (768 cycles) per wave, too short to cover a global load, so the register
@@ -545,7 +545,6 @@ static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hip
     p.ntiles = p.tiles_m * p.tiles_n;
     p.group_m = h->gemm.group_m;
     p.prio = h->gemm.prio;
-    p.ablate = h->gemm.ablate;
     p.full_tiles = p.ntiles;
     p.nsplit = 1;
     p.partial = nullptr;
@@ -576,11 +575,11 @@ static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hip
         }
     }
     constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * (BK + 4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[kMaxDevices] = {};   // per (kernel instantiation, device): the attribute lives on the device's code object
+    if (!attr_set[h->device]) {
         RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f32<BM, BN, WM, WN, BK, OCC, TAPS, PREC>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[h->device] = true;
     }
     const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
 #ifdef RELAX_GEMM_STAMPS
@@ -674,7 +673,7 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
         const bool big = !taps && p.N % 256 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 256) >= 256 && h->gemm.variant != 1;
         if (big) rc = launch_variant<256, 256, 2, 4, 32, 1, false, 1>(h, p, 1, s);
         else rc = (p.N % 128 == 0) ? RELAX_DISPATCH_X3(128, 128, 2, 2, 2, 2) : RELAX_DISPATCH_X3(128, 64, 2, 2, 2, 2);
-        RELAX_TRY(rc);
+        if (rc != RELAX_OK) { prof_abort(h, span); return rc; }
         RELAX_TRY(prof_end(h, s, span));
         return RELAX_OK;
     }
@@ -686,9 +685,9 @@ int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s) {
         case 10: rc = RELAX_DISPATCH(128, 64, 2, 2, 16, 1, 4); break;   // N = 64 layers, BK 16   // 4 waves, 32x32 per wave
         default:
             set_error(h, "conv/gemm: unknown tile variant %d", variant);
-            return RELAX_ERR_INVALID;
+            rc = RELAX_ERR_INVALID;
     }
-    RELAX_TRY(rc);
+    if (rc != RELAX_OK) { prof_abort(h, span); return rc; }   // no half-recorded span is left behind for relax_profile_read
     RELAX_TRY(prof_end(h, s, span));
     return RELAX_OK;
 }
@@ -707,7 +706,20 @@ int relax_op_gemm(relax_handle* h, const float* A, const float* W, const float* 
     RELAX_REQUIRE(h, A && W && out, "relax_op_gemm: NULL operand");
     RELAX_REQUIRE(h, act >= 0 && act <= 2, "relax_op_gemm: act=%d", act);
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
-    return launch_gemm(h, A, W, bias, residual, out, M, N, K, act, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->gemm.precision == 2) {
+        // operator-level entry under "bf16x6": both operands are converted to split planes here (the model drivers
+        // keep weights and activations in that format instead)
+        RELAX_REQUIRE(h, K % 16 == 0, "relax_op_gemm (bf16x6): K=%d must be a multiple of 16", K);
+        const size_t a_bytes = (size_t)M * K * 6, w_bytes = (size_t)N * K * 6;
+        RELAX_TRY(ensure_buf(h, h->sp3_ws, a_bytes + w_bytes + 256));
+        char* As = static_cast<char*>(h->sp3_ws.p);
+        char* Ws = As + ((a_bytes + 255) & ~(size_t)255);
+        RELAX_TRY(launch_to_sp3(h, A, K, As, M, K, s));
+        RELAX_TRY(launch_to_sp3(h, W, K, Ws, N, K, s));
+        return launch_gemm_x6(h, As, Ws, bias, residual, out, nullptr, M, N, K, act, s);
+    }
+    return launch_gemm(h, A, W, bias, residual, out, M, N, K, act, s);
 }
 
 int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const float* bias, const float* residual,

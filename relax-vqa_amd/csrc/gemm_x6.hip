@@ -1,0 +1,661 @@
+// "bf16x6": the fp32-grade contraction kernel on the bf16 matrix cores of gfx950.
+//
+//   out[m, n] = act( sum_k A[m, k] * W[n, k] + bias[n] + residual[m, n] )          (same contract as gemm.hip)
+//
+// Every fp32 operand x is held as THREE bf16 numbers x = hi + mid + lo (each a round-to-nearest of what is left:
+// 3 x 8 = 24 significant bits, the split is exact), and a*b is evaluated with the six partial products whose weight is
+// at least 2^-16 of the full product,
+//        a*b ~= al*bh + am*bm + ah*bl + am*bh + ah*bm + ah*bh          (dropped: am*bl, al*bm ~2^-24, al*bl ~2^-32)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: the error per product is of the size of one fp32 rounding, and
+// the accumulator is rounded once per 16-deep MFMA instead of once per product, so the result is as close to the
+// exact sum as the fp32 FMA chain of gemm.hip (measured, tests/test_gpu_x6.py) at 6/16 of its matrix-pipe cycles.
+//
+// Operand format "sp3" (split planes): a row of K fp32 values is stored as K/16 chunks of 96 bytes,
+//        chunk = [16 x bf16 hi][16 x bf16 mid][16 x bf16 lo]
+// so one 16-deep K step of one row is 96 contiguous bytes whose 16-byte units are exactly the MFMA fragments
+// (lane (r, h) of a 32x32x16 MFMA holds k = 8h .. 8h+7 of row r).  The split happens ONCE where a value is produced
+// (weights at load time, activations in the producing kernel's epilogue / LayerNorm / im2sp3), never in the K loop:
+// the loop has no VALU work, and tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4) without touching registers.
+//
+// Structure: 256x256 tile on 8 waves (128x64 per wave, 8 accumulators of 32x32), BK = 16, THREE LDS stages of
+// 512 rows x 96 B (144 KB), one barrier per K step, the DMA of step k+2 issued right after the barrier of step k
+// (counted s_waitcnt vmcnt: loads stay in flight across barriers).  LDS rows are 96 B; the two 16-byte halves of a
+// plane are swapped in rows with bit 3 set, which makes the ds_read_b128 fragment reads bank-conflict free (the
+// permutation is applied on the SOURCE address of the DMA, the LDS image stays linear).  Rows beyond M and padding
+// taps of an implicit-GEMM convolution read from a page of zeros.
+#include "relax_internal.h"
+
+#ifdef RELAX_X6_STAMPS   // diagnostic build (tools/build_ablations.sh x6stamps): thread 0 of every workgroup records cycle stamps
+#define X6_STAMP(i_) if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime()
+#else
+#define X6_STAMP(i_)
+#endif
+#ifndef RELAX_X6_ABLATE
+#define RELAX_X6_ABLATE 0   // build-time timing experiments (WRONG results): 1 no DMA in the K loop, 2 every DMA re-reads K step 0 (L2 hits)
+#endif
+
+namespace relax {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kChunkBytes = 96;   // one 16-deep K step of one row
+
+// ---- the split -------------------------------------------------------------------------------------------------------
+// (x, y) -> packed bf16 pairs hi, mid, lo with x = hi + mid + lo exactly (round to nearest at every step)
+__device__ inline void split3_pair(float x, float y, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x, y}, bf16x2));
+    const float rx = x - __uint_as_float(hi << 16), ry = y - __uint_as_float(hi & 0xffff0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){rx, ry}, bf16x2));
+    const float sx = rx - __uint_as_float(mid << 16), sy = ry - __uint_as_float(mid & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){sx, sy}, bf16x2));
+}
+
+// 8 consecutive values (half a chunk) -> the three 16-byte units of its planes
+__device__ inline void split3_x8(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
+    unsigned h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+    split3_pair(a.x, a.y, h0, m0, l0);
+    split3_pair(a.z, a.w, h1, m1, l1);
+    split3_pair(b.x, b.y, h2, m2, l2);
+    split3_pair(b.z, b.w, h3, m3, l3);
+    hi = (u32x4){h0, h1, h2, h3};
+    mid = (u32x4){m0, m1, m2, m3};
+    lo = (u32x4){l0, l1, l2, l3};
+}
+
+// byte offset of the 8 values k .. k+7 (k % 8 == 0) of plane 0 inside an sp3 row
+__device__ __host__ inline int64_t sp3_offset(int k) { return (int64_t)(k >> 4) * kChunkBytes + (k & 8) * 2; }
+
+__device__ inline void store_sp3_x8(char* row, int k, const f32x4 a, const f32x4 b) {
+    u32x4 hi, mid, lo;
+    split3_x8(a, b, hi, mid, lo);
+    char* d = row + sp3_offset(k);
+    *reinterpret_cast<u32x4*>(d) = hi;
+    *reinterpret_cast<u32x4*>(d + 32) = mid;
+    *reinterpret_cast<u32x4*>(d + 64) = lo;
+}
+
+// fp32 [rows][K] (row stride ld floats) -> sp3 [rows][K*6 bytes]; one thread per 8 values
+__global__ __launch_bounds__(256) void to_sp3_kernel(const float* __restrict__ x, int64_t ld, char* __restrict__ y, int K,
+                                                     int64_t total8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int k8 = K >> 3;
+    const int64_t row = i / k8;
+    const int k = (int)(i - row * k8) * 8;
+    const float* s = x + row * ld + k;
+    store_sp3_x8(y + row * (int64_t)K * 6, k, *reinterpret_cast<const f32x4*>(s), *reinterpret_cast<const f32x4*>(s + 4));
+}
+
+int launch_to_sp3(relax_handle* h, const float* x, int64_t ld, void* y, int64_t rows, int K, hipStream_t s) {
+    RELAX_REQUIRE(h, K % 16 == 0 && ld % 4 == 0 && rows > 0, "to_sp3: K=%d must be a multiple of 16 (ld %lld)", K, (long long)ld);
+    const int64_t total8 = rows * (K / 8);
+    hipLaunchKernelGGL(to_sp3_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, x, ld, static_cast<char*>(y), K,
+                       total8);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------------------------
+struct X6Params {
+    const char* a;        // sp3 activations: [M][K*6 B] (plain) or NHWC pixels [Nimg*H*W][Cin*6 B] (implicit GEMM)
+    const char* w;        // sp3 weights [N][K*6 B], k = (dy*KW+dx)*Cin + c
+    const float* bias;
+    const float* residual;   // fp32 [M][N] or null
+    float* out;              // fp32 [M][N] or null
+    char* out_sp3;           // sp3 [M][N*6 B] or null
+    float* partial;          // split-K partial tiles
+    int M, N, K;
+    int H, W, Cin, Ho, Wo, KW, stride, pad;
+    int act;
+    int tiles_m, tiles_n, ntiles, group_m;
+    int full_tiles, nsplit;
+    int stagger;                  // cycles of one tile: XCD x delays its first round by x/8 of it (0 = off)
+    int first_round;              // workgroups resident at launch (256 CUs x workgroups per CU)
+    unsigned long long* stamps;   // RELAX_X6_STAMPS builds only
+};
+
+__device__ inline int xcd_remap6(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+__device__ inline float act_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// global -> LDS without registers: 16 bytes per lane to LDS address M0 + 16 * lane; the source is base(rsrc) + voff + soff,
+// and a lane whose voff is beyond the resource's byte count gets zeros (rows past M, padding taps)
+#define X6_DMA(rsrc_, lds_off_, voff_, soff_)                                                                             \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_, (__attribute__((address_space(3))) void*)(smem + (lds_off_)), 16,     \
+                                             voff_, soff_, 0, 0)
+constexpr unsigned kOutOfRange = 0x80000000u;   // > every num_records below: the DMA writes zeros for that lane
+constexpr int64_t kMaxRecords = 0x7ffffff0;
+
+// Tile BM x BN on 4 waves (2 x 2), TWO workgroups per CU (the epilogue / prologue of one runs under the MFMAs of the other),
+// BK = 16, two LDS stages.  The fragment reads are software-pipelined one half-step ahead of the MFMAs that use them:
+//   step k:  [ M0(k): MFMAs on Y-half 0 ]  while reading Y-half 1 of stage k
+//            wait own DMA of step k+1, barrier          (stage k is now fully in registers -> free; stage k+1 has landed)
+//            issue the DMA of step k+2 into stage k,  read X and Y-half 0 of stage k+1
+//            [ M1(k): MFMAs on Y-half 1 ]
+// X = the operand with fewer fragments per wave (double-buffered in registers), Y = the other one (two halves).
+template <int BM, int BN, int WM, int WN, bool TAPS>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8
+#if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (it has no __amdgpu_buffer_rsrc_t and emits no stub for a body that names it)
+    constexpr int NW = WM * WN;
+    constexpr int NT = NW * 64;
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr bool SPLIT_B = TN >= TM;
+    constexpr int XT = SPLIT_B ? TM : TN;
+    constexpr int YT = SPLIT_B ? TN : TM;
+    constexpr int YH = YT / 2;
+    constexpr int ROWS = BM + BN;
+    constexpr int STAGE = ROWS * kChunkBytes;
+    constexpr int NSTAGE = 2;
+    constexpr int PIECES = ROWS * 6 / 64;         // 1 KiB DMA pieces per stage
+    constexpr int A_PIECES = BM * 6 / 64;
+    constexpr int PPW = (PIECES + NW - 1) / NW;   // pieces per wave (a wave short of real pieces issues dummy ones)
+    constexpr int A_PPW = A_PIECES / NW;
+    constexpr int DUMMY = NSTAGE * STAGE;         // 1 KiB nobody reads
+    static_assert(ROWS % 32 == 0 && TM >= 1 && TN >= 1 && YT % 2 == 0 && A_PIECES % NW == 0, "tile / wave layout mismatch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // work unit -> (tile, K slice)
+    int tile, kt_begin, kt_end, slice = -1, split_tile = 0;
+    {
+        const int nk_all = p.K >> 4;
+        if ((int)blockIdx.x < p.full_tiles) {
+            tile = xcd_remap6(blockIdx.x, p.full_tiles);
+            kt_begin = 0;
+            kt_end = nk_all;
+        } else {
+            const int u = blockIdx.x - p.full_tiles;
+            split_tile = u / p.nsplit;
+            slice = u - split_tile * p.nsplit;
+            tile = p.full_tiles + split_tile;
+            kt_begin = (int)((int64_t)nk_all * slice / p.nsplit);
+            kt_end = (int)((int64_t)nk_all * (slice + 1) / p.nsplit);
+        }
+    }
+    int tm, tn;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = tile / per_group;
+        const int first = g * p.group_m;
+        const int gsz = p.tiles_m - first < p.group_m ? p.tiles_m - first : p.group_m;
+        const int w = tile - g * per_group;
+        tm = first + w % gsz;
+        tn = w / gsz;
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+    X6_STAMP(0);
+#ifdef RELAX_X6_STAMPS
+    if (p.stamps && threadIdx.x == 0) {
+        p.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    }
+#endif
+
+    // Launched together, the workgroups of a round run in lockstep and reach their epilogues at the same moment: 256 CUs
+    // then write (and re-read, for a residual) their tiles at once, and the epilogue takes as long as HBM needs for the
+    // burst (measured 48k cycles per 256x256 tile against ~15k when the memory system is quiet).  Lockstep INSIDE an XCD is
+    // wanted (the workgroups of an XCD share A / W tiles through its L2 while they walk K together), so the first round
+    // is staggered per XCD: XCD x starts x/8 of a tile later, which spreads the eight bursts over the tile time for the
+    // rest of the launch.  Speed heuristic only.
+    if (p.stagger > 0 && (int)blockIdx.x < p.first_round) {
+        if (tid == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;   // HW_REG_XCC_ID
+            const unsigned long long wait = (unsigned long long)p.stagger * xcc / 8;
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+        }
+        __syncthreads();
+    }
+
+    // ---- DMA descriptors.  Piece j of this wave (global piece wave + NW*j) covers LDS bytes [piece*1024, +1024) of a
+    // stage; lane l fills unit u = piece*64 + l = (tile row u/6, physical unit u%6); physical unit (plane q, half h')
+    // holds logical half h = h' ^ bit3(row).  Pieces j < A_PPW belong to the activation rows, the rest to the weight rows.
+    const bool pixels = TAPS || p.stride != 1;     // rows are output pixels of an NHWC image (else: plain matrix rows)
+    const int64_t row_bytes = (int64_t)p.K * 6;
+    const int64_t pix_bytes = (int64_t)p.Cin * 6;
+    const int img0 = pixels ? m0 / (p.Ho * p.Wo) : 0;
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
+    {
+        const int64_t base = pixels ? (int64_t)img0 * p.H * p.W * pix_bytes : (int64_t)m0 * row_bytes;
+        const int64_t total = pixels ? (int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * pix_bytes : (int64_t)p.M * row_bytes;
+        const int64_t left = total - base;
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a + base), 0, (int)(left < kMaxRecords ? left : kMaxRecords),
+                                                   0x00020000);
+        rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + (int64_t)n0 * row_bytes), 0, (int)(BN * row_bytes), 0x00020000);
+    }
+    unsigned voff[PPW];
+    int a_iy[A_PPW > 0 ? A_PPW : 1], a_ix[A_PPW > 0 ? A_PPW : 1];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave + NW * j;
+        const int u = piece * 64 + lane;
+        const int trow = u / 6;
+        const int c = u - trow * 6;
+        const int unit_off = (c >> 1) * 32 + (((c & 1) ^ ((trow >> 3) & 1)) << 4);
+        if (j < A_PPW) {
+            const int m = m0 + trow;
+            a_iy[j] = -(1 << 28);
+            a_ix[j] = 0;
+            if (m >= p.M) {
+                voff[j] = kOutOfRange;
+            } else if (pixels) {
+                const int img = m / (p.Ho * p.Wo);
+                const int rem = m - img * (p.Ho * p.Wo);
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                a_iy[j] = oy * p.stride - p.pad;
+                a_ix[j] = ox * p.stride - p.pad;
+                voff[j] = (unsigned)((((img - img0) * p.H + a_iy[j]) * p.W + a_ix[j]) * (int)pix_bytes + unit_off);
+            } else {
+                voff[j] = (unsigned)(trow * (int)row_bytes + unit_off);
+            }
+        } else {
+            voff[j] = piece < PIECES ? (unsigned)((trow - BM) * (int)row_bytes + unit_off) : kOutOfRange;
+        }
+    }
+    // K-step iterator of the DMA issue (steps are issued in order): plain = a byte offset; taps = (dy, dx, channel chunk)
+    int d_kt = kt_begin;
+    int d_dy = 0, d_dx = 0, d_cc = 0;
+    const int cin_chunks = p.Cin >> 4;
+    if (TAPS) {
+        const int tap = kt_begin / cin_chunks;
+        d_cc = kt_begin - tap * cin_chunks;
+        d_dy = tap / p.KW;
+        d_dx = tap - d_dy * p.KW;
+    }
+
+#define X6_ISSUE(st_)                                                                                                   \
+    {                                                                                                                   \
+        const int lin_ = d_kt * kChunkBytes;                                                                            \
+        const int tapoff_ = TAPS ? (d_dy * p.W + d_dx) * (int)pix_bytes + d_cc * kChunkBytes : 0;                        \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                                               \
+            const int piece_ = wave + NW * j;                                                                           \
+            const int dst_ = piece_ < PIECES ? (st_) * STAGE + piece_ * 1024 : DUMMY;                                   \
+            if (j < A_PPW) {                                                                                            \
+                if (TAPS) {                                                                                             \
+                    const int jj_ = j < A_PPW ? j : 0;                                                                  \
+                    const bool ok_ = (unsigned)(a_iy[jj_] + d_dy) < (unsigned)p.H && (unsigned)(a_ix[jj_] + d_dx) < (unsigned)p.W; \
+                    X6_DMA(rsrc_a, dst_, ok_ ? voff[j] + (unsigned)tapoff_ : kOutOfRange, 0);                            \
+                } else {                                                                                                \
+                    X6_DMA(rsrc_a, dst_, voff[j], lin_);                                                                \
+                }                                                                                                       \
+            } else {                                                                                                    \
+                X6_DMA(rsrc_w, dst_, voff[j], lin_);                                                                    \
+            }                                                                                                           \
+        }                                                                                                               \
+        if (!(RELAX_X6_ABLATE & 2)) ++d_kt;                                                                             \
+        if (TAPS) {                                                                                                     \
+            ++d_cc;                                                                                                     \
+            const bool wc_ = d_cc == cin_chunks;                                                                        \
+            d_cc = wc_ ? 0 : d_cc;                                                                                      \
+            d_dx += wc_ ? 1 : 0;                                                                                        \
+            const bool wx_ = d_dx == p.KW;                                                                              \
+            d_dx = wx_ ? 0 : d_dx;                                                                                      \
+            d_dy += wx_ ? 1 : 0;                                                                                        \
+        }                                                                                                               \
+    }
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets: lane (r, h) reads the unit of half h of row r; rows with bit 3 set hold the halves swapped
+    const int r32 = lane & 31;
+    const int frag = r32 * kChunkBytes + ((((lane >> 5) ^ (r32 >> 3)) & 1) << 4);
+    const int a_off = (wm * TM * 32) * kChunkBytes + frag;
+    const int b_off = (BM + wn * TN * 32) * kChunkBytes + frag;
+    const int x_off = SPLIT_B ? a_off : b_off;
+    const int y_off = SPLIT_B ? b_off : a_off;
+
+    bf16x8 xf[2][XT][3], yf0[YH][3], yf1[YH][3];   // [.][fragment][plane hi, mid, lo]
+#define X6_READ_X(set_, sp_)                                                                                            \
+    _Pragma("unroll") for (int x = 0; x < XT; ++x) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                     \
+        xf[set_][x][pl] = *reinterpret_cast<const bf16x8*>((sp_) + x_off + x * 32 * kChunkBytes + pl * 32);
+#define X6_READ_Y(yf_, half_, sp_)                                                                                      \
+    _Pragma("unroll") for (int y = 0; y < YH; ++y) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                     \
+        yf_[y][pl] = *reinterpret_cast<const bf16x8*>((sp_) + y_off + ((half_) * YH + y) * 32 * kChunkBytes + pl * 32);
+    // the six partial products, smallest first: (A plane, B plane) = (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi);
+    // product type outermost: XT*YH independent accumulators between two MFMAs on the same one
+#define X6_MFMAS(set_, yf_, half_)                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                                     \
+        const int pa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0;                                                         \
+        const int pb = t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0;                                                         \
+        _Pragma("unroll") for (int x = 0; x < XT; ++x) _Pragma("unroll") for (int y = 0; y < YH; ++y) {                 \
+            if (SPLIT_B)                                                                                                \
+                acc[x][(half_) * YH + y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[set_][x][pa], yf_[y][pb],         \
+                                                                                   acc[x][(half_) * YH + y], 0, 0, 0);  \
+            else                                                                                                        \
+                acc[(half_) * YH + y][x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf_[y][pa], xf[set_][x][pb],         \
+                                                                                   acc[(half_) * YH + y][x], 0, 0, 0);  \
+        }                                                                                                               \
+    }
+    // one K step on stage xs_ (= its parity): has_next_ / has_d_ are literal `true` in the steady state (branch-free body)
+#define X6_STEP(xs_, has_next_, has_d_)                                                                                 \
+    {                                                                                                                   \
+        const char* sp_ = smem + (xs_) * STAGE;                                                                         \
+        const char* sn_ = smem + ((xs_) ^ 1) * STAGE;                                                                   \
+        X6_READ_Y(yf1, 1, sp_);                                                                                         \
+        X6_MFMAS(xs_, yf0, 0);                                                                                          \
+        if (has_next_) {                                                                                                \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+            __builtin_amdgcn_s_barrier();                                                                               \
+            if (has_d_ && !(RELAX_X6_ABLATE & 1)) X6_ISSUE(xs_);                                                        \
+            X6_READ_X((xs_) ^ 1, sn_);                                                                                  \
+            X6_READ_Y(yf0, 0, sn_);                                                                                     \
+        }                                                                                                               \
+        X6_MFMAS(xs_, yf1, 1);                                                                                          \
+    }
+
+    const int nk = kt_end - kt_begin;
+    X6_ISSUE(0);
+    if (nk > 1) X6_ISSUE(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    X6_READ_X(0, smem);
+    X6_READ_Y(yf0, 0, smem);
+    X6_STAMP(1);
+    X6_STAMP(6);
+    int k = 0;
+    for (; k + 3 < nk; k += 2) {
+        X6_STEP(0, true, true);
+        X6_STEP(1, true, true);
+    }
+    for (; k < nk; k += 2) {
+        X6_STEP(0, k + 1 < nk, k + 2 < nk);
+        if (k + 1 < nk) X6_STEP(1, k + 2 < nk, k + 3 < nk);
+    }
+#undef X6_STEP
+#undef X6_MFMAS
+#undef X6_READ_X
+#undef X6_READ_Y
+#undef X6_ISSUE
+    X6_STAMP(2);
+    __syncthreads();   // no DMA is in flight and every fragment is in registers: the stages become the epilogue staging
+
+    // ---- epilogue, staged through LDS in 64-row chunks (C/D map of the 32x32 MFMA: col = lane & 31,
+    // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); a thread owns 8 consecutive columns: bias / residual / activation
+    // fused, 16-byte stores to the fp32 output and / or the three planes of the sp3 output
+    float* stg = reinterpret_cast<float*>(smem);
+    constexpr int LDC = BN + 4;
+    constexpr int EP_ROWS = 64;
+    constexpr int C8 = BN / 8;
+    static_assert(NT % C8 == 0 && (EP_ROWS * C8) % NT == 0, "epilogue chunk must divide over the workgroup");
+    static_assert(EP_ROWS * LDC * 4 <= NSTAGE * STAGE, "epilogue chunk must fit the staging LDS");
+    constexpr int EP_STEP = NT / C8;
+    constexpr int EP_ITERS = EP_ROWS / EP_STEP;
+    const int half = lane >> 5;
+    const int lc = (tid % C8) * 8;
+    const int lr0 = tid / C8;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bias_a = zero4, bias_b = zero4;
+    if (slice < 0 && p.bias) {
+        bias_a = *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
+        bias_b = *reinterpret_cast<const f32x4*>(p.bias + n0 + lc + 4);
+    }
+    const bool interior = m0 + BM <= p.M;   // workgroup-uniform
+#pragma unroll
+    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
+        if (pass > 0) __syncthreads();
+        // residual rows of this pass: requested before the accumulators are staged, in flight under the LDS traffic
+        f32x4 ra[EP_ITERS], rb[EP_ITERS];
+        if (slice < 0 && p.residual) {
+#pragma unroll
+            for (int it = 0; it < EP_ITERS; ++it) {
+                const int m = m0 + pass * EP_ROWS + it * EP_STEP + lr0;
+                ra[it] = zero4;
+                rb[it] = zero4;
+                if (interior || m < p.M) {
+                    const float* r = p.residual + (int64_t)m * p.N + n0 + lc;
+                    ra[it] = *reinterpret_cast<const f32x4*>(r);
+                    rb[it] = *reinterpret_cast<const f32x4*>(r + 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rb0 = (wm * TM + i) * 32;
+            if (rb0 / EP_ROWS == pass) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stg[(rb0 % EP_ROWS + 4 * half + (r & 3) + 8 * (r >> 2)) * LDC + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) {
+            const int lr = it * EP_STEP + lr0;
+            const int trow = pass * EP_ROWS + lr;
+            const int m = m0 + trow;
+            if (!interior && m >= p.M) continue;
+            f32x4 va = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lc);
+            f32x4 vb = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lc + 4);
+            if (slice >= 0) {   // K slice of a split tile: raw partial sums, the epilogue runs in splitk_finish_x6
+                float* o = p.partial + ((int64_t)split_tile * p.nsplit + slice) * (BM * BN) + (int64_t)trow * BN + lc;
+                *reinterpret_cast<f32x4*>(o) = va;
+                *reinterpret_cast<f32x4*>(o + 4) = vb;
+                continue;
+            }
+            va += bias_a;
+            vb += bias_b;
+            if (p.residual) {   // (acc + bias) + residual: the same order on every path
+                va += ra[it];
+                vb += rb[it];
+            }
+            if (p.act == 1) {
+                va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};
+                vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};
+            } else if (p.act == 2) {
+                va = (f32x4){act_gelu(va.x), act_gelu(va.y), act_gelu(va.z), act_gelu(va.w)};
+                vb = (f32x4){act_gelu(vb.x), act_gelu(vb.y), act_gelu(vb.z), act_gelu(vb.w)};
+            }
+            const int64_t o = (int64_t)m * p.N + n0 + lc;
+            if (p.out) {
+                *reinterpret_cast<f32x4*>(p.out + o) = va;
+                *reinterpret_cast<f32x4*>(p.out + o + 4) = vb;
+            }
+            if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lc, va, vb);
+        }
+    }
+    X6_STAMP(3);
+#endif
+}
+
+// Sums the K slices of the split tiles in slice order (deterministic) and applies the epilogue.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void splitk_finish_x6(const X6Params p) {
+    const int split_tile = blockIdx.y;
+    const int tile = p.full_tiles + split_tile;
+    int tm, tn;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = tile / per_group;
+        const int first = g * p.group_m;
+        const int gsz = p.tiles_m - first < p.group_m ? p.tiles_m - first : p.group_m;
+        const int w = tile - g * per_group;
+        tm = first + w % gsz;
+        tn = w / gsz;
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+    const int e8 = blockIdx.x * 256 + threadIdx.x;  // 8-column group index inside the tile
+    if (e8 >= BM * BN / 8) return;
+    const int lr = e8 / (BN / 8), lc = (e8 % (BN / 8)) * 8;
+    const int m = m0 + lr;
+    if (m >= p.M) return;
+    const float* pt = p.partial + (int64_t)split_tile * p.nsplit * (BM * BN) + lr * BN + lc;
+    f32x4 va = *reinterpret_cast<const f32x4*>(pt), vb = *reinterpret_cast<const f32x4*>(pt + 4);
+    for (int k = 1; k < p.nsplit; ++k) {
+        va += *reinterpret_cast<const f32x4*>(pt + (int64_t)k * (BM * BN));
+        vb += *reinterpret_cast<const f32x4*>(pt + (int64_t)k * (BM * BN) + 4);
+    }
+    const int64_t o = (int64_t)m * p.N + n0 + lc;
+    if (p.bias) {
+        va += *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
+        vb += *reinterpret_cast<const f32x4*>(p.bias + n0 + lc + 4);
+    }
+    if (p.residual) {
+        va += *reinterpret_cast<const f32x4*>(p.residual + o);
+        vb += *reinterpret_cast<const f32x4*>(p.residual + o + 4);
+    }
+    if (p.act == 1) {
+        va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};
+        vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};
+    } else if (p.act == 2) {
+        va = (f32x4){act_gelu(va.x), act_gelu(va.y), act_gelu(va.z), act_gelu(va.w)};
+        vb = (f32x4){act_gelu(vb.x), act_gelu(vb.y), act_gelu(vb.z), act_gelu(vb.w)};
+    }
+    if (p.out) {
+        *reinterpret_cast<f32x4*>(p.out + o) = va;
+        *reinterpret_cast<f32x4*>(p.out + o + 4) = vb;
+    }
+    if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lc, va, vb);
+}
+
+template <int BM, int BN, int WM, int WN, bool TAPS>
+static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int WG_PER_CU = NT == 256 ? 2 : 1;
+    p.tiles_n = p.N / BN;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.ntiles = p.tiles_m * p.tiles_n;
+    p.group_m = h->gemm.group_m;
+    p.full_tiles = p.ntiles;
+    p.nsplit = 1;
+    p.partial = nullptr;
+    // Tail split-K (same cost model as gemm.hip; two workgroups per CU).
+    const int slots = 256 * WG_PER_CU;
+    const int nk = p.K / 16;
+    const int rem = p.ntiles % slots;
+    if (h->gemm.split_k && rem > 0) {
+        int best_s = 1;
+        double best = 1.0;
+        const int smax = nk / 8 < 16 ? nk / 8 : 16;
+        for (int S = 2; S <= smax; ++S) {
+            const double t = (double)((rem * S + slots - 1) / slots) / S + 0.04 * S;
+            if (t < best - 0.05) {
+                best = t;
+                best_s = S;
+            }
+        }
+        if (best_s >= 2) {
+            const size_t need = sizeof(float) * (size_t)rem * best_s * BM * BN;
+            RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
+            p.partial = static_cast<float*>(h->splitk_ws.p);
+            p.full_tiles = p.ntiles - rem;
+            p.nsplit = best_s;
+        }
+    }
+    // per-XCD stagger of the first round: one tile = its K loop at the full matrix rate (32 cycles per MFMA, two waves per SIMD)
+    // plus an epilogue; "gemm_stagger" scales it in percent
+    p.stagger = h->gemm.stagger ? (int)(((int64_t)nk * (BM / 64) * (BN / 64) * 6 * 32 * 2 / (NT / 128) + 20000) * h->gemm.stagger / 100) : 0;
+    p.first_round = slots;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * kChunkBytes + 1024;
+    static bool attr_set[kMaxDevices] = {};
+    if (!attr_set[h->device]) {
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[h->device] = true;
+    }
+    const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
+#ifdef RELAX_X6_STAMPS
+    RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * 8 * (size_t)units));
+    p.stamps = static_cast<unsigned long long*>(h->scratch.p);
+#endif
+    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS>), dim3(units), dim3(NT), lds, s, p);
+#ifdef RELAX_X6_STAMPS
+    {
+        RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
+        std::vector<unsigned long long> hs(8 * (size_t)units);
+        RELAX_HIP_CHECK(h, hipMemcpy(hs.data(), p.stamps, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
+        double d[3] = {0, 0, 0};
+        for (int u = 0; u < p.full_tiles; ++u) {
+            const unsigned long long* t = &hs[8 * (size_t)u];
+            d[0] += (double)(t[1] - t[0]);
+            d[1] += (double)(t[2] - t[1]);
+            d[2] += (double)(t[3] - t[2]);
+        }
+        if (const char* dump = getenv("RELAX_X6_STAMP_DUMP")) {   // raw records of every launch, appended
+            if (FILE* f = fopen(dump, "ab")) {
+                const int hdr[8] = {p.M, p.N, p.K, BM, BN, units, p.full_tiles, p.stagger};
+                fwrite(hdr, sizeof(hdr), 1, f);
+                fwrite(hs.data(), sizeof(hs[0]), hs.size(), f);
+                fclose(f);
+            }
+        }
+        const double n = p.full_tiles > 0 ? p.full_tiles : 1;
+        fprintf(stderr, "x6 %dx%dx%d tile %dx%d act %d res %d sp3out %d: cycles per tile: prologue %.0f, K loop %.0f (%d steps, %.0f per step), "
+                "epilogue %.0f\n", p.M, p.N, p.K, BM, BN, p.act, p.residual != nullptr, p.out_sp3 != nullptr, d[0] / n, d[1] / n,
+                p.K / 16, d[1] / n / (p.K / 16), d[2] / n);
+    }
+#endif
+    if (p.nsplit > 1)
+        hipLaunchKernelGGL((splitk_finish_x6<BM, BN>), dim3(BM * BN / 8 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
+    X6Params p{};
+    p.a = static_cast<const char*>(d.in);
+    p.w = static_cast<const char*>(d.w);
+    p.bias = d.bias; p.residual = d.residual; p.out = d.out; p.out_sp3 = static_cast<char*>(d.out_sp3);
+    p.M = d.Nimg * d.Ho * d.Wo;
+    p.N = d.Cout;
+    p.K = d.KH * d.KW * d.Cin;
+    p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Ho = d.Ho; p.Wo = d.Wo;
+    p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
+    p.act = d.act;
+    const bool taps = d.KH * d.KW > 1;
+    RELAX_REQUIRE(h, p.M > 0 && p.N > 0 && p.K > 0, "x6 conv/gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+    RELAX_REQUIRE(h, d.Cin % 16 == 0, "x6 conv/gemm: Cin=%d must be a multiple of 16", d.Cin);
+    RELAX_REQUIRE(h, p.N % 64 == 0, "x6 conv/gemm: N=%d must be a multiple of 64", p.N);
+    RELAX_REQUIRE(h, (int64_t)p.K * 6 * 256 < kMaxRecords, "x6 conv/gemm: K=%d too large", p.K);
+    RELAX_REQUIRE(h, d.out || d.out_sp3, "x6 conv/gemm: no output requested");
+    RELAX_REQUIRE(h, !taps || d.pad >= 0, "x6 conv: bad padding");
+    RELAX_REQUIRE(h, taps || d.pad == 0, "x6 conv: 1x1 with padding is not supported");
+    const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)p.K;
+    // algorithmic HBM bytes: activation in (6 B per value), weights, outputs (+ residual), each touched once
+    const double bytes = 6.0 * ((double)d.Nimg * d.H * d.W * d.Cin + (double)p.N * p.K) +
+                         (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.residual ? 4.0 : 0.0));
+    int span;
+    RELAX_TRY(prof_begin(h, s, 0, flops, &span, bytes));
+    int rc;
+    // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA: K loop at 85 % of the
+    // matrix rate).  The alternative measured against it, two 4-wave workgroups per CU on 128x256 tiles ("gemm_variant" 2),
+    // hides its epilogues under the other workgroup's MFMAs but needs 1.5x the DMA pieces per MFMA: 4 % slower on the ViT.
+    if (p.N % 256 == 0 && h->gemm.variant != 2)
+        rc = taps ? launch_x6_variant<256, 256, 2, 4, true>(h, p, s) : launch_x6_variant<256, 256, 2, 4, false>(h, p, s);
+    else if (p.N % 256 == 0)
+        rc = taps ? launch_x6_variant<128, 256, 2, 2, true>(h, p, s) : launch_x6_variant<128, 256, 2, 2, false>(h, p, s);
+    else if (p.N % 128 == 0)
+        rc = taps ? launch_x6_variant<256, 128, 2, 2, true>(h, p, s) : launch_x6_variant<256, 128, 2, 2, false>(h, p, s);
+    else
+        rc = taps ? launch_x6_variant<256, 64, 4, 1, true>(h, p, s) : launch_x6_variant<256, 64, 4, 1, false>(h, p, s);
+    if (rc != RELAX_OK) { prof_abort(h, span); return rc; }
+    RELAX_TRY(prof_end(h, s, span));
+    return RELAX_OK;
+}
+
+}  // namespace relax

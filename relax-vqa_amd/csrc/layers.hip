@@ -14,8 +14,22 @@ __device__ inline float wave_sum(float v) {
 }
 
 // ---- LayerNorm: one 64-lane wave per row, row held in registers (dim <= 768) ---------------------------
+// SP3: the normalised row leaves as split planes (bf16 hi + mid + lo, gemm_x6.hip) for the bf16x6 contraction that
+// consumes it; the arithmetic before the store is the same, so the fp32 value that is split is the one the fp32 path stores.
+typedef float ln_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ln_bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ inline void ln_split3_pair(float x, float y, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector((ln_f32x2){x, y}, ln_bf16x2));
+    const float rx = x - __uint_as_float(hi << 16), ry = y - __uint_as_float(hi & 0xffff0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector((ln_f32x2){rx, ry}, ln_bf16x2));
+    const float sx = rx - __uint_as_float(mid << 16), sy = ry - __uint_as_float(mid & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((ln_f32x2){sx, sy}, ln_bf16x2));
+}
+
+template <bool SP3>
 __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x, const float* __restrict__ g,
-                                                      const float* __restrict__ b, float* __restrict__ y, int rows,
+                                                      const float* __restrict__ b, void* __restrict__ yv, int rows,
                                                       int dim, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -41,7 +55,6 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + eps);
-    float4* yr = reinterpret_cast<float4*>(y + (int64_t)row * dim);
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const float4* b4 = reinterpret_cast<const float4*>(b);
 #pragma unroll
@@ -54,7 +67,18 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
             o.y = (v[j].y - mean) * rstd * gg.y + bb.y;
             o.z = (v[j].z - mean) * rstd * gg.z + bb.z;
             o.w = (v[j].w - mean) * rstd * gg.w + bb.w;
-            yr[i] = o;
+            if (SP3) {
+                // values k = 4i .. 4i+3: 8 bytes of each plane of chunk k / 16 (96-byte chunks: [16 hi][16 mid][16 lo])
+                uint2 hi, mid, lo;
+                ln_split3_pair(o.x, o.y, hi.x, mid.x, lo.x);
+                ln_split3_pair(o.z, o.w, hi.y, mid.y, lo.y);
+                char* d = static_cast<char*>(yv) + (int64_t)row * dim * 6 + (i >> 2) * 96 + (i & 3) * 8;
+                *reinterpret_cast<uint2*>(d) = hi;
+                *reinterpret_cast<uint2*>(d + 32) = mid;
+                *reinterpret_cast<uint2*>(d + 64) = lo;
+            } else {
+                reinterpret_cast<float4*>(static_cast<float*>(yv) + (int64_t)row * dim)[i] = o;
+            }
         }
     }
 }
@@ -63,7 +87,16 @@ int launch_layernorm(relax_handle* h, const float* x, const float* g, const floa
                      float eps, hipStream_t s) {
     RELAX_REQUIRE(h, dim % 4 == 0 && dim > 0 && dim <= 768, "layernorm: dim=%d must be a multiple of 4, <= 768", dim);
     RELAX_REQUIRE(h, rows > 0, "layernorm: rows=%d", rows);
-    hipLaunchKernelGGL(layernorm_rows, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, dim, eps);
+    hipLaunchKernelGGL(layernorm_rows<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, dim, eps);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+int launch_layernorm_sp3(relax_handle* h, const float* x, const float* g, const float* b, void* y_sp3, int rows, int dim,
+                         float eps, hipStream_t s) {
+    RELAX_REQUIRE(h, dim % 16 == 0 && dim > 0 && dim <= 768, "layernorm_sp3: dim=%d must be a multiple of 16, <= 768", dim);
+    RELAX_REQUIRE(h, rows > 0, "layernorm: rows=%d", rows);
+    hipLaunchKernelGGL(layernorm_rows<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y_sp3, rows, dim, eps);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }
@@ -127,7 +160,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
             qf[q8] = *reinterpret_cast<const att_f32x4*>(q_ + 8 * q8) * (0.125f * 1.44269504088896341f);         \
     }
 
-    // diagnostic build only (RELAX_GEMM_ABLATE bit 64): per-wave cycle shares of the phases of one item
+    // diagnostic instantiation only (-DRELAX_ATT_STAMPS): per-wave cycle shares of the phases of one item
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
 #define ATT_STAMP(i_)                                                  \
@@ -237,29 +270,26 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
 
 int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s) {
     RELAX_REQUIRE(h, Nimg > 0 && heads > 0, "attention: Nimg=%d heads=%d", Nimg, heads);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[kMaxDevices] = {};
+    if (!attr_set[h->device]) {
         RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_197x64<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_LDS));
+#ifdef RELAX_ATT_STAMPS
         RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_197x64<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_LDS));
-        attr_set = true;
+#endif
+        attr_set[h->device] = true;
     }
     const int total = Nimg * heads;
     // one persistent workgroup (7 waves, ~250 VGPRs) per CU
     const int grid = total < 256 ? total : 256;
-    unsigned long long* stamps = nullptr;
-    if (h->gemm.ablate & 64) {   // diagnostic: phase shares, printed after a sync (never in a timed or product run)
+#ifdef RELAX_ATT_STAMPS   // diagnostic build only (tools/build_ablations.sh att_stamps[:mask]): per-wave phase shares, printed after a sync
+    {
         RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * (size_t)grid * KTILES * 6));
-        stamps = static_cast<unsigned long long*>(h->scratch.p);
-    }
-    if (stamps)
+        unsigned long long* stamps = static_cast<unsigned long long*>(h->scratch.p);
         hipLaunchKernelGGL(attention_197x64<true>, dim3(grid), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, total,
-                           h->gemm.ablate & 56, stamps);
-    else
-        hipLaunchKernelGGL(attention_197x64<false>, dim3(grid), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, total, 0, stamps);
-    RELAX_HIP_CHECK(h, hipGetLastError());
-    if (stamps) {
+                           RELAX_ATT_STAMPS & 56, stamps);
+        RELAX_HIP_CHECK(h, hipGetLastError());
         RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
         std::vector<unsigned long long> hs((size_t)grid * KTILES * 6);
         RELAX_HIP_CHECK(h, hipMemcpy(hs.data(), stamps, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
@@ -269,6 +299,10 @@ int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, in
         fprintf(stderr, "attention phase cycles per wave per item: S %.0f softmax %.0f sync+Vstore %.0f PV %.0f stores %.0f Q+sync+Kstore %.0f\n",
                 tot[0] / n, tot[1] / n, tot[2] / n, tot[3] / n, tot[4] / n, tot[5] / n);
     }
+#else
+    hipLaunchKernelGGL(attention_197x64<false>, dim3(grid), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, total, 0, nullptr);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+#endif
     return RELAX_OK;
 }
 

@@ -12,6 +12,8 @@
 
 namespace relax {
 
+constexpr int kMaxDevices = 64;   // relax_create refuses device ids beyond this (per-device launch-attribute flags)
+
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(relax_handle* h, const char* fmt, ...);
 
@@ -62,6 +64,23 @@ struct ConvDesc {
     double flops;           // algorithmic FLOPs for the profiler (0 = 2*M*N*KH*KW*Cin)
 };
 
+// sp3 ("split planes") operands of the bf16x6 kernel (gemm_x6.hip): every fp32 value as bf16 hi + mid + lo, a row of K
+// values = K/16 chunks of [16 hi][16 mid][16 lo] (96 bytes)
+struct ConvDescX6 {
+    const void* in;         // sp3 NHWC activation [Nimg*H*W][Cin*6 B] (plain GEMM: H = 1, W = M rows of Cin = K values)
+    int Nimg, H, W, Cin;
+    int Ho, Wo;
+    int KH, KW, stride, pad;
+    const void* w;          // sp3 weights [Cout][KH*KW*Cin*6 B], k = (dy*KW+dx)*Cin + c
+    int Cout;
+    const float* bias;      // [Cout] or null
+    const float* residual;  // fp32 [M, Cout] or null
+    float* out;             // fp32 [M, Cout] or null
+    void* out_sp3;          // sp3 [M][Cout*6 B] or null (at least one output)
+    int act;                // 0 none, 1 relu, 2 gelu(erf)
+    double flops;           // algorithmic FLOPs for the profiler (0 = 2*M*N*K)
+};
+
 // ---- model weights ------------------------------------------------------------------------------
 struct ConvW {          // one folded conv (+BN) of ResNet-50
     float* w = nullptr;     // device [Cout][Kpad]
@@ -86,6 +105,7 @@ struct ResNet50W {
 
 struct LinearW {
     float* w = nullptr;  // device [out][in]
+    void* w_sp3 = nullptr;  // the same matrix as split planes (bf16 hi + mid + lo, gemm_x6.hip), made once at load time
     float* b = nullptr;  // device [out]
     int in = 0, out = 0;
 };
@@ -146,13 +166,13 @@ struct Profiler {
 namespace relax {
 // Tuning / reproducibility switches of the contraction kernel (relax_set_option; env defaults RELAX_GEMM_*).
 struct GemmOptions {
-    int precision = 0; // "gemm_precision": 0 = exact fp32 MFMA (default), 1 = bf16x3 split products (opt-in, ~1e-5 relative)
+    int precision = 0; // "gemm_precision": 0 = exact fp32 MFMA, 1 = bf16x3 split products (~1e-5 relative), 2 = bf16x6 (fp32-grade)
     int split_k = 1;   // "gemm_split_k": tail split-K on (1) / off (0: K sums are batch-invariant bit for bit)
     int variant = -1;  // "gemm_variant": pin the tile variant for N % 128 == 0 problems, -1 = automatic
     int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)
     int group_m = 8;   // "gemm_group_m": row-tiles per L2 group
     int prio = 0;      // "gemm_prio": s_setprio around the MFMA cluster
-    int ablate = 0;    // env RELAX_GEMM_ABLATE only: timing-only ablations (results are WRONG): 1 barrier, 2 global loads, 4 LDS stores
+    int stagger = 0;   // "gemm_stagger": bf16x6 per-XCD stagger of the first round of tiles, in % of one tile time (0 = off)
 };
 }  // namespace relax
 
@@ -164,6 +184,7 @@ struct relax_handle {
     int reserved_images = 0;
     relax::DevBuf scratch;      // stage-A scratch (scores)
     relax::DevBuf splitk_ws;    // split-K partial tiles of the contraction kernel
+    relax::DevBuf sp3_ws;       // operand conversions of the operator-level entry points under "bf16x6"
     relax::DevBuf resize_ws;    // uint8 intermediates of the two-pass resize
     relax::DevBuf flow_ws;      // optical-flow pyramid workspace
     relax::DevBuf head_ws;      // scaled features + hidden activations of the quality head
@@ -182,6 +203,7 @@ int upload(relax_handle* h, const float* host, size_t n, float** dev, std::vecto
 // profiling helpers: call around a launch; no-ops when profiling is off
 int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_idx, double bytes = 0);
 int prof_end(relax_handle* h, hipStream_t s, int span_idx);
+void prof_abort(relax_handle* h, int span_idx);   // a launch failed between begin and end: drop the half-recorded span
 
 // contraction kernel launcher (gemm.hip)
 int launch_conv(relax_handle* h, const ConvDesc& d, hipStream_t s);
@@ -194,9 +216,23 @@ inline int launch_gemm(relax_handle* h, const float* A, const float* W, const fl
     return launch_conv(h, d, s);
 }
 
+// bf16x6 contraction kernel (gemm_x6.hip)
+int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s);
+int launch_to_sp3(relax_handle* h, const float* x, int64_t ld, void* y, int64_t rows, int K, hipStream_t s);
+inline int launch_gemm_x6(relax_handle* h, const void* A_sp3, const void* W_sp3, const float* bias, const float* residual,
+                          float* out, void* out_sp3, int M, int N, int K, int act, hipStream_t s) {
+    ConvDescX6 d{};
+    d.in = A_sp3; d.Nimg = 1; d.H = 1; d.W = M; d.Cin = K; d.Ho = 1; d.Wo = M;
+    d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+    d.w = W_sp3; d.Cout = N; d.bias = bias; d.residual = residual; d.out = out; d.out_sp3 = out_sp3; d.act = act;
+    return launch_conv_x6(h, d, s);
+}
+
 // small kernels (layers.hip)
 int launch_layernorm(relax_handle* h, const float* x, const float* g, const float* b, float* y, int rows, int dim,
                      float eps, hipStream_t s);
+int launch_layernorm_sp3(relax_handle* h, const float* x, const float* g, const float* b, void* y_sp3, int rows, int dim,
+                         float eps, hipStream_t s);
 int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s);
 int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
                            int Nimg, int H, int W, int C, hipStream_t s);

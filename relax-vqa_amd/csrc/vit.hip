@@ -30,6 +30,35 @@ __global__ __launch_bounds__(256) void vit_patchify(const uint8_t* __restrict__ 
     P[i] = (float)frag[((n * 224 + y) * 224 + x) * 3 + (2 - c)] / 255.0f;
 }
 
+// the same patches as split planes (bf16 hi + mid + lo of value/255, gemm_x6.hip): one thread per 8 k (8 pixels of a patch row)
+typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pf_bf16x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void vit_patchify_sp3(const uint8_t* __restrict__ frag, char* __restrict__ P, int64_t total8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int k = (int)(i % (PATCH_K / 8)) * 8;
+    const int64_t row = i / (PATCH_K / 8);
+    const int p = (int)(row % NPATCH);
+    const int64_t n = row / NPATCH;
+    const int c = k >> 8, py = (k >> 4) & 15, px = k & 15;
+    const int y = (p / 14) * 16 + py, x = (p % 14) * 16 + px;
+    const uint8_t* src = frag + ((n * 224 + y) * 224 + x) * 3 + (2 - c);
+    unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = (float)src[6 * j] / 255.0f, b = (float)src[6 * j + 3] / 255.0f;
+        hi[j] = __builtin_bit_cast(unsigned, __builtin_convertvector((pf_f32x2){a, b}, pf_bf16x2));
+        const float ra = a - __uint_as_float(hi[j] << 16), rb = b - __uint_as_float(hi[j] & 0xffff0000u);
+        mid[j] = __builtin_bit_cast(unsigned, __builtin_convertvector((pf_f32x2){ra, rb}, pf_bf16x2));
+        const float sa = ra - __uint_as_float(mid[j] << 16), sb = rb - __uint_as_float(mid[j] & 0xffff0000u);
+        lo[j] = __builtin_bit_cast(unsigned, __builtin_convertvector((pf_f32x2){sa, sb}, pf_bf16x2));
+    }
+    char* d = P + row * (PATCH_K * 6) + (k >> 4) * 96 + (k & 8) * 2;
+    *reinterpret_cast<uint4*>(d) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(d + 32) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+    *reinterpret_cast<uint4*>(d + 64) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
 // X[n,0,:] = cls + pos[0];  X[n,1+p,:] = PE[n*196+p,:] + pos[1+p]
 __global__ __launch_bounds__(256) void vit_assemble(const float* __restrict__ PE, const float* __restrict__ cls,
                                                     const float* __restrict__ pos, float* __restrict__ X, int dim4,
@@ -113,7 +142,21 @@ static size_t vit_floats_per_image(int dim) {
            + (size_t)NTOK * dim * 4;       // Hid
 }
 
-size_t vit_arena_bytes(const VitW& v, int n) { return sizeof(float) * vit_floats_per_image(v.dim) * (size_t)n; }
+// bf16x6 path: sp3 operands take 6 bytes per value (1.5 floats)
+static size_t vit_floats_per_image_x6(int dim) {
+    return (size_t)NPATCH * PATCH_K * 3 / 2     // P    patches, sp3
+           + (size_t)NPATCH * dim               // PE   patch-embed output
+           + (size_t)NTOK * dim                 // X    residual stream
+           + (size_t)NTOK * dim * 3 / 2         // Y    LayerNorm / attention output, sp3
+           + (size_t)NTOK * dim * 3             // QKV
+           + (size_t)NTOK * dim                 // ATT  attention output / final LayerNorm, fp32
+           + (size_t)NTOK * dim * 4 * 3 / 2;    // Hid  GELU(fc1), sp3
+}
+
+size_t vit_arena_bytes(const VitW& v, int n) {
+    const size_t a = vit_floats_per_image(v.dim), b = vit_floats_per_image_x6(v.dim);
+    return sizeof(float) * (a > b ? a : b) * (size_t)n;
+}
 
 }  // namespace relax
 
@@ -174,6 +217,30 @@ int relax_load_vit(relax_handle* h, const float* const* tensors, const char* con
     }
     up("norm.weight", dim, &v.norm_g);
     up("norm.bias", dim, &v.norm_b);
+    // split planes of every GEMM weight for the bf16x6 kernel (made on the device from the uploaded fp32 copy)
+    auto sp3 = [&](LinearW* l) {
+        if (rc != RELAX_OK) return;
+        void* q = nullptr;
+        if (hipMalloc(&q, (size_t)l->in * l->out * 6) != hipSuccess) {
+            set_error(h, "vit: hipMalloc of split-plane weights failed");
+            rc = RELAX_ERR_NOMEM;
+            return;
+        }
+        v.allocs.push_back(q);
+        l->w_sp3 = q;
+        rc = launch_to_sp3(h, l->w, l->in, q, l->out, l->in, nullptr);
+    };
+    sp3(&v.patch);
+    for (VitBlockW& b : v.blocks) {
+        sp3(&b.qkv);
+        sp3(&b.proj);
+        sp3(&b.fc1);
+        sp3(&b.fc2);
+    }
+    if (rc == RELAX_OK && hipDeviceSynchronize() != hipSuccess) {
+        set_error(h, "vit: weight conversion failed");
+        rc = RELAX_ERR_HIP;
+    }
     if (rc != RELAX_OK) {
         free_vit(h);
         return rc;
@@ -200,6 +267,43 @@ int relax_vit_features(relax_handle* h, const uint8_t* frags, int N, float* toke
     float* QKV = Y + n * NTOK * dim;
     float* Hid = QKV + n * NTOK * dim * 3;
     const int rows = N * NTOK;
+
+    if (h->gemm.precision == 2) {
+        // bf16x6: GEMM inputs travel as split planes (written by the kernel that produces them), GEMM outputs that feed
+        // LayerNorm / attention / the residual stream stay fp32
+        float* base = static_cast<float*>(h->arena.p);
+        char* Ps = reinterpret_cast<char*>(base);
+        float* PEx = base + n * NPATCH * PATCH_K * 3 / 2;
+        float* Xx = PEx + n * NPATCH * dim;
+        char* Ys = reinterpret_cast<char*>(Xx + n * NTOK * dim);
+        float* QKVx = reinterpret_cast<float*>(Ys) + n * NTOK * dim * 3 / 2;
+        float* ATT = QKVx + n * NTOK * dim * 3;
+        char* Hs = reinterpret_cast<char*>(ATT + n * NTOK * dim);
+        const int64_t p8 = (int64_t)N * NPATCH * (PATCH_K / 8);
+        hipLaunchKernelGGL(vit_patchify_sp3, dim3((unsigned)((p8 + 255) / 256)), dim3(256), 0, s, frags, Ps, p8);
+        RELAX_TRY(launch_gemm_x6(h, Ps, v.patch.w_sp3, v.patch.b, nullptr, PEx, nullptr, N * NPATCH, dim, PATCH_K, 0, s));
+        const int64_t at = (int64_t)rows * (dim / 4);
+        hipLaunchKernelGGL(vit_assemble, dim3((unsigned)((at + 255) / 256)), dim3(256), 0, s, PEx, v.cls, v.pos, Xx, dim / 4, at);
+        RELAX_HIP_CHECK(h, hipGetLastError());
+        for (const VitBlockW& b : v.blocks) {
+            RELAX_TRY(launch_layernorm_sp3(h, Xx, b.ln1_g, b.ln1_b, Ys, rows, dim, kLnEps, s));
+            RELAX_TRY(launch_gemm_x6(h, Ys, b.qkv.w_sp3, b.qkv.b, nullptr, QKVx, nullptr, rows, 3 * dim, dim, 0, s));
+            RELAX_TRY(launch_attention(h, QKVx, ATT, N, v.heads, s));
+            RELAX_TRY(launch_to_sp3(h, ATT, dim, Ys, rows, dim, s));
+            RELAX_TRY(launch_gemm_x6(h, Ys, b.proj.w_sp3, b.proj.b, Xx, Xx, nullptr, rows, dim, dim, 0, s));      // x += proj(attn)
+            RELAX_TRY(launch_layernorm_sp3(h, Xx, b.ln2_g, b.ln2_b, Ys, rows, dim, kLnEps, s));
+            RELAX_TRY(launch_gemm_x6(h, Ys, b.fc1.w_sp3, b.fc1.b, nullptr, nullptr, Hs, rows, 4 * dim, dim, 2, s)); // GELU(erf) -> sp3
+            RELAX_TRY(launch_gemm_x6(h, Hs, b.fc2.w_sp3, b.fc2.b, Xx, Xx, nullptr, rows, dim, 4 * dim, 0, s));     // x += mlp
+        }
+        RELAX_TRY(launch_layernorm(h, Xx, v.norm_g, v.norm_b, ATT, rows, dim, kLnEps, s));
+        if (tokens) {
+            const int64_t t = (int64_t)N * NPATCH * (dim / 4);
+            hipLaunchKernelGGL(vit_drop_cls, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, ATT, tokens, dim / 4, t);
+        }
+        if (pooled) hipLaunchKernelGGL(vit_token_stats, dim3(dim / 64, N), dim3(256), 0, s, ATT, pooled, dim, NTOK, 1, NPATCH);
+        RELAX_HIP_CHECK(h, hipGetLastError());
+        return RELAX_OK;
+    }
 
     const int64_t ptotal = (int64_t)N * NPATCH * PATCH_K;
     hipLaunchKernelGGL(vit_patchify, dim3((unsigned)((ptotal + 255) / 256)), dim3(256), 0, s, frags, P, ptotal);

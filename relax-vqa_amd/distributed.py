@@ -72,10 +72,10 @@ def gather_clip_vectors(local, n_clips, rank, world, group=None):
 
 def extract_dataset(extract_fn, n_clips, rank, world, group=None):
     """Run extract_fn(clip_index) -> [F] on this rank's shard and all-gather the per-clip vectors."""
+    if n_clips < world:
+        # decided from the arguments alone, so EVERY rank raises (an error on the empty ranks only would leave the others
+        # waiting in the all-gather until the collective times out)
+        raise ValueError(f"every rank needs at least one clip: n_clips={n_clips} < world={world}")
     mine = shard_clips(n_clips, rank, world)
-    vecs = [extract_fn(i) for i in mine]
-    if vecs:
-        local = torch.stack(vecs)
-    else:
-        raise ValueError("every rank needs at least one clip (n_clips >= world)")
+    local = torch.stack([extract_fn(i) for i in mine])
     return gather_clip_vectors(local, n_clips, rank, world, group)

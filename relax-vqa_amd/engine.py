@@ -119,14 +119,26 @@ class RelaxEngine:
         self._check(self.lib.relax_mlp_head(self.h, _ptr(features), features.shape[0], _ptr(out), _stream()), "relax_mlp_head")
         return out
 
+    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
+
     def set_precision(self, mode):
-        """'fp32' (default): exact fp32 products on the fp32 MFMA.  'bf16x3' (opt-in): each fp32 operand is split into
-        two bf16 values and a*b = hi*hi + hi*lo + lo*hi runs on the bf16 MFMA with fp32 accumulation; features stay
-        within ~1e-5 (norm-relative) of the fp32 path - the parity bar is 1e-3 - at roughly half the time."""
-        self.set_option("gemm_precision", {"fp32": 0, "bf16x3": 1}[mode])
+        """'fp32': exact fp32 products on the fp32 MFMA.  'bf16x6' (fp32-grade): each fp32 operand is held as three bf16
+        values (hi + mid + lo, exact) and a*b = the six partial products of weight >= 2^-16 on the bf16 MFMA with fp32
+        accumulation - as close to the exact result as the fp32 FMA chain at 6/16 of its matrix cycles.  'bf16x3'
+        (opt-in, lower precision): two bf16 values, three products, ~1e-5 norm-relative (the parity bar is 1e-3)."""
+        self.set_option("gemm_precision", self.PRECISIONS[mode])
+
+    def precision(self):
+        """The arithmetic the engine's contraction kernel is in right now, read back from the library."""
+        return {v: k for k, v in self.PRECISIONS.items()}[self.get_option("gemm_precision")]
 
     def set_option(self, key, value):
         self._check(self.lib.relax_set_option(self.h, key.encode(), int(value)), "relax_set_option")
+
+    def get_option(self, key):
+        v = C.c_int()
+        self._check(self.lib.relax_get_option(self.h, key.encode(), C.byref(v)), "relax_get_option")
+        return v.value
 
     def reserve(self, max_images):
         self._check(self.lib.relax_reserve(self.h, int(max_images)), "relax_reserve")

@@ -27,8 +27,10 @@ class LayerStackActivations(dict):
 
 def _frame_number(filename):
     # same naming rules as the reference (:63-79): fragment files carry their suffixes into the frame id
-    stem = filename.split(".")[0]
-    parts = stem.split("_")
+    # the reference splits the whole file name at '_' and strips the extension from the LAST part only (:64-79), so a
+    # dot earlier in the base name ("clip.v2_12_next.png") survives
+    parts = filename.split("_")
+    parts[-1] = parts[-1].split(".")[0]
     for marker, n in (("residual_of_imp", 4), ("residual_merged_frag", 4), ("residual_of", 3), ("residual_imp", 3),
                       ("ori_frag", 3)):
         if marker in filename:

@@ -1,8 +1,9 @@
 """Process-wide engine + weights, the counterpart of the reference's import-time globals
 (`resnet50 = models.resnet50(pretrained=True).to(device)`, src/extractor/visualise_resnet.py:17-21).
 Created lazily, never at import.  Weights: a torchvision / DINO state-dict file named by
-RELAX_RESNET50_WEIGHTS / RELAX_VIT_WEIGHTS when present, else the deterministic synthetic weights
-(there is no network in the build environment)."""
+RELAX_RESNET50_WEIGHTS / RELAX_VIT_WEIGHTS.  The reference always runs pretrained weights, so a missing
+variable is an error; the deterministic synthetic weights (there is no network in the build environment)
+are used only when RELAX_ALLOW_SYNTHETIC_WEIGHTS=1 says so, or when injected explicitly with set_weights()."""
 import logging
 import os
 
@@ -22,22 +23,32 @@ def _load_file(path):
     return {k: v.numpy() if hasattr(v, "numpy") else np.asarray(v) for k, v in sd.items()}
 
 
-def get_engine(device=0):
+def get_engine(device=None):
+    """The process-wide engine.  One process per GPU: the device defaults to LOCAL_RANK (torchrun)."""
     if _state["engine"] is None:
         from .engine import RelaxEngine
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
         _state["engine"] = RelaxEngine(device)
     return _state["engine"]
+
+
+def _weights_or_synthetic(env_var, what, make_synthetic):
+    path = os.environ.get(env_var)
+    if path:
+        return _load_file(path)
+    if os.environ.get("RELAX_ALLOW_SYNTHETIC_WEIGHTS") == "1":
+        log.warning("%s not set: using synthetic %s weights (RELAX_ALLOW_SYNTHETIC_WEIGHTS=1)", env_var, what)
+        return make_synthetic()
+    raise RuntimeError(
+        f"{env_var} is not set: point it at the pretrained {what} state dict (the reference loads pretrained weights), "
+        "inject weights with runtime.set_weights(), or set RELAX_ALLOW_SYNTHETIC_WEIGHTS=1 to run on random-init weights")
 
 
 def ensure_resnet50():
     eng = get_engine()
     if not _state["rn"]:
-        path = os.environ.get("RELAX_RESNET50_WEIGHTS")
-        if path:
-            sd = _load_file(path)
-        else:
-            log.warning("RELAX_RESNET50_WEIGHTS not set: using synthetic ResNet-50 weights")
-            sd = synth.resnet50_state_dict()
+        sd = _weights_or_synthetic("RELAX_RESNET50_WEIGHTS", "ResNet-50", synth.resnet50_state_dict)
         eng.load_resnet50(sd)
         _state["rn"] = True
     return eng
@@ -46,12 +57,7 @@ def ensure_resnet50():
 def ensure_vit(name_model="vit_base"):
     eng = get_engine()
     if _state["vit"] != name_model:
-        path = os.environ.get("RELAX_VIT_WEIGHTS")
-        if path:
-            sd = _load_file(path)
-        else:
-            log.warning("RELAX_VIT_WEIGHTS not set: using synthetic %s weights", name_model)
-            sd = synth.vit_state_dict(name_model)
+        sd = _weights_or_synthetic("RELAX_VIT_WEIGHTS", name_model, lambda: synth.vit_state_dict(name_model))
         eng.load_vit(sd, name_model)
         _state["vit"] = name_model
     return eng

@@ -1,0 +1,163 @@
+"""bf16x6 (csrc/gemm_x6.hip): fp32 operands as three bf16 planes, six partial products on the bf16 MFMA, fp32 accumulate.
+The claim under test is fp32-GRADE accuracy: against an fp64 reference its error is no larger than the exact-fp32 path's
+(v_mfma_f32_32x32x2_f32, an fp32 FMA chain), not merely "within the 1e-3 bar"."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_common import assert_close, engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+@pytest.fixture()
+def x6():
+    eng = engine()
+    eng.set_precision("bf16x6")
+    assert eng.precision() == "bf16x6"
+    yield eng
+    eng.set_precision("fp32")
+
+
+def test_permutation_matrix_copies_values_bit_for_bit(x6):
+    """W = a permutation matrix: out[m, n] = A[m, perm[n]] EXACTLY (x = hi + mid + lo is an exact split, every other
+    product is 0): checks the sp3 layout, the swizzled LDS image, the DMA piece map and the C write in one go; the
+    asymmetric permutation catches any transpose, M = 300 the zero-page rows past M."""
+    M, K = 300, 256
+    A = _rand(M, K, seed=1) * torch.logspace(-6, 6, K)[None, :]
+    for N in (256, 128, 64):
+        perm = torch.randperm(K, generator=torch.Generator().manual_seed(N))[:N]
+        W = torch.zeros(N, K)
+        W[torch.arange(N), perm] = 1.0
+        got = x6.op_gemm(A.cuda(), W.cuda()).cpu()
+        assert torch.equal(got, A[:, perm]), f"N={N}"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1000, 256, 512), (197 * 3, 2304, 768), (50, 64, 64), (4096, 64, 576),
+                                   (777, 3072, 768), (12608, 768, 3072), (2049, 384, 4608)])
+def test_error_is_no_larger_than_the_fp32_paths(M, N, K):
+    eng = engine()
+    A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    ref = A.double() @ W.double().T
+    eng.set_precision("fp32")
+    e32 = (eng.op_gemm(A.cuda(), W.cuda()).cpu().double() - ref).abs()
+    eng.set_precision("bf16x6")
+    try:
+        got = eng.op_gemm(A.cuda(), W.cuda())
+    finally:
+        eng.set_precision("fp32")
+    e6 = (got.cpu().double() - ref).abs()
+    scale = ref.abs().mean().item()
+    print(f"\\n{M}x{N}x{K}: mean |err| / mean |ref|: fp32 {e32.mean().item() / scale:.3e}  bf16x6 {e6.mean().item() / scale:.3e};"
+          f"  max: fp32 {e32.max().item() / scale:.3e}  bf16x6 {e6.max().item() / scale:.3e}")
+    assert_close(got, ref.float().numpy(), f"x6 gemm {M}x{N}x{K}")
+    assert e6.mean().item() <= 1.05 * e32.mean().item() + 1e-12, "bf16x6 mean error exceeds the fp32 FMA chain's"
+    assert e6.max().item() <= 1.5 * e32.max().item() + 1e-12, "bf16x6 worst error exceeds the fp32 FMA chain's"
+
+
+def test_wide_dynamic_range_operands():
+    """Values spanning 2^-40 .. 2^40 inside one row: every plane keeps fp32's exponent range (bf16 has fp32's exponent), so
+    nothing over- or underflows; what is left is how the matrix core aligns 16 products of very different size before its
+    single rounding.  Measured against the sum of magnitudes and beside the fp32 FMA chain on the same data."""
+    eng = engine()
+    M, N, K = 257, 128, 512
+    g = torch.Generator().manual_seed(5)
+    A = _rand(M, K, seed=3) * torch.exp2(torch.randint(-40, 41, (M, K), generator=g).float())
+    W = _rand(N, K, seed=4) * torch.exp2(torch.randint(-20, 21, (N, K), generator=g).float())
+    ref = A.double() @ W.double().T
+    mag = (A.double().abs() @ W.double().abs().T)
+    e32 = ((eng.op_gemm(A.cuda(), W.cuda()).cpu().double() - ref).abs() / mag)
+    eng.set_precision("bf16x6")
+    try:
+        e6 = ((eng.op_gemm(A.cuda(), W.cuda()).cpu().double() - ref).abs() / mag)
+    finally:
+        eng.set_precision("fp32")
+    print(f"\nerr / sum|a||w|: fp32 mean {e32.mean().item():.3e} max {e32.max().item():.3e}; bf16x6 mean {e6.mean().item():.3e} max {e6.max().item():.3e}")
+    assert e6.max().item() < 1e-6 and e6.mean().item() < 1.5e-7
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_epilogue(x6, act):
+    M, N, K = 333, 192, 96
+    A, W, b, r = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=0.1), _rand(N, seed=5), _rand(M, N, seed=6)
+    y = A.double() @ W.double().T + b.double() + r.double()
+    want = [y, F.relu(y), F.gelu(y)][act].float().numpy()
+    assert_close(x6.op_gemm(A.cuda(), W.cuda(), b.cuda(), r.cuda(), act=act), want, f"x6 epilogue act={act}")
+    rr = r.cuda().clone()
+    x6.op_gemm(A.cuda(), W.cuda(), b.cuda(), rr, act=act, out=rr)
+    assert_close(rr, want, f"x6 in-place residual act={act}")
+
+
+def test_split_k_is_deterministic_and_optional(x6):
+    """300 tiles of 256x256: 44 tail tiles are cut along K.  Same bits run to run; with gemm_split_k = 0 the bits do not
+    depend on how many rows travel together."""
+    M, N, K = 256 * 100, 768, 768
+    A, W = _rand(M, K, seed=8).cuda(), _rand(N, K, seed=9, scale=K ** -0.5).cuda()
+    a = x6.op_gemm(A, W)
+    b = x6.op_gemm(A, W)
+    assert torch.equal(a, b)
+    x6.set_option("gemm_split_k", 0)
+    try:
+        whole = x6.op_gemm(A, W)
+        part = x6.op_gemm(A[: 256 * 7], W)
+    finally:
+        x6.set_option("gemm_split_k", 1)
+    assert torch.equal(whole[: 256 * 7], part)
+    assert_close(a, whole.cpu().numpy(), "split-K vs whole-K", rtol=1e-4, atol_frac=1e-5)
+
+
+# ---- the ViT under bf16x6 -----------------------------------------------------------------------------------------------
+import os  # noqa: E402
+
+from oracle import fragment_ref, pooling_ref, vit_ref  # noqa: E402
+from tests.gpu_common import synth, vit_weights  # noqa: E402
+
+
+def _fragments(n, seed=0):
+    frs = []
+    for i in range(n):
+        o, nx = synth.synthetic_pair(240, 320, 500 + seed * 64 + i)
+        f = fragment_ref.fragment_pair(o, nx)
+        frs.append(f["ori_frag"] if i % 2 == 0 else f["diff_frag"])
+    return np.stack(frs)
+
+
+@pytest.mark.parametrize("name,heads", [("vit_tiny", 3), ("vit_base", 12)])
+def test_vit_matches_reference_golden_tokens_under_x6(golden_dir, x6, name, heads):
+    vit_weights(name)
+    z = np.load(os.path.join(golden_dir, f"{name}_tokens.npz"))
+    tokens, pooled = x6.vit_features(torch.from_numpy(z["frags"]).cuda(), tokens=True, pooled=True)
+    assert_close(tokens, z["tokens"], f"{name} tokens (bf16x6) vs reference VisionTransformer")
+    want = np.stack([pooling_ref.vit_pool_vector(t) for t in z["tokens"]])
+    assert_close(pooled, want, f"{name} pooled (bf16x6) vs reference process_video_feature")
+
+
+def test_vit_base_error_against_fp64_is_no_larger_than_the_fp32_paths():
+    """12 blocks deep: tokens of the fp32 path and of the bf16x6 path against an fp64 run of the oracle (same fp32
+    weights and inputs, all arithmetic in double)."""
+    sd = vit_weights("vit_base")
+    eng = engine()
+    frags = _fragments(3, seed=2)
+    sd64 = {k: v.double() for k, v in vit_ref.to_torch_state_dict(sd).items()}
+    ref = vit_ref.forward_tokens(sd64, vit_ref.preprocess_bgr_u8(frags).double(), 12).numpy()
+    f = torch.from_numpy(frags).cuda()
+    t32, _ = eng.vit_features(f, tokens=True, pooled=False)
+    eng.set_precision("bf16x6")
+    try:
+        t6, _ = eng.vit_features(f, tokens=True, pooled=False)
+        t6b, _ = eng.vit_features(f, tokens=True, pooled=False)
+    finally:
+        eng.set_precision("fp32")
+    assert torch.equal(t6, t6b), "bf16x6 is not deterministic"
+    e32 = np.abs(t32.cpu().numpy().astype(np.float64) - ref)
+    e6 = np.abs(t6.cpu().numpy().astype(np.float64) - ref)
+    n32 = np.linalg.norm(e32) / np.linalg.norm(ref)
+    n6 = np.linalg.norm(e6) / np.linalg.norm(ref)
+    print(f"\nvit_base tokens vs fp64: norm-rel fp32 {n32:.3e} bf16x6 {n6:.3e}; max abs fp32 {e32.max():.3e} bf16x6 {e6.max():.3e}")
+    assert n6 <= 1.1 * n32 and e6.max() <= 1.5 * e32.max()
