@@ -205,11 +205,23 @@ int relax_op_gap(relax_handle* h, const float* x, float* out, int Nimg, int HW, 
 int relax_op_token_stats(relax_handle* h, const float* x, float* out, int Nimg, int tokens, int dim,
                          relax_stream stream);
 
+/* Device-to-device copy on the caller's stream (the fragment batch of one backbone duplicated for the other). */
+int relax_copy_bytes(relax_handle* h, const void* src, void* dst, int64_t n_bytes, relax_stream stream);
+
+/* Per-clip mean over frames (src/demo_test.py:171-175, src/data_processing/extract_npy2mat.py:121-126) of one column block
+ * of a per-frame feature matrix: dst[s, dst_col0 + c] = mean of src[row0 + r, c] over r in [seg_offsets[s], seg_offsets[s+1]),
+ * c < ncols.  seg_offsets: HOST int32 [nseg + 1] (prefix sums of the frames per clip; passed to the kernel by value, so the
+ * call stays capturable into a HIP graph).  Rows are summed in order. */
+int relax_segment_mean(relax_handle* h, const float* src, int64_t src_stride, int ncols, int row0, const int32_t* seg_offsets,
+                       int nseg, float* dst, int64_t dst_stride, int dst_col0, relax_stream stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* While enabled, every launch of the contraction kernel (GEMM / implicit-GEMM conv) and of the patch-score
  * kernel is bracketed by HIP events on the caller's stream.  relax_profile_read synchronises those events and
- * returns totals since the last enable: kind 0 = contraction (work = FLOPs), kind 1 = patch score (work = bytes),
- * kind 2 = contraction again with work = its algorithmic HBM bytes (operands and results touched once). */
+ * returns totals since the last enable: kind 0 = fp32 / bf16x3 contraction launches (work = algorithmic FLOPs), kind 1 =
+ * patch score (work = bytes), kind 2 = kind 0 again with work = algorithmic HBM bytes (operands and results touched once),
+ * kind 3 / 4 = the same two views of the bf16x6 contraction launches, kind 5 = update_matrices_k, the dominant kernel of the
+ * Farneback stage (work = algorithmic bytes: 68 per pixel, level and iteration). */
 int relax_profile_enable(relax_handle* h, int on);
 int relax_profile_read(relax_handle* h, int kind, double* total_ms, double* total_work, int64_t* launches);
 

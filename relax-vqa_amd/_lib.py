@@ -45,6 +45,8 @@ PROTOTYPES = {
     "relax_op_bn_relu_maxpool": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "relax_op_gap": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int64, c_vp]),
     "relax_op_token_stats": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
+    "relax_copy_bytes": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
+    "relax_segment_mean": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int, C.c_int, c_vp, C.c_int, c_vp, C.c_int64, C.c_int, c_vp]),
     "relax_profile_enable": (C.c_int, [c_vp, C.c_int]),
     "relax_profile_read": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_int64)]),

@@ -210,10 +210,20 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     else if (k == "gemm_group_m") h->gemm.group_m = value > 0 ? value : 1;
     else if (k == "gemm_prio") h->gemm.prio = value;
     else if (k == "gemm_stagger") h->gemm.stagger = value > 0 ? value : 0;
+    else if (k == "flow_max_pairs") h->gemm.flow_max_pairs = value > 0 ? value : 0;
     else {
         set_error(h, "relax_set_option: unknown option '%s'", key);
         return RELAX_ERR_INVALID;
     }
+    return RELAX_OK;
+}
+
+int relax_copy_bytes(relax_handle* h, const void* src, void* dst, int64_t n_bytes, relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, src && dst && n_bytes >= 0, "relax_copy_bytes: bad arguments");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    if (n_bytes > 0)
+        RELAX_HIP_CHECK(h, hipMemcpyAsync(dst, src, (size_t)n_bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     return RELAX_OK;
 }
 
@@ -228,6 +238,7 @@ int relax_get_option(relax_handle* h, const char* key, int* value) {
     else if (k == "gemm_group_m") *value = h->gemm.group_m;
     else if (k == "gemm_prio") *value = h->gemm.prio;
     else if (k == "gemm_stagger") *value = h->gemm.stagger;
+    else if (k == "flow_max_pairs") *value = h->gemm.flow_max_pairs;
     else {
         set_error(h, "relax_get_option: unknown option '%s'", key);
         return RELAX_ERR_INVALID;
@@ -240,7 +251,7 @@ int relax_profile_enable(relax_handle* h, int on) {
     RELAX_TRY(prof_drain(h));
     h->prof.on = on != 0;
     if (on) {
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < Profiler::kKinds; ++k) {
             h->prof.total_ms[k] = 0;
             h->prof.total_work[k] = 0;
             h->prof.total_bytes[k] = 0;
@@ -252,11 +263,14 @@ int relax_profile_enable(relax_handle* h, int on) {
 
 int relax_profile_read(relax_handle* h, int kind, double* total_ms, double* total_work, int64_t* launches) {
     if (!h) return RELAX_ERR_INVALID;
-    RELAX_REQUIRE(h, kind >= 0 && kind <= 2, "relax_profile_read: kind must be 0, 1 or 2");
+    RELAX_REQUIRE(h, kind >= 0 && kind <= 5, "relax_profile_read: kind must be 0..5");
     RELAX_TRY(prof_drain(h));
-    const int k = kind == 2 ? 0 : kind;   // kind 2: the contraction launches again, work = algorithmic HBM bytes
+    // read kind -> (span kind, which total): 2 and 4 return the algorithmic HBM bytes of the contraction launches
+    static const int span_of[6] = {0, 1, 0, 2, 2, 3};
+    const int k = span_of[kind];
+    const bool bytes = kind == 2 || kind == 4;
     if (total_ms) *total_ms = h->prof.total_ms[k];
-    if (total_work) *total_work = kind == 2 ? h->prof.total_bytes[0] : h->prof.total_work[k];
+    if (total_work) *total_work = bytes ? h->prof.total_bytes[k] : h->prof.total_work[k];
     if (launches) *launches = h->prof.launches[k];
     return RELAX_OK;
 }

@@ -729,7 +729,14 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
             }
         }
         hipLaunchKernelGGL(poly_expansion, dim3((w + POLY_OUT - 1) / POLY_OUT, hh, P * 2), dim3(256), 0, s, Isrc, R, hh, w, pc);
+        // measurement (relax_profile_read kind 5): the dominant kernel of the stage, with its algorithmic bytes: per pixel
+        // 2 x 5 floats of R at the pixel + 5 floats of R1 gathered at the displaced position (counted once: neighbours share
+        // the lines) ... = 40 + 8 (flow) + 20 (M written) = 68 bytes
+        const double um_bytes = 68.0 * (double)hw * P;
+        int um_span;
+        RELAX_TRY(prof_begin(h, s, 3, um_bytes, &um_span));
         hipLaunchKernelGGL(update_matrices_k, g_lvl, dim3(256), 0, s, R, cur, M, hh, w);
+        RELAX_TRY(prof_end(h, s, um_span));
         {
             int seg = 135;   // a multiple of the 15-row ring period
             const int bands = (w + FUSE_OUT - 1) / FUSE_OUT;
@@ -737,7 +744,11 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
             const dim3 gf(bands, (hh + seg - 1) / seg, P);
             for (int it = 0; it < ITERS; ++it) {
                 hipLaunchKernelGGL(box_solve_fused, gf, dim3(256), 0, s, M, cur, hh, w, seg);
-                if (it < ITERS - 1) hipLaunchKernelGGL(update_matrices_k, g_lvl, dim3(256), 0, s, R, cur, M, hh, w);
+                if (it < ITERS - 1) {
+                    RELAX_TRY(prof_begin(h, s, 3, um_bytes, &um_span));
+                    hipLaunchKernelGGL(update_matrices_k, g_lvl, dim3(256), 0, s, R, cur, M, hh, w);
+                    RELAX_TRY(prof_end(h, s, um_span));
+                }
             }
         }
         prev_flow = cur;
@@ -772,6 +783,7 @@ int relax_optical_flow(relax_handle* h, const uint8_t* orig, const uint8_t* next
     int64_t ws_gb = 32;
     if (const char* e = getenv("RELAX_FLOW_WS_GB")) ws_gb = atoll(e) > 0 ? atoll(e) : ws_gb;
     int chunk = (int)((ws_gb << 30) / (HW * 112));
+    if (h->gemm.flow_max_pairs > 0 && chunk > h->gemm.flow_max_pairs) chunk = h->gemm.flow_max_pairs;   // tests: force the chunk loop
     if (chunk < 1) chunk = 1;
     if (chunk > T) chunk = T;
     for (int t0 = 0; t0 < T; t0 += chunk) {

@@ -739,7 +739,22 @@ int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const
     d.w = w; d.Cout = Cout;
     d.Kpad = ((KH * KW * Cin + 31) / 32) * 32;
     d.bias = bias; d.residual = residual; d.out = out; d.act = act;
-    return launch_conv(h, d, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->gemm.precision == 2 && Cin % 16 == 0 && d.Kpad == KH * KW * Cin) {
+        // operator-level entry under "bf16x6": input and weights are converted to split planes here
+        const size_t a_bytes = (size_t)Nimg * H * W * Cin * 6, w_bytes = (size_t)Cout * d.Kpad * 6;
+        RELAX_TRY(ensure_buf(h, h->sp3_ws, a_bytes + w_bytes + 256));
+        char* As = static_cast<char*>(h->sp3_ws.p);
+        char* Ws = As + ((a_bytes + 255) & ~(size_t)255);
+        RELAX_TRY(launch_to_sp3(h, in, Cin, As, (int64_t)Nimg * H * W, Cin, s));
+        RELAX_TRY(launch_to_sp3(h, w, d.Kpad, Ws, Cout, d.Kpad, s));
+        ConvDescX6 x{};
+        x.in = As; x.Nimg = Nimg; x.H = H; x.W = W; x.Cin = Cin; x.Ho = d.Ho; x.Wo = d.Wo;
+        x.KH = KH; x.KW = KW; x.stride = stride; x.pad = pad;
+        x.w = Ws; x.Cout = Cout; x.bias = bias; x.residual = residual; x.out = out; x.out_sp3 = nullptr; x.act = act;
+        return launch_conv_x6(h, x, s);
+    }
+    return launch_conv(h, d, s);
 }
 
 }  // extern "C"

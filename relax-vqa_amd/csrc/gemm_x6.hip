@@ -132,7 +132,7 @@ __device__ inline float act_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0
 #define X6_DMA(rsrc_, lds_off_, voff_, soff_)                                                                             \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_, (__attribute__((address_space(3))) void*)(smem + (lds_off_)), 16,     \
                                              voff_, soff_, 0, 0)
-constexpr unsigned kOutOfRange = 0x80000000u;   // > every num_records below: the DMA writes zeros for that lane
+[[maybe_unused]] constexpr unsigned kOutOfRange = 0x80000000u;   // > every num_records below: the DMA writes zeros for that lane
 constexpr int64_t kMaxRecords = 0x7ffffff0;
 
 // Tile BM x BN on 4 waves (2 x 2), TWO workgroups per CU (the epilogue / prologue of one runs under the MFMAs of the other),
@@ -640,7 +640,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     const double bytes = 6.0 * ((double)d.Nimg * d.H * d.W * d.Cin + (double)p.N * p.K) +
                          (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.residual ? 4.0 : 0.0));
     int span;
-    RELAX_TRY(prof_begin(h, s, 0, flops, &span, bytes));
+    RELAX_TRY(prof_begin(h, s, 2, flops, &span, bytes));
     int rc;
     // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA: K loop at 85 % of the
     // matrix rate).  The alternative measured against it, two 4-wave workgroups per CU on 128x256 tiles ("gemm_variant" 2),

@@ -307,8 +307,9 @@ int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, in
 }
 
 // ---- relu(bn(x)) then 3x3 / stride 2 / pad 1 max-pool, NHWC, 4 channels per thread ---------------------------
+template <bool SP3>   // SP3: the pooled map leaves as split planes (bf16 hi + mid + lo) for the bf16x6 convolutions of layer1
 __global__ __launch_bounds__(256) void bn_relu_maxpool_nhwc(const float* __restrict__ x, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, float* __restrict__ y,
+                                                            const float* __restrict__ shift, void* __restrict__ yv,
                                                             int Nimg, int H, int W, int C) {
     const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
     const int64_t total = (int64_t)Nimg * Ho * Wo * C4;
@@ -338,14 +339,35 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_nhwc(const float* __restr
             m.w = fmaxf(m.w, fmaxf(v.w * sc.w + sh.w, 0.f));
         }
     }
-    reinterpret_cast<float4*>(y + (((int64_t)n * Ho + oy) * Wo + ox) * C)[c4] = m;
+    const int64_t opix = ((int64_t)n * Ho + oy) * Wo + ox;
+    if (SP3) {
+        uint2 hi, mid, lo;
+        ln_split3_pair(m.x, m.y, hi.x, mid.x, lo.x);
+        ln_split3_pair(m.z, m.w, hi.y, mid.y, lo.y);
+        char* d = static_cast<char*>(yv) + opix * C * 6 + (c4 >> 2) * 96 + (c4 & 3) * 8;
+        *reinterpret_cast<uint2*>(d) = hi;
+        *reinterpret_cast<uint2*>(d + 32) = mid;
+        *reinterpret_cast<uint2*>(d + 64) = lo;
+    } else {
+        reinterpret_cast<float4*>(static_cast<float*>(yv) + opix * C)[c4] = m;
+    }
 }
 
 int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
                            int Nimg, int H, int W, int C, hipStream_t s) {
     RELAX_REQUIRE(h, Nimg > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "bn_relu_maxpool: bad shape");
     const int64_t total = (int64_t)Nimg * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, y,
+    hipLaunchKernelGGL(bn_relu_maxpool_nhwc<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, y,
+                       Nimg, H, W, C);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+int launch_bn_relu_maxpool_sp3(relax_handle* h, const float* x, const float* scale, const float* shift, void* y_sp3,
+                               int Nimg, int H, int W, int C, hipStream_t s) {
+    RELAX_REQUIRE(h, Nimg > 0 && H % 2 == 0 && W % 2 == 0 && C % 16 == 0, "bn_relu_maxpool_sp3: bad shape");
+    const int64_t total = (int64_t)Nimg * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_nhwc<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, y_sp3,
                        Nimg, H, W, C);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
@@ -440,11 +462,50 @@ int launch_nhwc_to_nchw(relax_handle* h, const float* x, float* y, int Nimg, int
     return RELAX_OK;
 }
 
+// ---- per-clip mean over frames (src/demo_test.py:171-175; src/data_processing/extract_npy2mat.py:121-126) --------------------
+// dst[s, dst_col0 + c] = mean over the rows [row0 + off[s], row0 + off[s+1]) of src[:, c]: rows summed in order, then one
+// division (numpy's mean over axis 0 does the same), so a clip's vector does not depend on which batch it travelled in
+constexpr int kSegChunk = 64;
+struct SegOffsets {   // passed by value: nothing to copy to the device, and a captured launch (HIP graph) keeps its own copy
+    int32_t off[kSegChunk + 1];
+};
+
+__global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ src, int64_t src_stride, int ncols, int row0,
+                                                           const SegOffsets so, int seg0, float* __restrict__ dst,
+                                                           int64_t dst_stride, int dst_col0) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    const int sgm = seg0 + blockIdx.y;
+    const int lo = so.off[blockIdx.y], hi = so.off[blockIdx.y + 1];
+    const float* p = src + (int64_t)(row0 + lo) * src_stride + c;
+    float t = 0.f;
+    for (int r = lo; r < hi; ++r, p += src_stride) t += *p;
+    dst[(int64_t)sgm * dst_stride + dst_col0 + c] = t / (float)(hi - lo);
+}
+
 }  // namespace relax
 
 using namespace relax;
 
 extern "C" {
+
+int relax_segment_mean(relax_handle* h, const float* src, int64_t src_stride, int ncols, int row0, const int32_t* seg_offsets,
+                       int nseg, float* dst, int64_t dst_stride, int dst_col0, relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, src && seg_offsets && dst && ncols > 0 && nseg > 0 && row0 >= 0, "relax_segment_mean: bad arguments");
+    for (int i = 0; i < nseg; ++i)
+        RELAX_REQUIRE(h, seg_offsets[i + 1] > seg_offsets[i] && seg_offsets[0] >= 0, "relax_segment_mean: segment %d is empty or out of order", i);
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    for (int s0 = 0; s0 < nseg; s0 += kSegChunk) {
+        const int n = nseg - s0 < kSegChunk ? nseg - s0 : kSegChunk;
+        SegOffsets so;
+        for (int i = 0; i <= n; ++i) so.off[i] = seg_offsets[s0 + i];
+        hipLaunchKernelGGL(segment_mean_kernel, dim3((ncols + 255) / 256, n), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                           src_stride, ncols, row0, so, s0, dst, dst_stride, dst_col0);
+    }
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
 
 int relax_op_layernorm(relax_handle* h, const float* x, const float* gamma, const float* beta, float* y, int rows,
                        int dim, float eps, relax_stream stream) {

@@ -84,6 +84,7 @@ struct ConvDescX6 {
 // ---- model weights ------------------------------------------------------------------------------
 struct ConvW {          // one folded conv (+BN) of ResNet-50
     float* w = nullptr;     // device [Cout][Kpad]
+    void* w_sp3 = nullptr;  // the same as split planes (bf16x6 kernel); null for conv1 (Cin = 4 stays on the fp32 kernel)
     float* bias = nullptr;  // device [Cout] (null for the raw conv1)
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, Kpad = 0;
 };
@@ -155,10 +156,12 @@ struct Profiler {
     bool on = false;
     std::vector<ProfSpan> spans;
     std::vector<hipEvent_t> pool;
-    double total_ms[2] = {0, 0};
-    double total_work[2] = {0, 0};
-    double total_bytes[2] = {0, 0};
-    int64_t launches[2] = {0, 0};
+    // span kinds: 0 fp32 / bf16x3 contraction, 1 patch score, 2 bf16x6 contraction, 3 Farneback matrix update
+    static constexpr int kKinds = 4;
+    double total_ms[kKinds] = {};
+    double total_work[kKinds] = {};
+    double total_bytes[kKinds] = {};
+    int64_t launches[kKinds] = {};
 };
 
 }  // namespace relax
@@ -166,12 +169,13 @@ struct Profiler {
 namespace relax {
 // Tuning / reproducibility switches of the contraction kernel (relax_set_option; env defaults RELAX_GEMM_*).
 struct GemmOptions {
-    int precision = 0; // "gemm_precision": 0 = exact fp32 MFMA, 1 = bf16x3 split products (~1e-5 relative), 2 = bf16x6 (fp32-grade)
+    int precision = 2; // "gemm_precision": 2 = bf16x6 (default, fp32-grade), 0 = exact fp32 MFMA, 1 = bf16x3 split products (~1e-5 relative)
     int split_k = 1;   // "gemm_split_k": tail split-K on (1) / off (0: K sums are batch-invariant bit for bit)
     int variant = -1;  // "gemm_variant": pin the tile variant for N % 128 == 0 problems, -1 = automatic
     int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)
     int group_m = 8;   // "gemm_group_m": row-tiles per L2 group
     int prio = 0;      // "gemm_prio": s_setprio around the MFMA cluster
+    int flow_max_pairs = 0;  // "flow_max_pairs": cap on the pairs per optical-flow chunk (0 = by workspace size only)
     int stagger = 0;   // "gemm_stagger": bf16x6 per-XCD stagger of the first round of tiles, in % of one tile time (0 = off)
 };
 }  // namespace relax
@@ -236,6 +240,8 @@ int launch_layernorm_sp3(relax_handle* h, const float* x, const float* g, const 
 int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s);
 int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
                            int Nimg, int H, int W, int C, hipStream_t s);
+int launch_bn_relu_maxpool_sp3(relax_handle* h, const float* x, const float* scale, const float* shift, void* y_sp3,
+                               int Nimg, int H, int W, int C, hipStream_t s);
 int launch_gap(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,
                hipStream_t s);
 int launch_nhwc_to_nchw(relax_handle* h, const float* x, float* y, int Nimg, int HW, int C, hipStream_t s);

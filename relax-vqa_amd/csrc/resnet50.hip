@@ -156,8 +156,25 @@ static constexpr size_t kT2 = 56 * 56 * 64;         // largest conv2 output
 static constexpr size_t kGapWs = 16 * 2048;         // GAP partial sums
 static constexpr size_t kAvg = 2048;
 static constexpr size_t kRnFloatsPerImage = kX0 + 3 * kBig + kT1 + kT2 + kGapWs + kAvg;
+// bf16x6 path: block inputs / outputs exist twice (fp32 for the residual add and the taps, split planes = 1.5 floats per
+// value for the next convolutions), the intermediates of a block only as split planes
+static constexpr size_t kRnFloatsPerImageX6 = kX0 + 3 * kBig + 2 * (kBig * 3 / 2) + (kT1 + kT2) * 3 / 2 + kGapWs + kAvg;
 
-size_t resnet_arena_bytes(int n) { return sizeof(float) * kRnFloatsPerImage * (size_t)n; }
+size_t resnet_arena_bytes(int n) {
+    return sizeof(float) * (kRnFloatsPerImage > kRnFloatsPerImageX6 ? kRnFloatsPerImage : kRnFloatsPerImageX6) * (size_t)n;
+}
+
+static int run_conv_x6(relax_handle* h, const ConvW& c, const void* in_sp3, int Nimg, int H, int W, const float* residual,
+                       float* out, void* out_sp3, int act, hipStream_t s) {
+    ConvDescX6 d{};
+    d.in = in_sp3; d.Nimg = Nimg; d.H = H; d.W = W; d.Cin = c.Cin;
+    d.Ho = (H + 2 * c.pad - c.KH) / c.stride + 1;
+    d.Wo = (W + 2 * c.pad - c.KW) / c.stride + 1;
+    d.KH = c.KH; d.KW = c.KW; d.stride = c.stride; d.pad = c.pad;
+    d.w = c.w_sp3; d.Cout = c.Cout;
+    d.bias = c.bias; d.residual = residual; d.out = out; d.out_sp3 = out_sp3; d.act = act;
+    return launch_conv_x6(h, d, s);
+}
 
 static int run_conv(relax_handle* h, const ConvW& c, const float* in, int Nimg, int H, int W, const float* residual,
                     float* out, int act, hipStream_t s, double flops = 0) {
@@ -230,6 +247,33 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
             cin = width * 4;
         }
     }
+    // split planes of every convolution but conv1 for the bf16x6 kernel (made on the device from the packed fp32 copy)
+    for (Bottleneck& blk : rn.blocks) {
+        for (ConvW* c : {&blk.c1, &blk.c2, &blk.c3, &blk.down}) {
+            if (!c->w) continue;
+            const int K = c->KH * c->KW * c->Cin;
+            if (K != c->Kpad || c->Cin % 16 != 0) {
+                set_error(h, "resnet50: conv K=%d (padded %d) does not fit the split-plane layout", K, c->Kpad);
+                free_resnet(h);
+                return RELAX_ERR_INVALID;
+            }
+            void* q = nullptr;
+            if (hipMalloc(&q, (size_t)c->Cout * K * 6) != hipSuccess) {
+                set_error(h, "resnet50: hipMalloc of split-plane weights failed");
+                free_resnet(h);
+                return RELAX_ERR_NOMEM;
+            }
+            rn.allocs.push_back(q);
+            c->w_sp3 = q;
+            rc = launch_to_sp3(h, c->w, K, q, c->Cout, K, nullptr);
+            if (rc != RELAX_OK) { free_resnet(h); return rc; }
+        }
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {
+        set_error(h, "resnet50: weight conversion failed");
+        free_resnet(h);
+        return RELAX_ERR_HIP;
+    }
     rn.loaded = true;
     return RELAX_OK;
 }
@@ -270,6 +314,57 @@ int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float*
     // conv1 7x7/2 (raw), algorithmic FLOPs use the real 3 input channels
     RELAX_TRY(run_conv(h, rn.conv1, X0, N, 224, 224, nullptr, bufA, 0, s, 2.0 * N * 112.0 * 112.0 * 64.0 * 147.0));
     RELAX_TRY(emit_tap(0, bufA));
+    if (h->gemm.precision == 2) {
+        // bf16x6: conv1 (Cin = 4) stays on the exact-fp32 kernel; from the max-pool on, every convolution input travels as
+        // split planes written by its producer, and block outputs are written twice (fp32: residual / taps; planes: next convs)
+        float* f32a = bufB;                                   // block in / out, fp32 (ping-pong with f32b)
+        float* f32b = bufD;
+        float* D = bufA;                                      // downsample branch, fp32 (conv1's raw map is dead after the pool)
+        char* spa = reinterpret_cast<char*>(T1);              // carve the rest of the arena anew
+        char* spb = spa + sizeof(float) * (kBig * 3 / 2) * n;
+        char* T1s = spb + sizeof(float) * (kBig * 3 / 2) * n;
+        char* T2s = T1s + sizeof(float) * (kT1 * 3 / 2) * n;
+        float* gapws6 = reinterpret_cast<float*>(T2s + sizeof(float) * (kT2 * 3 / 2) * n);
+        float* avg6 = gapws6 + kGapWs * n;
+        gapws = gapws6;
+        RELAX_TRY(launch_bn_relu_maxpool_sp3(h, bufA, rn.bn1_scale, rn.bn1_shift, spa, N, 112, 112, 64, s));
+        const float* cur32 = nullptr;                         // the pooled map is only ever a convolution input
+        char* cursp = spa;
+        char* othersp = spb;
+        float* out32 = f32a;
+        int H = 56;
+        for (const Bottleneck& blk : rn.blocks) {
+            const int Ho = H / blk.c2.stride;
+            RELAX_TRY(run_conv_x6(h, blk.c1, cursp, N, H, H, nullptr, nullptr, T1s, 1, s));
+            RELAX_TRY(run_conv_x6(h, blk.c2, T1s, N, H, H, nullptr, nullptr, T2s, 1, s));
+            const float* identity = cur32;
+            if (blk.has_down) {
+                RELAX_TRY(run_conv_x6(h, blk.down, cursp, N, H, H, nullptr, D, nullptr, 0, s));
+                identity = D;
+            }
+            RELAX_TRY(run_conv_x6(h, blk.c3, T2s, N, Ho, Ho, identity, out32, othersp, 1, s));
+            cur32 = out32;
+            out32 = out32 == f32a ? f32b : f32a;
+            char* t = cursp; cursp = othersp; othersp = t;
+            H = Ho;
+            if (blk.tap >= 0) RELAX_TRY(emit_tap(blk.tap, cur32));
+        }
+        if (pool) {
+            const float* avg_src;
+            int64_t avg_stride;
+            if (layer_stack) {
+                avg_src = layer_stack + (RELAX_RN50_LAYER_STACK_DIM - 2048);
+                avg_stride = RELAX_RN50_LAYER_STACK_DIM;
+            } else {
+                RELAX_TRY(launch_gap_ws(h, cur32, avg6, N, 49, 2048, 2048, gapws, s));
+                avg_src = avg6;
+                avg_stride = 2048;
+            }
+            hipLaunchKernelGGL(rn_pool_stats, dim3(N), dim3(256), 0, s, avg_src, avg_stride, pool);
+            RELAX_HIP_CHECK(h, hipGetLastError());
+        }
+        return RELAX_OK;
+    }
     RELAX_TRY(launch_bn_relu_maxpool(h, bufA, rn.bn1_scale, rn.bn1_shift, bufB, N, 112, 112, 64, s));
     float* cur = bufB;
     float* other = bufA;

@@ -1,7 +1,9 @@
 """Host side of the MI355X feature-extraction engine.
 
-PyTorch-ROCm is plumbing only (device memory, streams, torch.distributed); all
-compute goes through the C-ABI of librelax_hip.so (include/relax_hip.h).
+PyTorch-ROCm is plumbing only (device memory allocation, streams, torch.distributed, tiny host-to-device copies of
+index vectors); all compute of the clip paths (clip_vectors / full_clip_vectors: fragments, backbones, per-clip means) goes
+through the C-ABI of librelax_hip.so (include/relax_hip.h) - the fragments are written straight into the batch buffer the
+backbones read and the per-clip means straight into the result matrix, so no aten kernel runs in between.
 Array-in / array-out counterparts of the reference's path-based functions:
 
   fragment_pairs      <- cv2.absdiff + process_patches('frame_diff') + get_original_frame_patches
@@ -152,9 +154,10 @@ class RelaxEngine:
             raise TypeError(f"expected uint8, got {a.dtype}")
         return a.contiguous()
 
-    def fragment_pairs(self, frames, top_n=TOP_N, want_scores=False):
+    def fragment_pairs(self, frames, top_n=TOP_N, want_scores=False, out_ori=None, out_diff=None):
         """frames: uint8 [T,2,H,W,3] BGR (frames[t,0] = sampled frame, frames[t,1] = the next one).
-        -> dict(positions int32 [T,196,2], counts int32 [T], ori_frag, diff_frag uint8 [T,224,224,3][, scores])"""
+        -> dict(positions int32 [T,196,2], counts int32 [T], ori_frag, diff_frag uint8 [T,224,224,3][, scores])
+        out_ori / out_diff: optional preallocated [T,224,224,3] uint8 views (slices of a batch buffer) to write into."""
         frames = self._dev_u8(frames)
         if frames.dim() != 5 or frames.shape[1] != 2 or frames.shape[4] != 3:
             raise ValueError(f"frames must be [T,2,H,W,3], got {tuple(frames.shape)}")
@@ -162,8 +165,11 @@ class RelaxEngine:
         dev = self.device
         positions = torch.empty((T, TOP_N, 2), dtype=torch.int32, device=dev)
         counts = torch.empty((T,), dtype=torch.int32, device=dev)
-        ori = torch.empty((T, TARGET, TARGET, 3), dtype=torch.uint8, device=dev)
-        diff = torch.empty((T, TARGET, TARGET, 3), dtype=torch.uint8, device=dev)
+        ori = out_ori if out_ori is not None else torch.empty((T, TARGET, TARGET, 3), dtype=torch.uint8, device=dev)
+        diff = out_diff if out_diff is not None else torch.empty((T, TARGET, TARGET, 3), dtype=torch.uint8, device=dev)
+        for o in (ori, diff):
+            if o.dtype != torch.uint8 or tuple(o.shape) != (T, TARGET, TARGET, 3) or not o.is_contiguous():
+                raise ValueError("fragment_pairs: output buffers must be contiguous uint8 [T,224,224,3]")
         scores = torch.empty((T, (H // 16) * (W // 16)), dtype=torch.int32, device=dev) if want_scores else None
         frame_bytes = H * W * 3
         base = frames.data_ptr()
@@ -176,7 +182,7 @@ class RelaxEngine:
             out["scores"] = scores.view(T, H // 16, W // 16)
         return out
 
-    def fragment_image(self, images, top_n=TOP_N, want_scores=False):
+    def fragment_image(self, images, top_n=TOP_N, want_scores=False, out=None):
         """images: uint8 [T,H,W,3] residual images (e.g. flow_to_rgb output). -> dict(positions, counts, frag[, scores])"""
         images = self._dev_u8(images)
         if images.dim() != 4 or images.shape[3] != 3:
@@ -185,7 +191,7 @@ class RelaxEngine:
         dev = self.device
         positions = torch.empty((T, TOP_N, 2), dtype=torch.int32, device=dev)
         counts = torch.empty((T,), dtype=torch.int32, device=dev)
-        frag = torch.empty((T, TARGET, TARGET, 3), dtype=torch.uint8, device=dev)
+        frag = out if out is not None else torch.empty((T, TARGET, TARGET, 3), dtype=torch.uint8, device=dev)
         scores = torch.empty((T, (H // 16) * (W // 16)), dtype=torch.int32, device=dev) if want_scores else None
         rc = self.lib.relax_fragment_image(self.h, _ptr(images), H * W * 3, T, H, W, int(top_n), _ptr(positions),
                                            _ptr(counts), _ptr(frag), _ptr(scores), _stream())
@@ -206,11 +212,12 @@ class RelaxEngine:
         self._check(rc, "relax_gather_patches")
         return frag
 
-    def merge_fragments(self, a, b):
+    def merge_fragments(self, a, b, out=None):
         a, b = self._dev_u8(a), self._dev_u8(b)
         if a.shape != b.shape:
             raise ValueError("merge_fragments: shape mismatch")
-        out = torch.empty_like(a)
+        if out is None:
+            out = torch.empty_like(a)
         self._check(self.lib.relax_merge_fragments(self.h, _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()),
                     "relax_merge_fragments")
         return out
@@ -239,7 +246,7 @@ class RelaxEngine:
         self._check(self.lib.relax_flow_to_rgb(self.h, _ptr(flow), T, H, W, _ptr(out), _stream()), "relax_flow_to_rgb")
         return out
 
-    def resize_frames(self, frames, bilinear=True, lanczos=True):
+    def resize_frames(self, frames, bilinear=True, lanczos=True, out_bilinear=None, out_lanczos=None):
         """frames uint8 [N,H,W,3] -> (bilinear, lanczos) uint8 [N,224,224,3] each (None if not requested), bit-identical
         to PIL's Image.resize((224,224), BILINEAR / LANCZOS) (the reference's whole-frame inputs)."""
         if isinstance(frames, np.ndarray):
@@ -251,8 +258,10 @@ class RelaxEngine:
         if frames.stride()[1:] != (W * 3, 3, 1):      # items may be strided (e.g. clip[:, 0]); pixels must be packed
             frames = frames.contiguous()
         item_stride = frames.stride(0) if N > 1 else H * W * 3
-        ob = torch.empty((N, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device) if bilinear else None
-        ol = torch.empty((N, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device) if lanczos else None
+        ob = (out_bilinear if out_bilinear is not None else
+              torch.empty((N, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device)) if bilinear else None
+        ol = (out_lanczos if out_lanczos is not None else
+              torch.empty((N, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device)) if lanczos else None
         self._check(self.lib.relax_resize_frames(self.h, _ptr(frames), item_stride, N, H, W, _ptr(ob), _ptr(ol), _stream()),
                     "relax_resize_frames")
         return ob, ol
@@ -324,25 +333,37 @@ class RelaxEngine:
             out["vit"] = torch.cat([pooled[:T], pooled[T:]], dim=1)
         return out
 
+    def _segment_means(self, out, blocks, counts):
+        """out [len(counts), F] <- per-clip means; blocks: list of (src [rows, cols] fp32, first row, dst column)."""
+        offs = np.ascontiguousarray(np.concatenate([[0], np.cumsum(counts)]), dtype=np.int32)   # host array, passed by value
+        for src, row0, col0 in blocks:
+            rc = self.lib.relax_segment_mean(self.h, _ptr(src), src.stride(0), src.shape[1], row0, C.c_void_p(offs.ctypes.data), len(counts),
+                                             _ptr(out), out.stride(0), col0, _stream())
+            self._check(rc, "relax_segment_mean")
+        return out
+
     def clip_vectors(self, clips, resnet=True, vit=True):
         """Several clips (list of uint8 [T,2,H,W,3] device tensors, any mix of resolutions) in ONE batched pass of
         both backbones -> fp32 [len(clips), F] per-clip mean vectors.  Bigger batches fill the 256 CUs better
         (more tiles per launch, fewer partial rounds); results per clip do not depend on the batching."""
-        frs = [self.fragment_pairs(c) for c in clips]
-        counts = [f["ori_frag"].shape[0] for f in frs]
-        ori = torch.cat([f["ori_frag"] for f in frs], dim=0)
-        res = torch.cat([f["diff_frag"] for f in frs], dim=0)
-        n = ori.shape[0]
-        both = torch.cat([ori, res], dim=0)
-        parts = []
+        counts = [int(c.shape[0]) for c in clips]
+        n = sum(counts)
+        both = torch.empty((2 * n, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device)   # [originals | residuals]
+        at = 0
+        for c, t in zip(clips, counts):
+            self.fragment_pairs(c, out_ori=both[at:at + t], out_diff=both[n + at:n + at + t])
+            at += t
+        F = (LAYER_STACK_DIM + RN50_POOL_DIM if resnet else 0) + (6 * self.vit_dim if vit else 0)
+        out = torch.empty((len(clips), F), dtype=torch.float32, device=self.device)
+        blocks, col = [], 0
         if resnet:
             ls, pool = self.resnet50_features(both, layer_stack=True, pool=True)
-            parts.append(torch.cat([ls[:n], pool[n:]], dim=1))
+            blocks += [(ls, 0, 0), (pool, n, LAYER_STACK_DIM)]
+            col = LAYER_STACK_DIM + RN50_POOL_DIM
         if vit:
             _, pooled = self.vit_features(both, tokens=False, pooled=True)
-            parts.append(torch.cat([pooled[:n], pooled[n:]], dim=1))
-        per_frame = torch.cat(parts, dim=1)
-        return torch.stack([chunk.mean(dim=0) for chunk in torch.split(per_frame, counts, dim=0)])
+            blocks += [(pooled, 0, col), (pooled, n, col + 3 * self.vit_dim)]
+        return self._segment_means(out, blocks, counts)
 
     def whole_frame_features(self, frames):
         """frames uint8 [N,H,W,3] BGR (whole sampled frames) -> (ResNet-50 layer-stack fp32 [N,13120], ViT pooled
@@ -353,40 +374,62 @@ class RelaxEngine:
         _, vp = self.vit_features(lan, tokens=False, pooled=True)
         return ls, vp
 
-    def full_clip_vector(self, frames, flow_images=None, flow=False):
+    def full_clip_vector(self, frames, flow_images=None, flow=False, whole_frames=None):
         """frames uint8 [T,2,H,W,3] -> fp32 [35203]: the vector src/demo_test.py:171-175 assembles
         (whole-frame ResNet-50 LS | whole-frame ViT | fragment ResNet-50 LS+pool | fragment ViT x2), each part averaged
-        over the sampled frames.  Without flow_images the residual fragment is the frame-difference fragment alone."""
-        f = self.extract_clip(frames, flow_images=flow_images, flow=flow)
-        ls, vp = self.whole_frame_features(frames[:, 0])
-        return torch.cat([ls.mean(dim=0), vp.mean(dim=0), f["resnet"].mean(dim=0), f["vit"].mean(dim=0)])
+        over the sampled frames.  Without flow_images the residual fragment is the frame-difference fragment alone.
+        whole_frames uint8 [Ts,H,W,3]: all sampled frames when the last one has no pair (see full_clip_vectors)."""
+        return self.full_clip_vectors([frames], flow=flow, flow_images=None if flow_images is None else [flow_images],
+                                      whole_frames=None if whole_frames is None else [whole_frames])[0]
 
-    def full_clip_vectors(self, clips, flow=True, flow_images=None):
+    def full_clip_vectors(self, clips, flow=True, flow_images=None, whole_frames=None):
         """Several clips -> fp32 [len(clips), 35203] in ONE batched pass of each backbone (3*T fragments / frames per
-        clip: original fragment, residual fragment, whole frame).  Same layout as full_clip_vector."""
-        ori, res, bil, lan, counts = [], [], [], [], []
-        for i, c in enumerate(clips):
-            fr = self.fragment_pairs(c)
-            r = fr["diff_frag"]
+        clip: original fragment, residual fragment, whole frame).  Same layout as full_clip_vector.
+        whole_frames: optional list of uint8 [Ts,H,W,3] per clip - ALL sampled frames (src/demo_test.py:76-87 averages the
+        whole-frame features over every sampled frame, including a last one that has no `next` partner and therefore no
+        pair); default: the first frame of every pair."""
+        counts = [int(c.shape[0]) for c in clips]
+        wf = [c[:, 0] for c in clips] if whole_frames is None else list(whole_frames)
+        wcounts = [int(w.shape[0]) for w in wf]
+        n, nw = sum(counts), sum(wcounts)
+        rn_in = torch.empty((2 * n + nw, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device)   # [ori | residual | bilinear]
+        vit_in = torch.empty((2 * n + nw, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device)  # [ori | residual | lanczos]
+        at = aw = 0
+        for i, (c, t) in enumerate(zip(clips, counts)):
+            res = rn_in[n + at:n + at + t]
+            self.fragment_pairs(c, out_ori=rn_in[at:at + t], out_diff=res)
             fimg = None if flow_images is None else flow_images[i]
             if flow and fimg is None:
                 _, fimg = self.optical_flow(c)
             if fimg is not None:
-                r = self.merge_fragments(r, self.fragment_image(fimg)["frag"])
-            b, l = self.resize_frames(c[:, 0])
-            ori.append(fr["ori_frag"]); res.append(r); bil.append(b); lan.append(l)
-            counts.append(r.shape[0])
-        n = sum(counts)
-        ls, pool = self.resnet50_features(torch.cat(ori + res + bil, dim=0), layer_stack=True, pool=True)
-        _, vp = self.vit_features(torch.cat(ori + res + lan, dim=0), tokens=False, pooled=True)
-        per_frame = torch.cat([ls[2 * n:], vp[2 * n:], ls[:n], pool[n:2 * n], vp[:n], vp[n:2 * n]], dim=1)
-        return torch.stack([chunk.mean(dim=0) for chunk in torch.split(per_frame, counts, dim=0)])
+                self.merge_fragments(res, self.fragment_image(fimg)["frag"], out=res)
+            tw = wcounts[i]
+            self.resize_frames(wf[i], out_bilinear=rn_in[2 * n + aw:2 * n + aw + tw], out_lanczos=vit_in[2 * n + aw:2 * n + aw + tw])
+            at += t
+            aw += tw
+        self._check(self.lib.relax_copy_bytes(self.h, _ptr(rn_in), _ptr(vit_in), 2 * n * TARGET * TARGET * 3, _stream()),
+                    "relax_copy_bytes")   # the fragments are the same for both backbones
+        ls, pool = self.resnet50_features(rn_in, layer_stack=True, pool=True)
+        _, vp = self.vit_features(vit_in, tokens=False, pooled=True)
+        d = self.vit_dim
+        out = torch.empty((len(clips), LAYER_STACK_DIM + 3 * d + LAYER_STACK_DIM + RN50_POOL_DIM + 6 * d), dtype=torch.float32,
+                          device=self.device)
+        c0 = LAYER_STACK_DIM + 3 * d
+        self._segment_means(out, [(ls, 2 * n, 0), (vp, 2 * n, LAYER_STACK_DIM)], wcounts)
+        return self._segment_means(out, [(ls, 0, c0), (pool, n, c0 + LAYER_STACK_DIM),
+                                         (vp, 0, c0 + LAYER_STACK_DIM + RN50_POOL_DIM),
+                                         (vp, n, c0 + LAYER_STACK_DIM + RN50_POOL_DIM + 3 * d)], counts)
 
     def clip_vector(self, frames, **kw):
         """Per-clip mean over frames of the concatenated features (src/demo_test.py:171-175)."""
         f = self.extract_clip(frames, **kw)
-        parts = [f[k].mean(dim=0) for k in ("resnet", "vit") if k in f]
-        return torch.cat(parts)
+        parts = [f[k] for k in ("resnet", "vit") if k in f]
+        out = torch.empty((1, sum(p.shape[1] for p in parts)), dtype=torch.float32, device=self.device)
+        blocks, col = [], 0
+        for p in parts:
+            blocks.append((p, 0, col))
+            col += p.shape[1]
+        return self._segment_means(out, blocks, [int(parts[0].shape[0])])[0]
 
     # ---- operator level (tests / benches) -------------------------------------------------------
     def op_gemm(self, A, W, bias=None, residual=None, act=0, out=None):

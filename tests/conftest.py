@@ -33,3 +33,24 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _engine_precision_is_restored(request):
+    """GPU tests share one engine: whatever arithmetic a test switches to, the next test starts from the default again."""
+    if "gpu" not in request.keywords or not _have_gpu():
+        yield
+        return
+    from tests.gpu_common import engine
+    eng = engine()
+    eng.set_precision("bf16x6")
+    yield
+    eng.set_precision("bf16x6")
+
+
+@pytest.fixture(params=["bf16x6", "fp32"])
+def each_precision(request):
+    """Parity tests that must hold on both fp32-grade arithmetics of the contraction kernels."""
+    from tests.gpu_common import engine
+    engine().set_precision(request.param)
+    return request.param

@@ -21,7 +21,7 @@ def _fragments(n, seed=0):
     return np.stack(frs)
 
 
-def test_resnet50_taps_and_features():
+def test_resnet50_taps_and_features(each_precision):
     sd = rn50_weights()
     frags = _fragments(3)
     ls, pool, taps = engine().resnet50_features(torch.from_numpy(frags).cuda(), taps=range(15))
@@ -40,7 +40,7 @@ def test_resnet50_taps_and_features():
     assert_close(pool[:, 2048:], want_pool[:, 2048:], "pool stats (mean,max,std)")
 
 
-def test_resnet50_pool_only_and_batch_independence():
+def test_resnet50_pool_only_and_batch_independence(each_precision):
     rn50_weights()
     frags = _fragments(5, seed=1)
     ls_all, pool_all = engine().resnet50_features(torch.from_numpy(frags).cuda())
@@ -65,7 +65,7 @@ def test_resnet50_pool_only_and_batch_independence():
 
 
 @pytest.mark.parametrize("name,heads", [("vit_tiny", 3), ("vit_base", 12)])
-def test_vit_matches_reference_golden_tokens(golden_dir, name, heads):
+def test_vit_matches_reference_golden_tokens(golden_dir, name, heads, each_precision):
     vit_weights(name)
     z = np.load(os.path.join(golden_dir, f"{name}_tokens.npz"))
     tokens, pooled = engine().vit_features(torch.from_numpy(z["frags"]).cuda(), tokens=True, pooled=True)
@@ -74,7 +74,7 @@ def test_vit_matches_reference_golden_tokens(golden_dir, name, heads):
     assert_close(pooled, want, f"{name} pooled vs reference process_video_feature")
 
 
-def test_vit_base_oracle_batch():
+def test_vit_base_oracle_batch(each_precision):
     sd = vit_weights("vit_base")
     frags = _fragments(3, seed=2)
     tokens, pooled = engine().vit_features(torch.from_numpy(frags).cuda(), tokens=True, pooled=True)
@@ -116,7 +116,7 @@ def test_extract_clip_config2_shape_720p():
     assert_close(out["resnet"][:, 13120:], want[:, 13120:], "clip residual pool")
 
 
-def test_extract_clip_config3_1080p_with_vit():
+def test_extract_clip_config3_1080p_with_vit(each_precision):
     sd_r, sd_v = rn50_weights(), vit_weights("vit_base")
     T = 2
     clip = synth.synthetic_clip(T, 1080, 1920, clip_id=3)
@@ -134,7 +134,7 @@ def test_extract_clip_config3_1080p_with_vit():
     assert vec.shape == (15171 + 4608,)
 
 
-def test_clip_vectors_batch_of_mixed_resolutions_config4_shape():
+def test_clip_vectors_batch_of_mixed_resolutions_config4_shape(each_precision):
     """BASELINE config 4 shape (540p) next to a 720p clip in ONE batched pass; each row must equal the clip processed
     alone (to fp32 rounding with the default tail split-K, bit for bit without it)."""
     rn50_weights(), vit_weights("vit_base")
@@ -165,7 +165,7 @@ def test_bf16x3_mode_meets_the_feature_tolerance():
         ls, pool = eng.resnet50_features(torch.from_numpy(frags).cuda())
         _, pooled = eng.vit_features(torch.from_numpy(frags).cuda(), tokens=False, pooled=True)
     finally:
-        eng.set_precision("fp32")
+        eng.set_precision("bf16x6")
     tr, tv = resnet50_ref.to_torch_state_dict(sd_r), vit_ref.to_torch_state_dict(sd_v)
     want_ls, want_pool = resnet50_ref.layer_stack_features(tr, frags), resnet50_ref.pool_features(tr, frags)
     want_vit = vit_ref.pool_features(tv, frags, 12)
@@ -225,12 +225,10 @@ def test_bf16x3_at_the_headline_batch_uses_the_large_tiles_and_holds_the_bar():
     rn50_weights(), vit_weights("vit_base")
     eng = engine()
     clips = [torch.from_numpy(synth.synthetic_clip(32, 1080, 1920, clip_id=320 + i, distinct=2)).cuda() for i in range(8)]
+    eng.set_precision("fp32")
     exact = eng.clip_vectors(clips).cpu().numpy()
     eng.set_precision("bf16x3")
-    try:
-        fast = eng.clip_vectors(clips).cpu().numpy()
-    finally:
-        eng.set_precision("fp32")
+    fast = eng.clip_vectors(clips).cpu().numpy()
     rel = np.linalg.norm(fast - exact) / np.linalg.norm(exact)
     assert rel < 5e-5, rel
     assert_close(fast, exact, "bf16x3 clip vectors vs fp32")

@@ -22,8 +22,12 @@ def test_errors_are_reported_not_swallowed():
         eng.fragment_pairs(f, top_n=500)
     with pytest.raises(ValueError):
         eng.fragment_pairs(torch.zeros((1, 3, 32, 32, 3), dtype=torch.uint8))
-    with pytest.raises(RuntimeError, match="multiple of 32"):
+    with pytest.raises(RuntimeError, match="multiple of 16"):       # bf16x6 kernel (default): K in 16-deep chunks
         eng.op_gemm(torch.zeros(8, 40, device="cuda"), torch.zeros(64, 40, device="cuda"))
+    eng.set_precision("fp32")
+    with pytest.raises(RuntimeError, match="multiple of 32"):       # exact-fp32 kernel
+        eng.op_gemm(torch.zeros(8, 40, device="cuda"), torch.zeros(64, 40, device="cuda"))
+    eng.set_precision("bf16x6")
     with pytest.raises(RuntimeError, match="multiple of 64"):
         eng.op_gemm(torch.zeros(8, 64, device="cuda"), torch.zeros(48, 64, device="cuda"))
     with pytest.raises(RuntimeError, match="unknown option"):
@@ -97,3 +101,23 @@ def test_bench_two_ranks_sharing_the_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert "roofline" in out and "cpu_baseline" not in out          # the CPU baseline is an N = 1 leg
+    assert out["rccl_ranks"] == 2
+
+
+def test_bench_gpus_2_run_plainly_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command line with a larger N):
+    bench.py starts torch.distributed.run itself, as a child, before touching the GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RELAX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "config2",
+           "--clips-per-step", "1"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0

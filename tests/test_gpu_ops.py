@@ -10,6 +10,14 @@ from tests.gpu_common import assert_close, engine
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _fp32_kernel():
+    """This file exercises the exact-fp32 contraction kernel (gemm.hip) and its tile variants; the default bf16x6 kernel has
+    its operator-level tests in tests/test_gpu_x6.py."""
+    engine().set_precision("fp32")
+    yield
+
+
 def _rand(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).float()
@@ -133,7 +141,6 @@ def test_gap(n, hw, c):
 def bf16x3():
     engine().set_precision("bf16x3")
     yield
-    engine().set_precision("fp32")
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 512), (197 * 3, 2304, 768), (12608, 768, 3072), (50, 64, 64), (4096, 64, 576)])
