@@ -187,8 +187,11 @@ def golden_pooling(mfl, mrf, mfp, report):
 
 def golden_vit(rv, report):
     device = torch.device("cpu")
-    for name, heads, n_img in [("vit_tiny", 3, 2), ("vit_base", 12, 1)]:
-        sd_np = synth.vit_state_dict(name, 16, seed=11)
+    # regular synthetic weights, and the adversarial set (attention logits of +-20: peaked softmax rows; LayerNorm gammas of
+    # mixed sign) - the reference's own VisionTransformer class computes the expected tokens for both
+    for name, heads, n_img, adv in [("vit_tiny", 3, 2, False), ("vit_base", 12, 1, False), ("vit_tiny", 3, 2, True),
+                                    ("vit_base", 12, 1, True)]:
+        sd_np = synth.vit_state_dict(name, 16, seed=11, adversarial=adv)
         gen = rv.VitGenerator(name, 16, device, evaluate=True, random=True, verbose=False)
         gen.model.load_state_dict(vit_ref.to_torch_state_dict(sd_np), strict=True)
         frags = np.stack([fragment_ref.fragment_pair(*synth.synthetic_pair(240, 320, 50 + i))["ori_frag"]
@@ -200,10 +203,11 @@ def golden_vit(rv, report):
         mine = vit_ref.tokens(vit_ref.to_torch_state_dict(sd_np), frags, heads)
         err = float(np.abs(mine - tokens).max() / np.abs(tokens).max())
         assert err < 2e-6, (name, err)
-        np.savez_compressed(os.path.join(GOLD, f"{name}_tokens.npz"), frags=frags, tokens=tokens,
+        tag = name + ("_adv" if adv else "")
+        np.savez_compressed(os.path.join(GOLD, f"{tag}_tokens.npz"), frags=frags, tokens=tokens,
                             weight_probe=np.float64([float(np.sum(v.astype(np.float64))) for v in sd_np.values()]).sum())
-        report["vit"][name] = dict(tokens=sha(tokens), restatement_vs_reference_maxrel=err,
-                                   shape=list(tokens.shape))
+        report["vit"][tag] = dict(tokens=sha(tokens), restatement_vs_reference_maxrel=err,
+                                  shape=list(tokens.shape))
 
 
 def pin_flow(report):

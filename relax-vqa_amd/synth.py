@@ -16,18 +16,31 @@ def _rng(seed):
     return np.random.Generator(np.random.PCG64(seed))
 
 
-def resnet50_state_dict(seed=7):
+def resnet50_state_dict(seed=7, adversarial=False):
     """fp32 numpy state dict with torchvision resnet50 key names (fc omitted:
-    the reference computes fc but never reads it)."""
-    g = _rng(seed)
+    the reference computes fc but never reads it).
+    adversarial: a second weight set built to stress the BatchNorm / ReLU arithmetic - running variances log-uniform over
+    [1e-3, 10] (eps = 1e-5 matters at the low end; the producing conv's rows are scaled by sqrt(var) so activations stay O(1)),
+    gammas of mixed sign (ReLU keeps the other half), larger running means and biases."""
+    g = _rng(seed + (1000 if adversarial else 0))
     sd = {}
+    last_conv = [None]
 
     def conv(name, cout, cin, k):
         fan_out = cout * k * k
         sd[name + ".weight"] = (g.standard_normal((cout, cin, k, k), dtype=np.float32)
                                 * np.float32(np.sqrt(2.0 / fan_out)))
+        last_conv[0] = name + ".weight"
 
     def bn(name, c, gamma_scale=1.0):
+        if adversarial:
+            var = np.exp(g.uniform(np.log(1e-3), np.log(10.0), c))
+            sd[name + ".weight"] = (g.uniform(0.5, 1.5, c) * g.choice([-1.0, 1.0], c) * gamma_scale).astype(np.float32)
+            sd[name + ".bias"] = (g.standard_normal(c) * 0.3).astype(np.float32)
+            sd[name + ".running_mean"] = (g.standard_normal(c) * 0.5 * np.sqrt(var)).astype(np.float32)
+            sd[name + ".running_var"] = var.astype(np.float32)
+            sd[last_conv[0]] = (sd[last_conv[0]] * np.sqrt(var).astype(np.float32)[:, None, None, None]).astype(np.float32)
+            return
         sd[name + ".weight"] = (g.uniform(0.5, 1.5, c) * gamma_scale).astype(np.float32)
         sd[name + ".bias"] = (g.standard_normal(c) * 0.1).astype(np.float32)
         sd[name + ".running_mean"] = (g.standard_normal(c) * 0.1).astype(np.float32)
@@ -52,12 +65,15 @@ def resnet50_state_dict(seed=7):
     return sd
 
 
-def vit_state_dict(name_model="vit_base", patch=16, seed=11):
+def vit_state_dict(name_model="vit_base", patch=16, seed=11, adversarial=False):
     """fp32 numpy state dict with DINO ViT key names.  Biases / LN affine are
-    non-trivial on purpose so a missing bias add cannot pass parity."""
+    non-trivial on purpose so a missing bias add cannot pass parity.
+    adversarial: a second weight set for the softmax path - the q and k rows of every qkv matrix are scaled so attention
+    logits span about +-20 (peaked, near one-hot rows next to flat ones: the max subtraction and the exp2 of the attention
+    kernel work at their limits), LayerNorm gammas of mixed sign."""
     cfg = {"vit_tiny": (192, 12, 3), "vit_small": (384, 12, 6), "vit_base": (768, 12, 12)}[name_model]
     dim, depth, _heads = cfg
-    g = _rng(seed)
+    g = _rng(seed + (1000 if adversarial else 0))
 
     def nrm(shape, std):
         return (g.standard_normal(shape, dtype=np.float32) * np.float32(std))
@@ -74,6 +90,9 @@ def vit_state_dict(name_model="vit_base", patch=16, seed=11):
         sd[p + "norm1.bias"] = nrm((dim,), 0.1)
         sd[p + "attn.qkv.weight"] = nrm((3 * dim, dim), 0.05)
         sd[p + "attn.qkv.bias"] = nrm((3 * dim,), 0.02)
+        if adversarial:
+            sd[p + "norm1.weight"] *= g.choice([-1.0, 1.0], dim).astype(np.float32)
+            sd[p + "attn.qkv.weight"][: 2 * dim] *= np.float32(3.0)      # q and k rows: logits (q.k / 8) of std ~18
         sd[p + "attn.proj.weight"] = nrm((dim, dim), 0.02)
         sd[p + "attn.proj.bias"] = nrm((dim,), 0.02)
         sd[p + "norm2.weight"] = g.uniform(0.5, 1.5, dim).astype(np.float32)

@@ -24,19 +24,24 @@ def engine():
     return _engine
 
 
-def rn50_weights():
-    if "rn" not in _weights:
-        _weights["rn"] = synth.resnet50_state_dict()
-        engine().load_resnet50(_weights["rn"])
-    return _weights["rn"]
+def rn50_weights(adversarial=False):
+    """The synthetic ResNet-50 weights (or the adversarial second set), loaded into the shared engine."""
+    key = "rn:adv" if adversarial else "rn"
+    if key not in _weights:
+        _weights[key] = synth.resnet50_state_dict(adversarial=adversarial)
+    if _weights.get("rn_loaded") != key:
+        engine().load_resnet50(_weights[key])
+        _weights["rn_loaded"] = key
+    return _weights[key]
 
 
-def vit_weights(name):
-    key = "vit:" + name
-    if _weights.get("vit_loaded") != name:
-        _weights[key] = _weights.get(key) or synth.vit_state_dict(name)
+def vit_weights(name, adversarial=False):
+    key = "vit:" + name + (":adv" if adversarial else "")
+    if key not in _weights:
+        _weights[key] = synth.vit_state_dict(name, adversarial=adversarial)
+    if _weights.get("vit_loaded") != key:
         engine().load_vit(_weights[key], name)
-        _weights["vit_loaded"] = name
+        _weights["vit_loaded"] = key
     return _weights[key]
 
 

@@ -21,8 +21,11 @@ def _fragments(n, seed=0):
     return np.stack(frs)
 
 
-def test_resnet50_taps_and_features(each_precision):
-    sd = rn50_weights()
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_resnet50_taps_and_features(each_precision, adversarial):
+    """Every hooked activation and both feature vectors, on the regular synthetic weights and on the adversarial set (BatchNorm
+    variances over 1e-3..10, gammas of mixed sign), on both arithmetics."""
+    sd = rn50_weights(adversarial)
     frags = _fragments(3)
     ls, pool, taps = engine().resnet50_features(torch.from_numpy(frags).cuda(), taps=range(15))
     torch.cuda.synchronize()
@@ -38,6 +41,7 @@ def test_resnet50_taps_and_features(each_precision):
         off += c
     assert_close(pool[:, :2048], want_pool[:, :2048], "pool vector")
     assert_close(pool[:, 2048:], want_pool[:, 2048:], "pool stats (mean,max,std)")
+    rn50_weights()   # the shared engine goes back to the regular set
 
 
 def test_resnet50_pool_only_and_batch_independence(each_precision):
@@ -64,10 +68,13 @@ def test_resnet50_pool_only_and_batch_independence(each_precision):
     assert torch.equal(again, ls_all), "not deterministic with split-K"
 
 
+@pytest.mark.parametrize("adversarial", [False, True])
 @pytest.mark.parametrize("name,heads", [("vit_tiny", 3), ("vit_base", 12)])
-def test_vit_matches_reference_golden_tokens(golden_dir, name, heads, each_precision):
-    vit_weights(name)
-    z = np.load(os.path.join(golden_dir, f"{name}_tokens.npz"))
+def test_vit_matches_reference_golden_tokens(golden_dir, name, heads, each_precision, adversarial):
+    """Tokens computed by the reference's own VisionTransformer class; the adversarial weights drive the attention kernel's
+    max subtraction / exp2 path with logits of +-20 (near one-hot softmax rows)."""
+    vit_weights(name, adversarial)
+    z = np.load(os.path.join(golden_dir, f"{name}{'_adv' if adversarial else ''}_tokens.npz"))
     tokens, pooled = engine().vit_features(torch.from_numpy(z["frags"]).cuda(), tokens=True, pooled=True)
     assert_close(tokens, z["tokens"], f"{name} tokens vs reference VisionTransformer")
     want = np.stack([pooling_ref.vit_pool_vector(t) for t in z["tokens"]])
