@@ -106,6 +106,8 @@ struct X6Params {
     const char* w;        // sp3 weights [N][K*6 B], k = (dy*KW+dx)*Cin + c
     const float* bias;
     const float* residual;   // fp32 [M][N] or null
+    const char* residual_sp3;   // the residual as split planes [M][N*6 B] (exact: hi + mid + lo), or null
+    float* gap;              // fused spatial mean, stage 1: sums of the outputs over aligned 16-row groups [M/16][N], or null
     float* out;              // fp32 [M][N] or null
     char* out_sp3;           // sp3 [M][N*6 B] or null
     float* partial;          // split-K partial tiles
@@ -430,6 +432,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                     rb[it] = *reinterpret_cast<const f32x4*>(r + 4);
                 }
             }
+        } else if (slice < 0 && p.residual_sp3) {
+            // the residual in split planes: x = (hi + mid) + lo reconstructs the fp32 value exactly
+#pragma unroll
+            for (int it = 0; it < EP_ITERS; ++it) {
+                const int m = m0 + pass * EP_ROWS + it * EP_STEP + lr0;
+                ra[it] = zero4;
+                rb[it] = zero4;
+                if (interior || m < p.M) {
+                    const char* r = p.residual_sp3 + (int64_t)m * ((int64_t)p.N * 6) + sp3_offset(n0 + lc);
+                    const u32x4 hi = *reinterpret_cast<const u32x4*>(r), mid = *reinterpret_cast<const u32x4*>(r + 32),
+                                lo = *reinterpret_cast<const u32x4*>(r + 64);
+#define X6_UNSPLIT(h_, m_, l_, sh_) ((__uint_as_float(sh_ ? (h_) & 0xffff0000u : (h_) << 16) + __uint_as_float(sh_ ? (m_) & 0xffff0000u : (m_) << 16)) + \
+                                      __uint_as_float(sh_ ? (l_) & 0xffff0000u : (l_) << 16))
+                    ra[it] = (f32x4){X6_UNSPLIT(hi.x, mid.x, lo.x, 0), X6_UNSPLIT(hi.x, mid.x, lo.x, 1), X6_UNSPLIT(hi.y, mid.y, lo.y, 0),
+                                     X6_UNSPLIT(hi.y, mid.y, lo.y, 1)};
+                    rb[it] = (f32x4){X6_UNSPLIT(hi.z, mid.z, lo.z, 0), X6_UNSPLIT(hi.z, mid.z, lo.z, 1), X6_UNSPLIT(hi.w, mid.w, lo.w, 0),
+                                     X6_UNSPLIT(hi.w, mid.w, lo.w, 1)};
+#undef X6_UNSPLIT
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             }
             va += bias_a;
             vb += bias_b;
-            if (p.residual) {   // (acc + bias) + residual: the same order on every path
+            if (p.residual || p.residual_sp3) {   // (acc + bias) + residual: the same order on every path
                 va += ra[it];
                 vb += rb[it];
             }
@@ -476,6 +498,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 *reinterpret_cast<f32x4*>(p.out + o + 4) = vb;
             }
             if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lc, va, vb);
+            if (p.gap) {   // the finished values go back to the staging rows for the group sums below
+                *reinterpret_cast<f32x4*>(stg + lr * LDC + lc) = va;
+                *reinterpret_cast<f32x4*>(stg + lr * LDC + lc + 4) = vb;
+            }
+        }
+        if (p.gap && slice < 0) {
+            // fused spatial mean, stage 1: sums over the aligned 16-row groups of this chunk, rows added in order.  Images start
+            // at multiples of 16 rows (the launcher checks Ho*Wo % 16 == 0), so a group never spans two images and the
+            // grouping does not depend on where in the batch an image sits: bits are batch-invariant.
+            __syncthreads();
+            for (int e = tid; e < (EP_ROWS / 16) * BN; e += NT) {
+                const int g = e / BN, col = e - g * BN;
+                const int mg = m0 + pass * EP_ROWS + g * 16;
+                if (mg < p.M) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += stg[(g * 16 + r) * LDC + col];
+                    p.gap[(int64_t)(mg >> 4) * p.N + n0 + col] = t;
+                }
+            }
         }
     }
     X6_STAMP(3);
@@ -548,7 +590,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     const int slots = 256 * WG_PER_CU;
     const int nk = p.K / 16;
     const int rem = p.ntiles % slots;
-    if (h->gemm.split_k && rem > 0) {
+    if (h->gemm.split_k && rem > 0 && !p.gap && !p.residual_sp3) {   // (the finish kernel knows neither of the two)
         int best_s = 1;
         double best = 1.0;
         const int smax = nk / 8 < 16 ? nk / 8 : 16;
@@ -621,6 +663,8 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     p.a = static_cast<const char*>(d.in);
     p.w = static_cast<const char*>(d.w);
     p.bias = d.bias; p.residual = d.residual; p.out = d.out; p.out_sp3 = static_cast<char*>(d.out_sp3);
+    p.residual_sp3 = static_cast<const char*>(d.residual_sp3);
+    p.gap = d.gap_groups;
     p.M = d.Nimg * d.Ho * d.Wo;
     p.N = d.Cout;
     p.K = d.KH * d.KW * d.Cin;
@@ -632,13 +676,15 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, d.Cin % 16 == 0, "x6 conv/gemm: Cin=%d must be a multiple of 16", d.Cin);
     RELAX_REQUIRE(h, p.N % 64 == 0, "x6 conv/gemm: N=%d must be a multiple of 64", p.N);
     RELAX_REQUIRE(h, (int64_t)p.K * 6 * 256 < kMaxRecords, "x6 conv/gemm: K=%d too large", p.K);
-    RELAX_REQUIRE(h, d.out || d.out_sp3, "x6 conv/gemm: no output requested");
+    RELAX_REQUIRE(h, d.out || d.out_sp3 || d.gap_groups, "x6 conv/gemm: no output requested");
+    RELAX_REQUIRE(h, !(d.residual && d.residual_sp3), "x6 conv/gemm: two residuals");
+    RELAX_REQUIRE(h, !d.gap_groups || ((d.Ho * d.Wo) % 16 == 0 && p.M % 16 == 0), "x6 conv: the fused spatial mean needs Ho*Wo %% 16 == 0");
     RELAX_REQUIRE(h, !taps || d.pad >= 0, "x6 conv: bad padding");
     RELAX_REQUIRE(h, taps || d.pad == 0, "x6 conv: 1x1 with padding is not supported");
     const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)p.K;
     // algorithmic HBM bytes: activation in (6 B per value), weights, outputs (+ residual), each touched once
     const double bytes = 6.0 * ((double)d.Nimg * d.H * d.W * d.Cin + (double)p.N * p.K) +
-                         (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.residual ? 4.0 : 0.0));
+                         (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.residual ? 4.0 : 0.0) + (d.residual_sp3 ? 6.0 : 0.0));
     int span;
     RELAX_TRY(prof_begin(h, s, 2, flops, &span, bytes));
     int rc;

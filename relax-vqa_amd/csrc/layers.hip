@@ -414,6 +414,27 @@ __global__ __launch_bounds__(256) void gap_finish(const float* __restrict__ part
     out[(int64_t)n * out_stride + c] = t / (float)HW;
 }
 
+// stage 2 of the spatial mean fused into the bf16x6 epilogue: out[n, c] = (sum of the HW/16 group sums of image n, in order) / HW
+__global__ __launch_bounds__(256) void gap_groups_finish(const float* __restrict__ groups, float* __restrict__ out, int Nimg,
+                                                         int G, int HW, int C, int64_t out_stride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Nimg * C) return;
+    const int n = (int)(i / C), c = (int)(i % C);
+    const float* g = groups + (int64_t)n * G * C + c;
+    float t = 0.f;
+    for (int k = 0; k < G; ++k) t += g[(int64_t)k * C];
+    out[(int64_t)n * out_stride + c] = t / (float)HW;
+}
+
+int launch_gap_groups_finish(relax_handle* h, const float* groups, float* out, int Nimg, int HW, int C, int64_t out_stride,
+                             hipStream_t s) {
+    RELAX_REQUIRE(h, HW % 16 == 0 && Nimg > 0 && C > 0, "gap_groups_finish: bad shape HW=%d C=%d", HW, C);
+    hipLaunchKernelGGL(gap_groups_finish, dim3((unsigned)(((int64_t)Nimg * C + 255) / 256)), dim3(256), 0, s, groups, out, Nimg,
+                       HW / 16, HW, C, out_stride);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
 constexpr int GAP_MAX_SPLIT = 16;
 
 int launch_gap_ws(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,

@@ -75,6 +75,8 @@ struct ConvDescX6 {
     int Cout;
     const float* bias;      // [Cout] or null
     const float* residual;  // fp32 [M, Cout] or null
+    const void* residual_sp3;  // the residual as split planes instead (exact), or null
+    float* gap_groups;      // fused spatial mean, stage 1: sums over aligned 16-row groups [M/16][Cout], or null
     float* out;             // fp32 [M, Cout] or null
     void* out_sp3;          // sp3 [M][Cout*6 B] or null (at least one output)
     int act;                // 0 none, 1 relu, 2 gelu(erf)
@@ -242,6 +244,8 @@ int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, 
                            int Nimg, int H, int W, int C, hipStream_t s);
 int launch_bn_relu_maxpool_sp3(relax_handle* h, const float* x, const float* scale, const float* shift, void* y_sp3,
                                int Nimg, int H, int W, int C, hipStream_t s);
+int launch_gap_groups_finish(relax_handle* h, const float* groups, float* out, int Nimg, int HW, int C, int64_t out_stride,
+                             hipStream_t s);
 int launch_gap(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,
                hipStream_t s);
 int launch_nhwc_to_nchw(relax_handle* h, const float* x, float* y, int Nimg, int HW, int C, hipStream_t s);

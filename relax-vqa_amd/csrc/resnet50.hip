@@ -153,7 +153,7 @@ static constexpr size_t kX0 = 224 * 224 * 4;        // preprocessed input, NHWC4
 static constexpr size_t kBig = 112 * 112 * 64;      // == 56*56*256: largest block in/out and conv1 raw
 static constexpr size_t kT1 = 56 * 56 * 128;        // largest conv1-of-block output (layer2.0 before the stride)
 static constexpr size_t kT2 = 56 * 56 * 64;         // largest conv2 output
-static constexpr size_t kGapWs = 16 * 2048;         // GAP partial sums
+static constexpr size_t kGapWs = 196 * 256;         // GAP partial sums (16 x 2048 two-stage kernel; 3136/16 x 256 fused group sums)
 static constexpr size_t kAvg = 2048;
 static constexpr size_t kRnFloatsPerImage = kX0 + 3 * kBig + kT1 + kT2 + kGapWs + kAvg;
 // bf16x6 path: block inputs / outputs exist twice (fp32 for the residual add and the taps, split planes = 1.5 floats per
@@ -165,7 +165,8 @@ size_t resnet_arena_bytes(int n) {
 }
 
 static int run_conv_x6(relax_handle* h, const ConvW& c, const void* in_sp3, int Nimg, int H, int W, const float* residual,
-                       float* out, void* out_sp3, int act, hipStream_t s) {
+                       float* out, void* out_sp3, int act, hipStream_t s, const void* residual_sp3 = nullptr,
+                       float* gap_groups = nullptr) {
     ConvDescX6 d{};
     d.in = in_sp3; d.Nimg = Nimg; d.H = H; d.W = W; d.Cin = c.Cin;
     d.Ho = (H + 2 * c.pad - c.KH) / c.stride + 1;
@@ -173,6 +174,7 @@ static int run_conv_x6(relax_handle* h, const ConvW& c, const void* in_sp3, int 
     d.KH = c.KH; d.KW = c.KW; d.stride = c.stride; d.pad = c.pad;
     d.w = c.w_sp3; d.Cout = c.Cout;
     d.bias = c.bias; d.residual = residual; d.out = out; d.out_sp3 = out_sp3; d.act = act;
+    d.residual_sp3 = residual_sp3; d.gap_groups = gap_groups;
     return launch_conv_x6(h, d, s);
 }
 
@@ -328,26 +330,47 @@ int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float*
         float* avg6 = gapws6 + kGapWs * n;
         gapws = gapws6;
         RELAX_TRY(launch_bn_relu_maxpool_sp3(h, bufA, rn.bn1_scale, rn.bn1_shift, spa, N, 112, 112, 64, s));
-        const float* cur32 = nullptr;                         // the pooled map is only ever a convolution input
+        // A block output exists as split planes always (next convolutions, next residual: hi + mid + lo is the fp32 value,
+        // exactly) and as fp32 only where something needs it: the tap export, or the spatial mean of the 14x14 / 7x7 taps
+        // (196 and 49 rows per image do not divide into the 16-row groups of the mean fused into the epilogue).
+        const float* cur32 = nullptr;
         char* cursp = spa;
         char* othersp = spb;
         float* out32 = f32a;
         int H = 56;
         for (const Bottleneck& blk : rn.blocks) {
             const int Ho = H / blk.c2.stride;
+            const int HWo = Ho * Ho, Cout = blk.c3.Cout;
+            const bool tapped = blk.tap >= 0;
+            const bool want_mean = tapped && layer_stack;
+            const bool want_export = tapped && taps_nchw && taps_nchw[blk.tap];
+            const bool is_last = &blk == &rn.blocks.back();
+            const bool fuse_mean = want_mean && HWo % 16 == 0;
+            const bool need32 = want_export || (want_mean && !fuse_mean) || (is_last && pool && !layer_stack);
             RELAX_TRY(run_conv_x6(h, blk.c1, cursp, N, H, H, nullptr, nullptr, T1s, 1, s));
             RELAX_TRY(run_conv_x6(h, blk.c2, T1s, N, H, H, nullptr, nullptr, T2s, 1, s));
-            const float* identity = cur32;
+            const float* identity = nullptr;
+            const void* identity_sp3 = cursp;
             if (blk.has_down) {
                 RELAX_TRY(run_conv_x6(h, blk.down, cursp, N, H, H, nullptr, D, nullptr, 0, s));
                 identity = D;
+                identity_sp3 = nullptr;
             }
-            RELAX_TRY(run_conv_x6(h, blk.c3, T2s, N, Ho, Ho, identity, out32, othersp, 1, s));
-            cur32 = out32;
-            out32 = out32 == f32a ? f32b : f32a;
+            RELAX_TRY(run_conv_x6(h, blk.c3, T2s, N, Ho, Ho, identity, need32 ? out32 : nullptr, othersp, 1, s, identity_sp3,
+                                  fuse_mean ? gapws : nullptr));
+            cur32 = need32 ? out32 : nullptr;
+            if (need32) out32 = out32 == f32a ? f32b : f32a;
             char* t = cursp; cursp = othersp; othersp = t;
             H = Ho;
-            if (blk.tap >= 0) RELAX_TRY(emit_tap(blk.tap, cur32));
+            if (tapped) {
+                int off = 0;
+                for (int t2 = 0; t2 < blk.tap; ++t2) off += kTapChannels[t2];
+                if (fuse_mean)
+                    RELAX_TRY(launch_gap_groups_finish(h, gapws, layer_stack + off, N, HWo, Cout, RELAX_RN50_LAYER_STACK_DIM, s));
+                else if (want_mean)
+                    RELAX_TRY(launch_gap_ws(h, cur32, layer_stack + off, N, HWo, Cout, RELAX_RN50_LAYER_STACK_DIM, gapws, s));
+                if (want_export) RELAX_TRY(launch_nhwc_to_nchw(h, cur32, taps_nchw[blk.tap], N, HWo, Cout, s));
+            }
         }
         if (pool) {
             const float* avg_src;
