@@ -24,6 +24,7 @@
 // permutation is applied on the SOURCE address of the DMA, the LDS image stays linear).  Rows beyond M and padding
 // taps of an implicit-GEMM convolution read from a page of zeros.
 #include "relax_internal.h"
+#include "sp3.h"
 
 #ifdef RELAX_X6_STAMPS   // diagnostic build (tools/build_ablations.sh x6stamps): thread 0 of every workgroup records cycle stamps
 #define X6_STAMP(i_) if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime()
@@ -42,42 +43,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kChunkBytes = 96;   // one 16-deep K step of one row
-
-// ---- the split -------------------------------------------------------------------------------------------------------
-// (x, y) -> packed bf16 pairs hi, mid, lo with x = hi + mid + lo exactly (round to nearest at every step)
-__device__ inline void split3_pair(float x, float y, unsigned& hi, unsigned& mid, unsigned& lo) {
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x, y}, bf16x2));
-    const float rx = x - __uint_as_float(hi << 16), ry = y - __uint_as_float(hi & 0xffff0000u);
-    mid = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){rx, ry}, bf16x2));
-    const float sx = rx - __uint_as_float(mid << 16), sy = ry - __uint_as_float(mid & 0xffff0000u);
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){sx, sy}, bf16x2));
-}
-
-// 8 consecutive values (half a chunk) -> the three 16-byte units of its planes
-__device__ inline void split3_x8(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
-    unsigned h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
-    split3_pair(a.x, a.y, h0, m0, l0);
-    split3_pair(a.z, a.w, h1, m1, l1);
-    split3_pair(b.x, b.y, h2, m2, l2);
-    split3_pair(b.z, b.w, h3, m3, l3);
-    hi = (u32x4){h0, h1, h2, h3};
-    mid = (u32x4){m0, m1, m2, m3};
-    lo = (u32x4){l0, l1, l2, l3};
-}
-
-// byte offset of the 8 values k .. k+7 (k % 8 == 0) of plane 0 inside an sp3 row
-__device__ __host__ inline int64_t sp3_offset(int k) { return (int64_t)(k >> 4) * kChunkBytes + (k & 8) * 2; }
-
-__device__ inline void store_sp3_x8(char* row, int k, const f32x4 a, const f32x4 b) {
-    u32x4 hi, mid, lo;
-    split3_x8(a, b, hi, mid, lo);
-    char* d = row + sp3_offset(k);
-    *reinterpret_cast<u32x4*>(d) = hi;
-    *reinterpret_cast<u32x4*>(d + 32) = mid;
-    *reinterpret_cast<u32x4*>(d + 64) = lo;
-}
 
 // fp32 [rows][K] (row stride ld floats) -> sp3 [rows][K*6 bytes]; one thread per 8 values
 __global__ __launch_bounds__(256) void to_sp3_kernel(const float* __restrict__ x, int64_t ld, char* __restrict__ y, int K,

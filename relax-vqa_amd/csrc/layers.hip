@@ -2,6 +2,7 @@
 // single-tile attention for 197 tokens x 64-d heads (fp32 MFMA, softmax in registers),
 // BN+ReLU+max-pool, deterministic global-average-pool, NHWC->NCHW tap export.
 #include "relax_internal.h"
+#include "sp3.h"
 
 namespace relax {
 
@@ -16,17 +17,6 @@ __device__ inline float wave_sum(float v) {
 // ---- LayerNorm: one 64-lane wave per row, row held in registers (dim <= 768) ---------------------------
 // SP3: the normalised row leaves as split planes (bf16 hi + mid + lo, gemm_x6.hip) for the bf16x6 contraction that
 // consumes it; the arithmetic before the store is the same, so the fp32 value that is split is the one the fp32 path stores.
-typedef float ln_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 ln_bf16x2 __attribute__((ext_vector_type(2)));
-
-__device__ inline void ln_split3_pair(float x, float y, unsigned& hi, unsigned& mid, unsigned& lo) {
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector((ln_f32x2){x, y}, ln_bf16x2));
-    const float rx = x - __uint_as_float(hi << 16), ry = y - __uint_as_float(hi & 0xffff0000u);
-    mid = __builtin_bit_cast(unsigned, __builtin_convertvector((ln_f32x2){rx, ry}, ln_bf16x2));
-    const float sx = rx - __uint_as_float(mid << 16), sy = ry - __uint_as_float(mid & 0xffff0000u);
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((ln_f32x2){sx, sy}, ln_bf16x2));
-}
-
 template <bool SP3>
 __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x, const float* __restrict__ g,
                                                       const float* __restrict__ b, void* __restrict__ yv, int rows,
@@ -69,13 +59,7 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
             o.w = (v[j].w - mean) * rstd * gg.w + bb.w;
             if (SP3) {
                 // values k = 4i .. 4i+3: 8 bytes of each plane of chunk k / 16 (96-byte chunks: [16 hi][16 mid][16 lo])
-                uint2 hi, mid, lo;
-                ln_split3_pair(o.x, o.y, hi.x, mid.x, lo.x);
-                ln_split3_pair(o.z, o.w, hi.y, mid.y, lo.y);
-                char* d = static_cast<char*>(yv) + (int64_t)row * dim * 6 + (i >> 2) * 96 + (i & 3) * 8;
-                *reinterpret_cast<uint2*>(d) = hi;
-                *reinterpret_cast<uint2*>(d + 32) = mid;
-                *reinterpret_cast<uint2*>(d + 64) = lo;
+                store_sp3_x4(static_cast<char*>(yv) + (int64_t)row * dim * 6, 4 * i, (sp3_f32x4){o.x, o.y, o.z, o.w});
             } else {
                 reinterpret_cast<float4*>(static_cast<float*>(yv) + (int64_t)row * dim)[i] = o;
             }
@@ -341,13 +325,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_nhwc(const float* __restr
     }
     const int64_t opix = ((int64_t)n * Ho + oy) * Wo + ox;
     if (SP3) {
-        uint2 hi, mid, lo;
-        ln_split3_pair(m.x, m.y, hi.x, mid.x, lo.x);
-        ln_split3_pair(m.z, m.w, hi.y, mid.y, lo.y);
-        char* d = static_cast<char*>(yv) + opix * C * 6 + (c4 >> 2) * 96 + (c4 & 3) * 8;
-        *reinterpret_cast<uint2*>(d) = hi;
-        *reinterpret_cast<uint2*>(d + 32) = mid;
-        *reinterpret_cast<uint2*>(d + 64) = lo;
+        store_sp3_x4(static_cast<char*>(yv) + opix * C * 6, 4 * c4, (sp3_f32x4){m.x, m.y, m.z, m.w});
     } else {
         reinterpret_cast<float4*>(static_cast<float*>(yv) + opix * C)[c4] = m;
     }
@@ -540,6 +518,7 @@ int relax_op_attention(relax_handle* h, const float* qkv, float* out, int Nimg, 
     if (!h) return RELAX_ERR_INVALID;
     RELAX_REQUIRE(h, qkv && out, "relax_op_attention: NULL operand");
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    if (h->gemm.precision == 2) return launch_attention_x6(h, qkv, out, nullptr, Nimg, heads, static_cast<hipStream_t>(stream));
     return launch_attention(h, qkv, out, Nimg, heads, static_cast<hipStream_t>(stream));
 }
 

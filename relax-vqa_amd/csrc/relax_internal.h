@@ -240,6 +240,7 @@ int launch_layernorm(relax_handle* h, const float* x, const float* g, const floa
 int launch_layernorm_sp3(relax_handle* h, const float* x, const float* g, const float* b, void* y_sp3, int rows, int dim,
                          float eps, hipStream_t s);
 int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s);
+int launch_attention_x6(relax_handle* h, const float* qkv, float* out, void* out_sp3, int Nimg, int heads, hipStream_t s);
 int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
                            int Nimg, int H, int W, int C, hipStream_t s);
 int launch_bn_relu_maxpool_sp3(relax_handle* h, const float* x, const float* scale, const float* shift, void* y_sp3,

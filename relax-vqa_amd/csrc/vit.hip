@@ -8,6 +8,7 @@
 //   :234-239  final LayerNorm (eps 1e-6, :287-289), patch tokens x[:,1:]
 //   src/main_fragment_pool.py:124-133  mean / max / population-std over the 196 tokens
 #include "relax_internal.h"
+#include "sp3.h"
 
 namespace relax {
 
@@ -31,8 +32,6 @@ __global__ __launch_bounds__(256) void vit_patchify(const uint8_t* __restrict__ 
 }
 
 // the same patches as split planes (bf16 hi + mid + lo of value/255, gemm_x6.hip): one thread per 8 k (8 pixels of a patch row)
-typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 pf_bf16x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void vit_patchify_sp3(const uint8_t* __restrict__ frag, char* __restrict__ P, int64_t total8) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total8) return;
@@ -43,20 +42,10 @@ __global__ __launch_bounds__(256) void vit_patchify_sp3(const uint8_t* __restric
     const int c = k >> 8, py = (k >> 4) & 15, px = k & 15;
     const int y = (p / 14) * 16 + py, x = (p % 14) * 16 + px;
     const uint8_t* src = frag + ((n * 224 + y) * 224 + x) * 3 + (2 - c);
-    unsigned hi[4], mid[4], lo[4];
+    float v[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float a = (float)src[6 * j] / 255.0f, b = (float)src[6 * j + 3] / 255.0f;
-        hi[j] = __builtin_bit_cast(unsigned, __builtin_convertvector((pf_f32x2){a, b}, pf_bf16x2));
-        const float ra = a - __uint_as_float(hi[j] << 16), rb = b - __uint_as_float(hi[j] & 0xffff0000u);
-        mid[j] = __builtin_bit_cast(unsigned, __builtin_convertvector((pf_f32x2){ra, rb}, pf_bf16x2));
-        const float sa = ra - __uint_as_float(mid[j] << 16), sb = rb - __uint_as_float(mid[j] & 0xffff0000u);
-        lo[j] = __builtin_bit_cast(unsigned, __builtin_convertvector((pf_f32x2){sa, sb}, pf_bf16x2));
-    }
-    char* d = P + row * (PATCH_K * 6) + (k >> 4) * 96 + (k & 8) * 2;
-    *reinterpret_cast<uint4*>(d) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    *reinterpret_cast<uint4*>(d + 32) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
-    *reinterpret_cast<uint4*>(d + 64) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    for (int j = 0; j < 8; ++j) v[j] = (float)src[3 * j] / 255.0f;
+    store_sp3_x8(P + row * (PATCH_K * 6), k, (sp3_f32x4){v[0], v[1], v[2], v[3]}, (sp3_f32x4){v[4], v[5], v[6], v[7]});
 }
 
 // X[n,0,:] = cls + pos[0];  X[n,1+p,:] = PE[n*196+p,:] + pos[1+p]
@@ -288,8 +277,7 @@ int relax_vit_features(relax_handle* h, const uint8_t* frags, int N, float* toke
         for (const VitBlockW& b : v.blocks) {
             RELAX_TRY(launch_layernorm_sp3(h, Xx, b.ln1_g, b.ln1_b, Ys, rows, dim, kLnEps, s));
             RELAX_TRY(launch_gemm_x6(h, Ys, b.qkv.w_sp3, b.qkv.b, nullptr, QKVx, nullptr, rows, 3 * dim, dim, 0, s));
-            RELAX_TRY(launch_attention(h, QKVx, ATT, N, v.heads, s));
-            RELAX_TRY(launch_to_sp3(h, ATT, dim, Ys, rows, dim, s));
+            RELAX_TRY(launch_attention_x6(h, QKVx, nullptr, Ys, N, v.heads, s));   // output straight into split planes
             RELAX_TRY(launch_gemm_x6(h, Ys, b.proj.w_sp3, b.proj.b, Xx, Xx, nullptr, rows, dim, dim, 0, s));      // x += proj(attn)
             RELAX_TRY(launch_layernorm_sp3(h, Xx, b.ln2_g, b.ln2_b, Ys, rows, dim, kLnEps, s));
             RELAX_TRY(launch_gemm_x6(h, Ys, b.fc1.w_sp3, b.fc1.b, nullptr, nullptr, Hs, rows, 4 * dim, dim, 2, s)); // GELU(erf) -> sp3

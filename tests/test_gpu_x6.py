@@ -246,3 +246,26 @@ def test_resnet50_every_tap_under_x6_and_error_against_fp64():
     n32, n6, ncpu = rel(ls32.cpu().numpy(), ls64), rel(ls6.cpu().numpy(), ls64), rel(want_ls, ls64)
     print(f"layer-stack 13120 vs fp64: fp32 MFMA path {n32:.3e}  bf16x6 {n6:.3e}  torch CPU fp32 {ncpu:.3e}")
     assert n6 < 1e-6      # the spatial means keep the (small) bias of the matrix core's product alignment: measured 5e-7
+
+
+@pytest.mark.parametrize("n_img,heads,scale", [(1, 3, 1.0), (3, 12, 1.0), (2, 6, 4.0), (40, 12, 2.0)])
+def test_attention_under_x6(n_img, heads, scale):
+    """softmax(q k^T / 8) v with both contractions on split planes (csrc/attention_x6.hip) against fp64, beside the fp32-MFMA
+    attention kernel; scale 4 makes logits of +-60 (near one-hot rows); 40 images x 12 heads = 480 items > 256 workgroups
+    exercises the persistent loop (K of the next item prefetched under the output phase)."""
+    eng = engine()
+    dim = heads * 64
+    qkv = _rand(n_img * 197, 3 * dim, seed=17, scale=scale)
+    t = qkv.double().reshape(n_img, 197, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    attn = ((t[0] @ t[1].transpose(-2, -1)) * 64 ** -0.5).softmax(dim=-1)
+    ref = (attn @ t[2]).transpose(1, 2).reshape(n_img * 197, dim)
+    eng.set_precision("fp32")
+    e32 = (eng.op_attention(qkv.cuda(), n_img, heads).cpu().double() - ref).abs()
+    eng.set_precision("bf16x6")
+    got = eng.op_attention(qkv.cuda(), n_img, heads)
+    again = eng.op_attention(qkv.cuda(), n_img, heads)
+    assert torch.equal(got, again)
+    assert_close(got, ref.float().numpy(), f"x6 attention n={n_img} heads={heads}")
+    e6 = (got.cpu().double() - ref).abs()
+    print(f"\nattention {n_img}x{heads} scale {scale}: mean err fp32 {e32.mean().item():.3e} x6 {e6.mean().item():.3e}; max fp32 {e32.max().item():.3e} x6 {e6.max().item():.3e}")
+    assert e6.mean().item() <= 1.25 * e32.mean().item() + 1e-12 and e6.max().item() <= 2.0 * e32.max().item() + 1e-12

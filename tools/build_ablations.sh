@@ -12,7 +12,7 @@ cd "$(dirname "$0")/../relax-vqa_amd/csrc"
 make -s
 mkdir -p ../../tools/abl
 CC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-function"
-OBJS="api.o fragment.o flow.o resize.o gemm.o gemm_x6.o layers.o resnet50.o vit.o head.o"
+OBJS="api.o fragment.o flow.o resize.o gemm.o gemm_x6.o attention_x6.o layers.o resnet50.o vit.o head.o"
 link() {  # link <replaced object> <new object> <output name>
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 ${OBJS/$1/$2} -o ../../tools/abl/librelax_$3.so
 }
