@@ -32,7 +32,7 @@
 #define X6_STAMP(i_)
 #endif
 #ifndef RELAX_X6_ABLATE
-#define RELAX_X6_ABLATE 0   // build-time timing experiments (WRONG results): 1 no DMA in the K loop, 2 every DMA re-reads K step 0 (L2 hits)
+#define RELAX_X6_ABLATE 0   // build-time experiments: 1 no DMA in the K loop (WRONG results), 2 every DMA re-reads K step 0 (WRONG), 4 pin the instruction order of a pipeline region with sched_group_barrier
 #endif
 
 namespace relax {
@@ -108,6 +108,8 @@ constexpr int64_t kMaxRecords = 0x7ffffff0;
 //            wait own DMA of step k+1, barrier          (stage k is now fully in registers -> free; stage k+1 has landed)
 //            issue the DMA of step k+2 into stage k,  read X and Y-half 0 of stage k+1
 //            [ M1(k): MFMAs on Y-half 1 ]
+// (the loop body is rotated: one "region" = barrier .. next barrier = M1(k) + M0(k+1), so that the instruction interleave of a
+// whole region can be pinned with sched_group_barrier)
 // X = the operand with fewer fragments per wave (double-buffered in registers), Y = the other one (two halves).
 template <int BM, int BN, int WM, int WN, bool TAPS>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8
@@ -316,12 +318,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         }                                                                                                               \
     }
     // one K step on stage xs_ (= its parity): has_next_ / has_d_ are literal `true` in the steady state (branch-free body)
-#define X6_STEP(xs_, has_next_, has_d_)                                                                                 \
+    // One pipeline region = everything between two barriers: [wait, barrier, DMA of step k+2, reads of X and Y-half-0 of step
+    // k+1, M1(k), reads of Y-half-1 of step k+1, M0(k+1)].  xs_ = parity (= LDS stage) of step k.  has_next_ / has_d_ are
+    // literal `true` in the steady state (branch-free).  Rotating the loop this way (one basic block per region) was worth
+    // 2.5 % by itself; PINNING the order inside a region with sched_group_barrier (build experiment RELAX_X6_ABLATE=4: reads of
+    // the next step first, the DMA pieces spread one per three MFMAs, Y-half-1 reads two MFMAs apart) measured 7 % slower than
+    // what the compiler's scheduler does on its own, so it is off.  Masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read.
+#define X6_REGION(xs_, has_next_, has_d_, steady_)                                                                      \
     {                                                                                                                   \
-        const char* sp_ = smem + (xs_) * STAGE;                                                                         \
         const char* sn_ = smem + ((xs_) ^ 1) * STAGE;                                                                   \
-        X6_READ_Y(yf1, 1, sp_);                                                                                         \
-        X6_MFMAS(xs_, yf0, 0);                                                                                          \
         if (has_next_) {                                                                                                \
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
             __builtin_amdgcn_s_barrier();                                                                               \
@@ -330,6 +335,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             X6_READ_Y(yf0, 0, sn_);                                                                                     \
         }                                                                                                               \
         X6_MFMAS(xs_, yf1, 1);                                                                                          \
+        if (has_next_) {                                                                                                \
+            X6_READ_Y(yf1, 1, sn_);                                                                                     \
+            X6_MFMAS((xs_) ^ 1, yf0, 0);                                                                                \
+        }                                                                                                               \
+        if (steady_ && (RELAX_X6_ABLATE & 4)) {   /* experiment only: measured 7 % SLOWER than the compiler's own order */                                                                        \
+            constexpr int NREAD_ = (XT + YH) * 3;      /* X' and Y-half-0 fragments of the next step */                 \
+            constexpr int NM_ = XT * YH * 6;           /* MFMAs of a half step */                                       \
+            constexpr int M_DMA_ = (NM_ - NREAD_ / 2) / PPW > 0 ? (NM_ - NREAD_ / 2) / PPW : 1;                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < NREAD_ / 2; ++i_) {                                                 \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                      \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
+            }                                                                                                           \
+            _Pragma("unroll") for (int i_ = 0; i_ < PPW; ++i_) {                                                        \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                      \
+                __builtin_amdgcn_sched_group_barrier(0x008, M_DMA_, 0);                                                 \
+            }                                                                                                           \
+            if (NM_ - NREAD_ / 2 - M_DMA_ * PPW > 0)                                                                    \
+                __builtin_amdgcn_sched_group_barrier(0x008, NM_ - NREAD_ / 2 - M_DMA_ * PPW, 0);                        \
+            _Pragma("unroll") for (int i_ = 0; i_ < YH * 3; ++i_) {                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
+            }                                                                                                           \
+        }                                                                                                               \
     }
 
     const int nk = kt_end - kt_begin;
@@ -342,16 +370,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     X6_READ_Y(yf0, 0, smem);
     X6_STAMP(1);
     X6_STAMP(6);
+    X6_READ_Y(yf1, 1, smem);
+    X6_MFMAS(0, yf0, 0);          // M0 of step 0
     int k = 0;
     for (; k + 3 < nk; k += 2) {
-        X6_STEP(0, true, true);
-        X6_STEP(1, true, true);
+        X6_REGION(0, true, true, true);
+        X6_REGION(1, true, true, true);
     }
     for (; k < nk; k += 2) {
-        X6_STEP(0, k + 1 < nk, k + 2 < nk);
-        if (k + 1 < nk) X6_STEP(1, k + 2 < nk, k + 3 < nk);
+        X6_REGION(0, k + 1 < nk, k + 2 < nk, false);
+        if (k + 1 < nk) X6_REGION(1, k + 2 < nk, k + 3 < nk, false);
     }
-#undef X6_STEP
+#undef X6_REGION
 #undef X6_MFMAS
 #undef X6_READ_X
 #undef X6_READ_Y
