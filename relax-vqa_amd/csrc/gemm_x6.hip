@@ -124,7 +124,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int YH = YT / 2;
     constexpr int ROWS = BM + BN;
     constexpr int STAGE = ROWS * kChunkBytes;
-    constexpr int NSTAGE = 2;
+    constexpr int NSTAGE = 2;                     // three stages (8-wave tile: 144 KB, DMA two steps ahead) measured 1.5 % slower
     constexpr int PIECES = ROWS * 6 / 64;         // 1 KiB DMA pieces per stage
     constexpr int A_PIECES = BM * 6 / 64;
     constexpr int PPW = (PIECES + NW - 1) / NW;   // pieces per wave (a wave short of real pieces issues dummy ones)
@@ -326,11 +326,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     // what the compiler's scheduler does on its own, so it is off.  Masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read.
 #define X6_REGION(xs_, has_next_, has_d_, steady_)                                                                      \
     {                                                                                                                   \
-        const char* sn_ = smem + ((xs_) ^ 1) * STAGE;                                                                   \
+        const int st_next_ = NSTAGE == 2 ? ((xs_) ^ 1) : (st_cur + 1 < NSTAGE ? st_cur + 1 : 0);                        \
+        const char* sn_ = smem + st_next_ * STAGE;                                                                      \
         if (has_next_) {                                                                                                \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+            /* own DMA pieces of step k+1 have landed (those of the steps after it stay in flight), own reads are done */ \
+            if (has_d_ || NSTAGE == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * PPW) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
             __builtin_amdgcn_s_barrier();                                                                               \
-            if (has_d_ && !(RELAX_X6_ABLATE & 1)) X6_ISSUE(xs_);                                                        \
+            /* every wave has stage k in registers: it is free for step k + NSTAGE */                                  \
+            if (has_d_ && !(RELAX_X6_ABLATE & 1)) X6_ISSUE(NSTAGE == 2 ? (xs_) : st_cur);                               \
             X6_READ_X((xs_) ^ 1, sn_);                                                                                  \
             X6_READ_Y(yf0, 0, sn_);                                                                                     \
         }                                                                                                               \
@@ -339,6 +343,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             X6_READ_Y(yf1, 1, sn_);                                                                                     \
             X6_MFMAS((xs_) ^ 1, yf0, 0);                                                                                \
         }                                                                                                               \
+        st_cur = st_next_;                                                                                              \
         if (steady_ && (RELAX_X6_ABLATE & 4)) {   /* experiment only: measured 7 % SLOWER than the compiler's own order */                                                                        \
             constexpr int NREAD_ = (XT + YH) * 3;      /* X' and Y-half-0 fragments of the next step */                 \
             constexpr int NM_ = XT * YH * 6;           /* MFMAs of a half step */                                       \
@@ -363,9 +368,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     const int nk = kt_end - kt_begin;
     X6_ISSUE(0);
     if (nk > 1) X6_ISSUE(1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    if (NSTAGE == 3 && nk > 2) X6_ISSUE(2);
+    if (NSTAGE == 3 && nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    int st_cur = 0;
     X6_READ_X(0, smem);
     X6_READ_Y(yf0, 0, smem);
     X6_STAMP(1);
@@ -373,13 +381,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     X6_READ_Y(yf1, 1, smem);
     X6_MFMAS(0, yf0, 0);          // M0 of step 0
     int k = 0;
-    for (; k + 3 < nk; k += 2) {
+    // region k: has_next = step k+1 exists; has_d = step k + NSTAGE exists (its DMA is issued here)
+    for (; k + NSTAGE + 1 < nk; k += 2) {
         X6_REGION(0, true, true, true);
         X6_REGION(1, true, true, true);
     }
     for (; k < nk; k += 2) {
-        X6_REGION(0, k + 1 < nk, k + 2 < nk, false);
-        if (k + 1 < nk) X6_REGION(1, k + 2 < nk, k + 3 < nk, false);
+        X6_REGION(0, k + 1 < nk, k + NSTAGE < nk, false);
+        if (k + 1 < nk) X6_REGION(1, k + 2 < nk, k + 1 + NSTAGE < nk, false);
     }
 #undef X6_REGION
 #undef X6_MFMAS
