@@ -98,30 +98,42 @@ __global__ __launch_bounds__(256) void patch_score_generic(const uint8_t* __rest
 // One workgroup per item.  Order = (score desc, flat index asc); output = the selected flat
 // indices in ascending order (== the reference's re-sort by (y,x)).  Two-level 16-bit radix select
 // for the n-th largest score, then an ordered compaction with a block-wide prefix sum.
-constexpr int SEL_THREADS = 1024;
+constexpr int SEL_THREADS = 256;   // 4 waves per pair: the work is latency, not bandwidth (32 KB of scores per 1080p pair)
+constexpr int SEL_BINS = 1024;
 
-__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
-    // lds: [SEL_THREADS]; Hillis-Steele inclusive scan
-    const int tid = threadIdx.x;
-    lds[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < SEL_THREADS; off <<= 1) {
-        uint32_t add = tid >= off ? lds[tid - off] : 0u;
-        __syncthreads();
-        lds[tid] += add;
-        __syncthreads();
+__device__ inline uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(v, off);
+        if (lane >= off) v += u;
     }
-    const uint32_t incl = lds[tid];
-    *total = lds[SEL_THREADS - 1];
+    return v;
+}
+
+// exclusive prefix sum over the 256 threads (wave scans by lane shuffles, then the 4 wave totals through LDS)
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_tot, uint32_t* total) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t incl = wave_inclusive_scan(v);
+    __syncthreads();                       // wave_tot may still be read from the previous scan
+    if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
-    return incl - v;
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_THREADS / 64; ++w) {
+        const uint32_t t = wave_tot[w];
+        before += w < wave ? t : 0u;
+        all += t;
+    }
+    *total = all;
+    return before + incl - v;
 }
 
 __global__ __launch_bounds__(SEL_THREADS) void select_topn(const uint32_t* __restrict__ scores, int npatch, int pw,
                                                            int top_n, int32_t* __restrict__ positions,
                                                            int32_t* __restrict__ counts) {
-    __shared__ uint32_t hist[1024];  // 10 bits per level x 2 levels = 20-bit scores (max 195840 < 2^18)
-    __shared__ uint32_t scan[SEL_THREADS];
+    __shared__ uint32_t hist[SEL_BINS];  // 10 bits per level x 2 levels = 20-bit scores (max 195840 < 2^18)
+    __shared__ uint32_t wave_tot[SEL_THREADS / 64];
     __shared__ uint32_t sh_digit, sh_remaining;
     const int t = blockIdx.x;
     const int tid = threadIdx.x;
@@ -140,22 +152,27 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topn(const uint32_t* __res
         uint32_t prefix = 0;
         for (int level = 1; level >= 0; --level) {
             const int shift = level * 10;
-            hist[tid] = 0;  // SEL_THREADS == 1024 == bins
+            for (int b = tid; b < SEL_BINS; b += SEL_THREADS) hist[b] = 0;
             __syncthreads();
             for (int i = tid; i < npatch; i += SEL_THREADS) {
                 const uint32_t v = s[i];
                 if (level == 1 || (v >> 10) == prefix) atomicAdd(&hist[(v >> shift) & 1023u], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                uint32_t acc = 0;
-                int d = 1023;
-                for (; d > 0; --d) {
-                    if (acc + hist[d] >= remaining) break;
-                    acc += hist[d];
+            // the digit d with  count(bins > d) < remaining <= count(bins >= d):  thread k owns the 4 bins
+            // 1023-4k .. 1020-4k (descending), a block scan gives the count of everything above its bins
+            uint32_t h[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = hist[1023 - 4 * tid - j];
+            uint32_t tot;
+            uint32_t above = block_exclusive_scan(h[0] + h[1] + h[2] + h[3], wave_tot, &tot);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (above < remaining && above + h[j] >= remaining) {   // exactly one (thread, j) satisfies this
+                    sh_digit = (uint32_t)(1023 - 4 * tid - j);
+                    sh_remaining = remaining - above;  // still to take from bin d (>= 1)
                 }
-                sh_digit = (uint32_t)d;
-                sh_remaining = remaining - acc;  // still to take from bin d (>= 1)
+                above += h[j];
             }
             __syncthreads();
             remaining = sh_remaining;
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topn(const uint32_t* __res
 
     // ordered compaction: each thread owns a contiguous run of flat indices
     const int per = (npatch + SEL_THREADS - 1) / SEL_THREADS;
-    const int lo = tid * per;
+    const int lo = tid * per < npatch ? tid * per : npatch;
     const int hi = lo + per < npatch ? lo + per : npatch;
     uint32_t n_gt = 0, n_eq = 0;
     for (int i = lo; i < hi; ++i) {
@@ -177,11 +194,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topn(const uint32_t* __res
         n_eq += v == thr;
     }
     uint32_t total_eq, total_sel;
-    const uint32_t eq_before = block_exclusive_scan(n_eq, scan, &total_eq);
+    const uint32_t eq_before = block_exclusive_scan(n_eq, wave_tot, &total_eq);
     uint32_t eq_take = 0;
     if (need_ties == 0xffffffffu) eq_take = n_eq;
     else if (eq_before < need_ties) eq_take = (need_ties - eq_before) < n_eq ? (need_ties - eq_before) : n_eq;
-    const uint32_t out_before = block_exclusive_scan(n_gt + eq_take, scan, &total_sel);
+    const uint32_t out_before = block_exclusive_scan(n_gt + eq_take, wave_tot, &total_sel);
     uint32_t o = out_before, eq_left = eq_take;
     for (int i = lo; i < hi; ++i) {
         const uint32_t v = s[i];
