@@ -81,6 +81,7 @@ struct X6Params {
     int act;
     int tiles_m, tiles_n, ntiles, group_m;
     int full_tiles, nsplit;
+    int f0, pu;                   // launch order: f0 full tiles, then pu split units (phase start, see launch_x6_variant), then the rest
     int stagger;                  // cycles of one tile: XCD x delays its first round by x/8 of it (0 = off)
     int first_round;              // workgroups resident at launch (256 CUs x workgroups per CU)
     unsigned long long* stamps;   // RELAX_X6_STAMPS builds only
@@ -142,12 +143,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     int tile, kt_begin, kt_end, slice = -1, split_tile = 0;
     {
         const int nk_all = p.K >> 4;
-        if ((int)blockIdx.x < p.full_tiles) {
-            tile = xcd_remap6(blockIdx.x, p.full_tiles);
+        const int b = blockIdx.x;
+        const bool early_split = b >= p.f0 && b < p.f0 + p.pu;
+        if (!early_split && b < p.pu + p.full_tiles) {
+            tile = xcd_remap6(b < p.f0 ? b : b - p.pu, p.full_tiles);
             kt_begin = 0;
             kt_end = nk_all;
         } else {
-            const int u = blockIdx.x - p.full_tiles;
+            const int u = early_split ? b - p.f0 : b - p.full_tiles;
             split_tile = u / p.nsplit;
             slice = u - split_tile * p.nsplit;
             tile = p.full_tiles + split_tile;
@@ -399,8 +402,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     __syncthreads();   // no DMA is in flight and every fragment is in registers: the stages become the epilogue staging
 
     // ---- epilogue, staged through LDS in 64-row chunks (C/D map of the 32x32 MFMA: col = lane & 31,
-    // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); a thread owns 8 consecutive columns: bias / residual / activation
-    // fused, 16-byte stores to the fp32 output and / or the three planes of the sp3 output
+    // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); a thread owns two groups of 4 columns, at lcA and lcB: bias / residual /
+    // activation fused, 16-byte stores.  With split planes on either side (sp3 output or residual) the groups are adjacent
+    // (8 consecutive columns = whole 16-byte plane units); for plain fp32 traffic group B sits half a tile row further, so
+    // that the 64 lanes of ONE store / load instruction cover contiguous 512-byte row segments (adjacent groups made every
+    // instruction touch 16 of each 32 bytes: twice the memory requests, and the 256x256 epilogue is bound by them)
     float* stg = reinterpret_cast<float*>(smem);
     constexpr int LDC = BN + 4;
     constexpr int EP_ROWS = 64;
@@ -410,13 +416,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int EP_STEP = NT / C8;
     constexpr int EP_ITERS = EP_ROWS / EP_STEP;
     const int half = lane >> 5;
-    const int lc = (tid % C8) * 8;
+    const bool planes = p.out_sp3 != nullptr || p.residual_sp3 != nullptr;   // workgroup-uniform
+    const int lcA = planes ? (tid % C8) * 8 : (tid % C8) * 4;
+    const int lcB = planes ? lcA + 4 : lcA + BN / 2;
     const int lr0 = tid / C8;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 bias_a = zero4, bias_b = zero4;
     if (slice < 0 && p.bias) {
-        bias_a = *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
-        bias_b = *reinterpret_cast<const f32x4*>(p.bias + n0 + lc + 4);
+        bias_a = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcA);
+        bias_b = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcB);
     }
     const bool interior = m0 + BM <= p.M;   // workgroup-uniform
 #pragma unroll
@@ -431,9 +439,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 ra[it] = zero4;
                 rb[it] = zero4;
                 if (interior || m < p.M) {
-                    const float* r = p.residual + (int64_t)m * p.N + n0 + lc;
-                    ra[it] = *reinterpret_cast<const f32x4*>(r);
-                    rb[it] = *reinterpret_cast<const f32x4*>(r + 4);
+                    const float* r = p.residual + (int64_t)m * p.N + n0;
+                    ra[it] = *reinterpret_cast<const f32x4*>(r + lcA);
+                    rb[it] = *reinterpret_cast<const f32x4*>(r + lcB);
                 }
             }
         } else if (slice < 0 && p.residual_sp3) {
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 ra[it] = zero4;
                 rb[it] = zero4;
                 if (interior || m < p.M) {
-                    const char* r = p.residual_sp3 + (int64_t)m * ((int64_t)p.N * 6) + sp3_offset(n0 + lc);
+                    const char* r = p.residual_sp3 + (int64_t)m * ((int64_t)p.N * 6) + sp3_offset(n0 + lcA);
                     const u32x4 hi = *reinterpret_cast<const u32x4*>(r), mid = *reinterpret_cast<const u32x4*>(r + 32),
                                 lo = *reinterpret_cast<const u32x4*>(r + 64);
 #define X6_UNSPLIT(h_, m_, l_, sh_) ((__uint_as_float(sh_ ? (h_) & 0xffff0000u : (h_) << 16) + __uint_as_float(sh_ ? (m_) & 0xffff0000u : (m_) << 16)) + \
@@ -475,12 +483,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             const int trow = pass * EP_ROWS + lr;
             const int m = m0 + trow;
             if (!interior && m >= p.M) continue;
-            f32x4 va = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lc);
-            f32x4 vb = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lc + 4);
+            f32x4 va = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lcA);
+            f32x4 vb = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lcB);
             if (slice >= 0) {   // K slice of a split tile: raw partial sums, the epilogue runs in splitk_finish_x6
-                float* o = p.partial + ((int64_t)split_tile * p.nsplit + slice) * (BM * BN) + (int64_t)trow * BN + lc;
-                *reinterpret_cast<f32x4*>(o) = va;
-                *reinterpret_cast<f32x4*>(o + 4) = vb;
+                float* o = p.partial + ((int64_t)split_tile * p.nsplit + slice) * (BM * BN) + (int64_t)trow * BN;
+                *reinterpret_cast<f32x4*>(o + lcA) = va;
+                *reinterpret_cast<f32x4*>(o + lcB) = vb;
                 continue;
             }
             va += bias_a;
@@ -496,15 +504,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 va = (f32x4){act_gelu(va.x), act_gelu(va.y), act_gelu(va.z), act_gelu(va.w)};
                 vb = (f32x4){act_gelu(vb.x), act_gelu(vb.y), act_gelu(vb.z), act_gelu(vb.w)};
             }
-            const int64_t o = (int64_t)m * p.N + n0 + lc;
+            const int64_t o = (int64_t)m * p.N + n0;
             if (p.out) {
-                *reinterpret_cast<f32x4*>(p.out + o) = va;
-                *reinterpret_cast<f32x4*>(p.out + o + 4) = vb;
+                *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
+                *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
             }
-            if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lc, va, vb);
+            if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lcA, va, vb);   // (planes: lcB = lcA + 4)
             if (p.gap) {   // the finished values go back to the staging rows for the group sums below
-                *reinterpret_cast<f32x4*>(stg + lr * LDC + lc) = va;
-                *reinterpret_cast<f32x4*>(stg + lr * LDC + lc + 4) = vb;
+                *reinterpret_cast<f32x4*>(stg + lr * LDC + lcA) = va;
+                *reinterpret_cast<f32x4*>(stg + lr * LDC + lcB) = vb;
             }
         }
         if (p.gap && slice < 0) {
@@ -590,12 +598,28 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     p.full_tiles = p.ntiles;
     p.nsplit = 1;
     p.partial = nullptr;
-    // Tail split-K (same cost model as gemm.hip; two workgroups per CU).
+    p.f0 = 0;
+    p.pu = 0;
     const int slots = 256 * WG_PER_CU;
     const int nk = p.K / 16;
-    const int rem = p.ntiles % slots;
-    if (h->gemm.split_k && rem > 0 && !p.gap && !p.residual_sp3) {   // (the finish kernel knows neither of the two)
-        int best_s = 1;
+    const bool can_split = h->gemm.split_k && !p.gap && !p.residual_sp3;   // (the finish kernel knows neither of the two)
+    // Phase start ("gemm_phase" = S, one workgroup per CU): equal tiles keep all 256 CUs in lockstep, so every epilogue is a
+    // chip-wide burst of stores (and residual loads) that HBM serves in 40-50 k cycles while the matrix pipes idle.  Work that
+    // has to be done anyway - K slices of some tiles - is launched FIRST, arranged so that a third (quarter) of the CUs start
+    // on full tiles, the others on one, two (, three) short slices: from then on the CUs run 1/S of a tile apart and the
+    // bursts are spread over the tile time.  Launch order: f0 full tiles, pu split units, the other full tiles, the tail.
+    int phase_tiles = 0;
+    const int S_phase = h->gemm.phase;
+    if (can_split && WG_PER_CU == 1 && S_phase >= 2 && p.ntiles >= 3 * slots && nk >= 8 * S_phase) {
+        p.f0 = (slots / S_phase + 7) & ~7;
+        phase_tiles = ((slots * (S_phase - 1) / 2 + S_phase - 1) / S_phase + 7) & ~7;
+        p.pu = phase_tiles * S_phase;
+        p.nsplit = S_phase;
+    }
+    // Tail split-K (same cost model as gemm.hip): the last partial round of tiles is cut along K
+    const int rem = (p.ntiles - phase_tiles) % slots;
+    int best_s = 1;
+    if (can_split && rem > 0) {
         double best = 1.0;
         const int smax = nk / 8 < 16 ? nk / 8 : 16;
         for (int S = 2; S <= smax; ++S) {
@@ -605,13 +629,15 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
                 best_s = S;
             }
         }
-        if (best_s >= 2) {
-            const size_t need = sizeof(float) * (size_t)rem * best_s * BM * BN;
-            RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
-            p.partial = static_cast<float*>(h->splitk_ws.p);
-            p.full_tiles = p.ntiles - rem;
-            p.nsplit = best_s;
-        }
+        if (phase_tiles) best_s = S_phase;   // one slice count per launch (one finish kernel)
+    }
+    const int split_tiles = phase_tiles + (best_s >= 2 ? rem : 0);
+    if (split_tiles > 0) {
+        p.nsplit = phase_tiles ? S_phase : best_s;
+        const size_t need = sizeof(float) * (size_t)split_tiles * p.nsplit * BM * BN;
+        RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
+        p.partial = static_cast<float*>(h->splitk_ws.p);
+        p.full_tiles = p.ntiles - split_tiles;
     }
     // per-XCD stagger of the first round: one tile = its K loop at the full matrix rate (32 cycles per MFMA, two waves per SIMD)
     // plus an epilogue; "gemm_stagger" scales it in percent
