@@ -58,8 +58,22 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
             o.z = (v[j].z - mean) * rstd * gg.z + bb.z;
             o.w = (v[j].w - mean) * rstd * gg.w + bb.w;
             if (SP3) {
-                // values k = 4i .. 4i+3: 8 bytes of each plane of chunk k / 16 (96-byte chunks: [16 hi][16 mid][16 lo])
-                store_sp3_x4(static_cast<char*>(yv) + (int64_t)row * dim * 6, 4 * i, (sp3_f32x4){o.x, o.y, o.z, o.w});
+                // values k = 4i .. 4i+3 = 8 bytes of each plane of chunk k / 16.  Lanes 2j and 2j+1 hold the two halves of a
+                // 16-byte unit: after one exchange the even lane stores the hi and lo units, the odd lane the mid unit (three
+                // 16-byte stores per pair instead of six 8-byte ones: 8-byte stores run at 0.5-0.7 of the 16-byte rate)
+                sp3_u32x2 hi, mid, lo;
+                split3_x4((sp3_f32x4){o.x, o.y, o.z, o.w}, hi, mid, lo);
+                const bool odd = lane & 1;
+                // what the partner needs from this lane: even lane gives its mid, odd lane gives its hi and lo
+                const unsigned s0 = __shfl_xor(odd ? hi.x : mid.x, 1), s1 = __shfl_xor(odd ? hi.y : mid.y, 1);
+                const unsigned t0 = __shfl_xor(lo.x, 1), t1 = __shfl_xor(lo.y, 1);
+                char* d = static_cast<char*>(yv) + (int64_t)row * dim * 6 + (i >> 2) * 96 + ((i >> 1) & 1) * 16;
+                if (!odd) {
+                    *reinterpret_cast<sp3_u32x4*>(d) = (sp3_u32x4){hi.x, hi.y, s0, s1};            // hi: own 4 values, partner's 4
+                    *reinterpret_cast<sp3_u32x4*>(d + 64) = (sp3_u32x4){lo.x, lo.y, t0, t1};       // lo
+                } else {
+                    *reinterpret_cast<sp3_u32x4*>(d + 32) = (sp3_u32x4){s0, s1, mid.x, mid.y};     // mid: partner's 4 values, own 4
+                }
             } else {
                 reinterpret_cast<float4*>(static_cast<float*>(yv) + (int64_t)row * dim)[i] = o;
             }
