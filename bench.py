@@ -172,7 +172,7 @@ def main():
                     help="arithmetic of the contraction kernels for the headline loop.  bf16x6 (default): fp32 operands as three bf16 "
                          "planes, six partial products, fp32 accumulate - error against fp64 of the size of the fp32 path's "
                          "(tests/test_gpu_x6.py); fp32: exact fp32 MFMA; bf16x3: lower precision, never the headline")
-    ap.add_argument("--clips-per-step", type=int, default=8,
+    ap.add_argument("--clips-per-step", type=int, default=16,
                     help="clips each rank pushes through the engine per step (one batched pass: B*2*T fragments)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only rehearse the N-rank launch + collectives (no engine, no GPU needed): tests/test_bench_launch.py")

@@ -32,7 +32,7 @@
 #define X6_STAMP(i_)
 #endif
 #ifndef RELAX_X6_ABLATE
-#define RELAX_X6_ABLATE 0   // build-time experiments: 1 no DMA in the K loop (WRONG results), 2 every DMA re-reads K step 0 (WRONG), 4 pin the instruction order of a pipeline region with sched_group_barrier
+#define RELAX_X6_ABLATE 0   // build-time experiments: 1 no DMA in the K loop (WRONG results), 2 every DMA re-reads K step 0 (WRONG), 4 pin the instruction order of a pipeline region with sched_group_barrier, 8 GELU = identity (WRONG), 16 non-temporal fp32 output stores
 #endif
 
 namespace relax {
@@ -93,7 +93,10 @@ __device__ inline int xcd_remap6(int b, int nwg) {
     return base + (b >> 3);
 }
 
-__device__ inline float act_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ inline float act_gelu(float v) {
+    if (RELAX_X6_ABLATE & 8) return v;   // build experiment: what the exact-erf GELU costs in the epilogue (WRONG results)
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
 
 // global -> LDS without registers: 16 bytes per lane to LDS address M0 + 16 * lane; the source is base(rsrc) + voff + soff,
 // and a lane whose voff is beyond the resource's byte count gets zeros (rows past M, padding taps)
@@ -506,8 +509,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             }
             const int64_t o = (int64_t)m * p.N + n0;
             if (p.out) {
-                *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
-                *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
+                if (RELAX_X6_ABLATE & 16) {   // build experiment: non-temporal stores
+                    __builtin_nontemporal_store(va, reinterpret_cast<f32x4*>(p.out + o + lcA));
+                    __builtin_nontemporal_store(vb, reinterpret_cast<f32x4*>(p.out + o + lcB));
+                } else {
+                    *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
+                    *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
+                }
             }
             if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lcA, va, vb);   // (planes: lcB = lcA + 4)
             if (p.gap) {   // the finished values go back to the staging rows for the group sums below
