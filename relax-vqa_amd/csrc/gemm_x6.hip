@@ -14,15 +14,24 @@
 //        chunk = [16 x bf16 hi][16 x bf16 mid][16 x bf16 lo]
 // so one 16-deep K step of one row is 96 contiguous bytes whose 16-byte units are exactly the MFMA fragments
 // (lane (r, h) of a 32x32x16 MFMA holds k = 8h .. 8h+7 of row r).  The split happens ONCE where a value is produced
-// (weights at load time, activations in the producing kernel's epilogue / LayerNorm / im2sp3), never in the K loop:
-// the loop has no VALU work, and tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4) without touching registers.
+// (weights at load time, activations in the producing kernel's epilogue / LayerNorm / patchify / max-pool), never in the
+// K loop: the loop has no VALU work, and tiles go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) without
+// touching registers.
 //
-// Structure: 256x256 tile on 8 waves (128x64 per wave, 8 accumulators of 32x32), BK = 16, THREE LDS stages of
-// 512 rows x 96 B (144 KB), one barrier per K step, the DMA of step k+2 issued right after the barrier of step k
-// (counted s_waitcnt vmcnt: loads stay in flight across barriers).  LDS rows are 96 B; the two 16-byte halves of a
-// plane are swapped in rows with bit 3 set, which makes the ds_read_b128 fragment reads bank-conflict free (the
-// permutation is applied on the SOURCE address of the DMA, the LDS image stays linear).  Rows beyond M and padding
-// taps of an implicit-GEMM convolution read from a page of zeros.
+// Structure: 256x256 tile on 8 waves (2 x 4, 128x64 per wave, 8 accumulators of 32x32), BK = 16, TWO LDS stages of
+// 512 rows x 96 B (96 KB + a 1 KB landing page for the padding pieces), one raw s_barrier per K step.  The K loop is
+// rotated into barrier-to-barrier "regions": region k issues the DMA of step k+1 into the stage step k-1 just left,
+// reads the fragments of step k+1 ahead of their MFMAs (X operand double-buffered in registers, Y in halves) and
+// runs the 48 MFMAs of step k; counted s_waitcnt vmcnt keeps loads in flight across barriers.  LDS rows are 96 B; the
+// two 16-byte halves of a plane are swapped in rows with bit 3 set, which makes the ds_read_b128 fragment reads
+// bank-conflict free (the permutation is applied on the SOURCE offset of the DMA, the LDS image stays linear).  Rows
+// beyond M and the padding taps of an implicit-GEMM convolution use an out-of-range buffer offset, which the buffer
+// unit answers with zeros.  Narrower outputs run the same loop on 4 waves (256x128, 256x64: two workgroups per CU);
+// the last, partial round of tiles is split along K (splitk_finish_x6 adds the slices in a fixed order).  The
+// epilogue goes through LDS in 64-row passes so that every store instruction writes whole 512-byte row segments, and
+// can add bias / an sp3 or fp32 residual, apply ReLU / GELU, write fp32 and / or sp3, and emit 16-row column sums for
+// the global-average-pool taps.  What was measured and NOT adopted (three stages, staggered starts, pinned
+// instruction order, non-temporal stores) is in DESIGN.md section 3.2.
 #include "relax_internal.h"
 #include "sp3.h"
 
