@@ -16,6 +16,7 @@
 // Defaults (launch_conv): fp32 128x128 tile, 4 waves, BK = 16, three workgroups per CU; 128x64 for N % 128 != 0;
 // opt-in bf16x3 precision: 256x256 tile on 8 waves for large plain GEMMs, 128-wide tiles otherwise.
 #include "relax_internal.h"
+#include "gelu.h"
 
 #ifndef RELAX_F32_ABLATE
 #define RELAX_F32_ABLATE 0  // build-time timing experiments on the fp32 loop (WRONG results): 1 no barrier, 2 no global loads,
@@ -80,7 +81,7 @@ __device__ inline void split_bf16x4(const f32x4 v, uint2* hi, uint2* lo) {
 
 __device__ inline float apply_act(float v, int act) {
     if (act == 1) return v > 0.f ? v : 0.f;
-    if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == 2) return gelu_erf(v);
     return v;
 }
 

@@ -34,6 +34,7 @@
 // instruction order, non-temporal stores) is in DESIGN.md section 3.2.
 #include "relax_internal.h"
 #include "sp3.h"
+#include "gelu.h"
 
 #ifdef RELAX_X6_STAMPS   // diagnostic build (tools/build_ablations.sh x6stamps): thread 0 of every workgroup records cycle stamps
 #define X6_STAMP(i_) if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime()
@@ -102,9 +103,9 @@ __device__ inline int xcd_remap6(int b, int nwg) {
     return base + (b >> 3);
 }
 
-__device__ inline float act_gelu(float v) {
+__device__ inline f32x4 act_gelu4(const f32x4 v) {
     if (RELAX_X6_ABLATE & 8) return v;   // build experiment: what the exact-erf GELU costs in the epilogue (WRONG results)
-    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    return gelu_erf4(v);
 }
 
 // global -> LDS without registers: 16 bytes per lane to LDS address M0 + 16 * lane; the source is base(rsrc) + voff + soff,
@@ -442,7 +443,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
 #pragma unroll
     for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
         if (pass > 0) __syncthreads();
-        // residual rows of this pass: requested before the accumulators are staged, in flight under the LDS traffic
+        // residual rows of this pass: requested before the accumulators are staged, in flight under the LDS traffic.  (Requesting them
+        // one pass ahead changes nothing: the epilogue takes the time the XCD's memory path needs for the tile's bytes - 17.7 k cycles
+        // for 256 KB of stores, 34 k with the 256 KB residual, chip-wide 7 TB/s - not the latency of these loads.)
         f32x4 ra[EP_ITERS], rb[EP_ITERS];
         if (slice < 0 && p.residual) {
 #pragma unroll
@@ -513,8 +516,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};
                 vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};
             } else if (p.act == 2) {
-                va = (f32x4){act_gelu(va.x), act_gelu(va.y), act_gelu(va.z), act_gelu(va.w)};
-                vb = (f32x4){act_gelu(vb.x), act_gelu(vb.y), act_gelu(vb.z), act_gelu(vb.w)};
+                va = act_gelu4(va);
+                vb = act_gelu4(vb);
             }
             const int64_t o = (int64_t)m * p.N + n0;
             if (p.out) {
@@ -594,8 +597,8 @@ __global__ __launch_bounds__(256) void splitk_finish_x6(const X6Params p) {
         va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};
         vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};
     } else if (p.act == 2) {
-        va = (f32x4){act_gelu(va.x), act_gelu(va.y), act_gelu(va.z), act_gelu(va.w)};
-        vb = (f32x4){act_gelu(vb.x), act_gelu(vb.y), act_gelu(vb.z), act_gelu(vb.w)};
+        va = act_gelu4(va);
+        vb = act_gelu4(vb);
     }
     if (p.out) {
         *reinterpret_cast<f32x4*>(p.out + o) = va;

@@ -103,6 +103,27 @@ def test_epilogue(x6, act):
     assert_close(rr, want, f"x6 in-place residual act={act}")
 
 
+def test_gelu_is_the_erf_gelu_to_fp32_rounding(each_precision):
+    """csrc/gelu.h (branch-free erfc form, tools/gelu_fit.py) against the fp64 function: identity weights make the contraction exact,
+    so the output IS gelu(x).  Largest error one rounding of the result; closer to the fp64 function than torch's own fp32 GELU
+    (which evaluates 1 + erf(x / sqrt 2) with its cancellation for x < 0).  Large tile (M >= 256) and small-tile / split finish paths."""
+    eng = engine()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.linspace(-9, 9, 64 * 700), rng.standard_normal(64 * 300) * 2, [-0.0, 0.0, 1e-30, -1e-30, 30.0, -30.0] * 32])
+    x = torch.from_numpy(x[: (x.size // 64) * 64].astype(np.float32).reshape(-1, 64))
+    eye = torch.eye(64)
+    true = (0.5 * x.double() * torch.special.erfc(-x.double() / np.sqrt(2.0))).numpy()
+    for rows in (x, x[:100]):
+        got = eng.op_gemm(rows.cuda(), eye.cuda(), act=2).cpu().double().numpy()
+        err = np.abs(got - true[: rows.shape[0]])
+        ref_err = np.abs(F.gelu(rows).double().numpy() - true[: rows.shape[0]])
+        print(f"\n{each_precision} rows {rows.shape[0]}: gelu max abs err {err.max():.3e} rms {np.sqrt((err ** 2).mean()):.3e}; torch fp32: {ref_err.max():.3e} / {np.sqrt((ref_err ** 2).mean()):.3e}")
+        assert err.max() < 5e-7 and np.sqrt((err ** 2).mean()) < 1e-7
+        assert np.sqrt((err ** 2).mean()) <= np.sqrt((ref_err ** 2).mean())
+    z = eng.op_gemm(torch.tensor([[-0.0] * 64] * 16).cuda(), eye.cuda(), act=2).cpu()
+    assert torch.all(z == 0)
+
+
 def test_split_k_is_deterministic_and_optional(x6):
     """300 tiles of 256x256: 44 tail tiles are cut along K.  Same bits run to run; with gemm_split_k = 0 the bits do not
     depend on how many rows travel together."""
