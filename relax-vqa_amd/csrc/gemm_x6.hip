@@ -116,14 +116,14 @@ __device__ inline f32x4 act_gelu4(const f32x4 v) {
 [[maybe_unused]] constexpr unsigned kOutOfRange = 0x80000000u;   // > every num_records below: the DMA writes zeros for that lane
 constexpr int64_t kMaxRecords = 0x7ffffff0;
 
-// Tile BM x BN on 4 waves (2 x 2), TWO workgroups per CU (the epilogue / prologue of one runs under the MFMAs of the other),
-// BK = 16, two LDS stages.  The fragment reads are software-pipelined one half-step ahead of the MFMAs that use them:
+// Tile BM x BN on WM x WN waves (256x256 on 2 x 4: one workgroup per CU; 256x128 / 256x64 on four waves: two workgroups per
+// CU), BK = 16, two LDS stages.  The fragment reads are software-pipelined one half-step ahead of the MFMAs that use them:
 //   step k:  [ M0(k): MFMAs on Y-half 0 ]  while reading Y-half 1 of stage k
 //            wait own DMA of step k+1, barrier          (stage k is now fully in registers -> free; stage k+1 has landed)
 //            issue the DMA of step k+2 into stage k,  read X and Y-half 0 of stage k+1
 //            [ M1(k): MFMAs on Y-half 1 ]
-// (the loop body is rotated: one "region" = barrier .. next barrier = M1(k) + M0(k+1), so that the instruction interleave of a
-// whole region can be pinned with sched_group_barrier)
+// (the loop body is rotated: one "region" = barrier .. next barrier = M1(k) + M0(k+1) is one basic block, which the compiler's
+// scheduler interleaves better than any order pinned by hand)
 // X = the operand with fewer fragments per wave (double-buffered in registers), Y = the other one (two halves).
 template <int BM, int BN, int WM, int WN, bool TAPS>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int YH = YT / 2;
     constexpr int ROWS = BM + BN;
     constexpr int STAGE = ROWS * kChunkBytes;
-    constexpr int NSTAGE = 2;                     // three stages (8-wave tile: 144 KB, DMA two steps ahead) measured 1.5 % slower
+    constexpr int NSTAGE = 2;                     // a third stage (8-wave tile: 144 KB, DMA two steps ahead) measured no faster
     constexpr int PIECES = ROWS * 6 / 64;         // 1 KiB DMA pieces per stage
     constexpr int A_PIECES = BM * 6 / 64;
     constexpr int PPW = (PIECES + NW - 1) / NW;   // pieces per wave (a wave short of real pieces issues dummy ones)

@@ -2,6 +2,8 @@
 """Summarises the rocprofv3 PMC passes of bench.py into profiles/:
    python tools/summarize_pmc.py hbm  FETCH_DIR WRITE_DIR TAG [CLIPS_PER_STEP]   -> profiles/r01_hbm_traffic_TAG.txt + r01_hbm_traffic.json
    python tools/summarize_pmc.py sq   SQ_DIR TAG                                 -> profiles/r01_pmc_sq_bench_TAG.txt
+   python tools/summarize_pmc.py hbm2 FETCH_DIR WRITE_DIR TAG WORKLOAD CLIPS PRECISION KERNEL_PREFIX [JSON]   (round 2+: RELAX_ROUND=r02)
+   python tools/summarize_pmc.py tcc  TCC_DIR TAG DESCRIPTION                    -> profiles/rNN_l2_hit_rate_TAG.txt
 FETCH_SIZE / WRITE_SIZE are KiB per dispatch; FETCH_SIZE is doubled in the corrected figure (gfx950 reports half of a 16-B
 per lane streaming read, MI355X_MICROARCH.md, HBM / rocprofv3 section).  Passes are collected separately (one --pmc each)."""
 import collections
@@ -20,8 +22,13 @@ def short(name):
     return m.group(1) if m else None
 
 
+def newest(dirname):
+    """gpurun merges every call's output into the same directory: take the most recent pass, never an arbitrary one."""
+    return max(glob.glob(os.path.join(dirname, "*", "*counter_collection.csv")), key=os.path.getmtime)
+
+
 def per_kernel(dirname, counter):
-    path = glob.glob(os.path.join(dirname, "*", "*counter_collection.csv"))[0]
+    path = newest(dirname)
     tot, cnt = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
@@ -93,7 +100,7 @@ def hbm(fetch_dir, write_dir, tag, clips=8):
 
 
 def sq(sq_dir, tag):
-    path = glob.glob(os.path.join(sq_dir, "*", "*counter_collection.csv"))[0]
+    path = newest(sq_dir)
     acc = collections.defaultdict(collections.Counter)
     dur = collections.Counter()
     seen = set()
@@ -122,11 +129,25 @@ def sq(sq_dir, tag):
     print("\n".join(lines))
 
 
+def tcc(tcc_dir, tag, what):
+    hit, n = per_kernel(tcc_dir, "TCC_HIT_sum")
+    miss, _ = per_kernel(tcc_dir, "TCC_MISS_sum")
+    lines = [f"rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum (own pass) on `bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+             f"--no-fast-mode --no-h2d` ({what}): L2 hit rate per kernel"]
+    for k in sorted(hit, key=lambda k: -(hit[k] + miss[k]))[:10]:
+        lines.append(f"{k:62s} hits {hit[k]:.3e} misses {miss[k]:.3e} hit rate {hit[k] / max(hit[k] + miss[k], 1):.3f}")
+    out = os.path.join(ROOT, "profiles", f"{os.environ.get('RELAX_ROUND', 'r01')}_l2_hit_rate_{tag}.txt")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "hbm":
         hbm(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 8)
     elif sys.argv[1] == "hbm2":   # hbm2 FETCH_DIR WRITE_DIR TAG WORKLOAD CLIPS PRECISION MAIN_PREFIX [OUT_JSON]
         hbm2(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), sys.argv[7], sys.argv[8],
              sys.argv[9] if len(sys.argv) > 9 else None)
+    elif sys.argv[1] == "tcc":    # tcc TCC_DIR TAG DESCRIPTION
+        tcc(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         sq(sys.argv[2], sys.argv[3])
