@@ -42,7 +42,7 @@
 #define X6_STAMP(i_)
 #endif
 #ifndef RELAX_X6_ABLATE
-#define RELAX_X6_ABLATE 0   // build-time experiments: 1 no DMA in the K loop (WRONG results), 2 every DMA re-reads K step 0 (WRONG), 4 pin the instruction order of a pipeline region with sched_group_barrier, 8 GELU = identity (WRONG), 16 non-temporal fp32 output stores
+#define RELAX_X6_ABLATE 0   // build-time experiments: 1 no DMA in the K loop (WRONG results), 2 every DMA re-reads K step 0 (WRONG), 4 pin the instruction order of a pipeline region with sched_group_barrier, 8 GELU = identity (WRONG), 16 non-temporal fp32 output stores, 32 split-plane output as linear 1 KiB-per-wave stores (WRONG layout; worth 0.4 % of a ViT pass: the 32-byte runs of the plane stores are not what bounds the epilogue)
 #endif
 
 namespace relax {
@@ -529,7 +529,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                     *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
                 }
             }
-            if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lcA, va, vb);   // (planes: lcB = lcA + 4)
+            if (p.out_sp3) {
+                if (RELAX_X6_ABLATE & 32) {   // build experiment (WRONG layout): the same bytes as linear 1 KiB-per-wave stores
+                    sp3_u32x4 hi, mid, lo;
+                    split3_x8(va, vb, hi, mid, lo);
+                    char* d = p.out_sp3 + ((int64_t)(tm * p.tiles_n + tn) * (BM * BN * 6)) + (int64_t)((pass * EP_ITERS + it) * 3) * (NT * 16) + tid * 16;
+                    *reinterpret_cast<sp3_u32x4*>(d) = hi;
+                    *reinterpret_cast<sp3_u32x4*>(d + NT * 16) = mid;
+                    *reinterpret_cast<sp3_u32x4*>(d + 2 * NT * 16) = lo;
+                } else {
+                    store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lcA, va, vb);   // (planes: lcB = lcA + 4)
+                }
+            }
             if (p.gap) {   // the finished values go back to the staging rows for the group sums below
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcA) = va;
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcB) = vb;
