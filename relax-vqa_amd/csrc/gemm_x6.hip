@@ -78,7 +78,7 @@ int launch_to_sp3(relax_handle* h, const float* x, int64_t ld, void* y, int64_t 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
 struct X6Params {
     const char* a;        // sp3 activations: [M][K*6 B] (plain) or NHWC pixels [Nimg*H*W][Cin*6 B] (implicit GEMM)
-    const char* w;        // sp3 weights [N][K*6 B], k = (dy*KW+dx)*Cin + c
+    const char* w;        // sp3 weights [N][K*6 B], k = (dy*KW+dx)*Cin + c (the K loop visits the 16-channel chunks tap-innermost)
     const float* bias;
     const float* residual;   // fp32 [M][N] or null
     const char* residual_sp3;   // the residual as split planes [M][N*6 B] (exact: hi + mid + lo), or null
@@ -253,20 +253,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             voff[j] = piece < PIECES ? (unsigned)((trow - BM) * (int)row_bytes + unit_off) : kOutOfRange;
         }
     }
-    // K-step iterator of the DMA issue (steps are issued in order): plain = a byte offset; taps = (dy, dx, channel chunk)
+    // K-step iterator of the DMA issue (steps are issued in order): plain = a byte offset; taps = (channel chunk, dy, dx) with the
+    // TAP innermost: the KH*KW steps of one 16-channel chunk read the same 96-byte pieces of neighbouring pixels, so all but the
+    // first find them in L2.  (Tap-outermost - the order of the weight rows - streams every pixel's whole channel vector once per
+    // tap, KH*KW times from HBM: 10 GB per launch for the 3x3 convolutions of layer1 against 2.5 GB algorithmic.)  The weight
+    // rows keep their (tap, channel) order; the step reads chunk tap * cin_chunks + cc of them.
     int d_kt = kt_begin;
-    int d_dy = 0, d_dx = 0, d_cc = 0;
+    int d_dy = 0, d_dx = 0, d_cc = 0, d_tap = 0;
     const int cin_chunks = p.Cin >> 4;
+    const int ntaps = p.K / p.Cin;   // KH * KW
     if (TAPS) {
-        const int tap = kt_begin / cin_chunks;
-        d_cc = kt_begin - tap * cin_chunks;
-        d_dy = tap / p.KW;
-        d_dx = tap - d_dy * p.KW;
+        d_cc = kt_begin / ntaps;
+        d_tap = kt_begin - d_cc * ntaps;
+        d_dy = d_tap / p.KW;
+        d_dx = d_tap - d_dy * p.KW;
     }
 
 #define X6_ISSUE(st_)                                                                                                   \
     {                                                                                                                   \
-        const int lin_ = d_kt * kChunkBytes;                                                                            \
+        const int lin_ = (TAPS ? d_tap * cin_chunks + d_cc : d_kt) * kChunkBytes;                                       \
         const int tapoff_ = TAPS ? (d_dy * p.W + d_dx) * (int)pix_bytes + d_cc * kChunkBytes : 0;                        \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                                               \
             const int piece_ = wave + NW * j;                                                                           \
@@ -285,13 +290,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         }                                                                                                               \
         if (!(RELAX_X6_ABLATE & 2)) ++d_kt;                                                                             \
         if (TAPS) {                                                                                                     \
-            ++d_cc;                                                                                                     \
-            const bool wc_ = d_cc == cin_chunks;                                                                        \
-            d_cc = wc_ ? 0 : d_cc;                                                                                      \
-            d_dx += wc_ ? 1 : 0;                                                                                        \
+            ++d_tap;                                                                                                    \
+            ++d_dx;                                                                                                     \
             const bool wx_ = d_dx == p.KW;                                                                              \
             d_dx = wx_ ? 0 : d_dx;                                                                                      \
             d_dy += wx_ ? 1 : 0;                                                                                        \
+            const bool wt_ = d_tap == ntaps;                                                                            \
+            d_tap = wt_ ? 0 : d_tap;                                                                                    \
+            d_dy = wt_ ? 0 : d_dy;                                                                                      \
+            d_cc += wt_ ? 1 : 0;                                                                                        \
         }                                                                                                               \
     }
 
