@@ -224,7 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + (int64_t)n0 * row_bytes), 0, (int)(BN * row_bytes), 0x00020000);
     }
     unsigned voff[PPW];
-    int a_iy[A_PPW > 0 ? A_PPW : 1], a_ix[A_PPW > 0 ? A_PPW : 1];
+    unsigned a_taps[A_PPW > 0 ? A_PPW : 1];   // implicit GEMM: bit t set = tap t of this piece's pixel lies inside the image (KH*KW <= 32)
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int piece = wave + NW * j;
@@ -234,8 +234,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         const int unit_off = (c >> 1) * 32 + (((c & 1) ^ ((trow >> 3) & 1)) << 4);
         if (j < A_PPW) {
             const int m = m0 + trow;
-            a_iy[j] = -(1 << 28);
-            a_ix[j] = 0;
+            a_taps[j] = 0u;
             if (m >= p.M) {
                 voff[j] = kOutOfRange;
             } else if (pixels) {
@@ -243,9 +242,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 const int rem = m - img * (p.Ho * p.Wo);
                 const int oy = rem / p.Wo;
                 const int ox = rem - oy * p.Wo;
-                a_iy[j] = oy * p.stride - p.pad;
-                a_ix[j] = ox * p.stride - p.pad;
-                voff[j] = (unsigned)((((img - img0) * p.H + a_iy[j]) * p.W + a_ix[j]) * (int)pix_bytes + unit_off);
+                const int iy = oy * p.stride - p.pad, ix = ox * p.stride - p.pad;
+                if (TAPS) {
+                    const int ntaps_ = p.K / p.Cin;
+                    for (int t = 0, dy = 0, dx = 0; t < ntaps_; ++t) {
+                        if ((unsigned)(iy + dy) < (unsigned)p.H && (unsigned)(ix + dx) < (unsigned)p.W) a_taps[j] |= 1u << t;
+                        if (++dx == p.KW) { dx = 0; ++dy; }
+                    }
+                }
+                voff[j] = (unsigned)((((img - img0) * p.H + iy) * p.W + ix) * (int)pix_bytes + unit_off);
             } else {
                 voff[j] = (unsigned)(trow * (int)row_bytes + unit_off);
             }
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             if (j < A_PPW) {                                                                                            \
                 if (TAPS) {                                                                                             \
                     const int jj_ = j < A_PPW ? j : 0;                                                                  \
-                    const bool ok_ = (unsigned)(a_iy[jj_] + d_dy) < (unsigned)p.H && (unsigned)(a_ix[jj_] + d_dx) < (unsigned)p.W; \
+                    const bool ok_ = (a_taps[jj_] >> d_tap) & 1u;                                                         \
                     X6_DMA(rsrc_a, dst_, ok_ ? voff[j] + (unsigned)tapoff_ : kOutOfRange, 0);                            \
                 } else {                                                                                                \
                     X6_DMA(rsrc_a, dst_, voff[j], lin_);                                                                \
@@ -747,7 +752,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, d.out || d.out_sp3 || d.gap_groups, "x6 conv/gemm: no output requested");
     RELAX_REQUIRE(h, !(d.residual && d.residual_sp3), "x6 conv/gemm: two residuals");
     RELAX_REQUIRE(h, !d.gap_groups || ((d.Ho * d.Wo) % 16 == 0 && p.M % 16 == 0), "x6 conv: the fused spatial mean needs Ho*Wo %% 16 == 0");
-    RELAX_REQUIRE(h, !taps || d.pad >= 0, "x6 conv: bad padding");
+    RELAX_REQUIRE(h, !taps || (d.pad >= 0 && d.KH * d.KW <= 32), "x6 conv: bad padding, or more than 32 taps (%dx%d)", d.KH, d.KW);
     RELAX_REQUIRE(h, taps || d.pad == 0, "x6 conv: 1x1 with padding is not supported");
     const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)p.K;
     // algorithmic HBM bytes: activation in (6 B per value), weights, outputs (+ residual), each touched once
