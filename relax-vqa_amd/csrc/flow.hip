@@ -221,55 +221,81 @@ __global__ __launch_bounds__(256) void resize_linear_f32(const float* __restrict
     dst[((b * h + dy) * w) * C + e] = (r0 * (1.f - fy) + r1 * fy) * mul;
 }
 
-// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][h][w][5].  A block owns one row of a band of 246 output
-// columns (256 threads = 246 + the 5-column halo on each side, replicated border): every thread applies the vertical 11-tap
-// filters to ITS column (float, as OpenCV), the three results go through LDS, and the horizontal 11-tap part (double
-// accumulators, as OpenCV) reads its neighbours there.  The intermediate [h][w][3] plane never goes to HBM: 4 + 20 bytes per
-// pixel instead of 48 (the 11 rows a block reads are shared with the blocks of the neighbouring rows through L2).
+// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][h][w][5].  A block owns a band of 246 output columns (256
+// threads = 246 + the 5-column halo on each side, replicated border) and a segment of rows, and walks down the rows:
+//   * vertical 11-tap filters (float, as OpenCV), one COLUMN per thread: the 11 rows of the window live in a register ring
+//     (static indices: the row loop is unrolled over the ring period), so every input value is loaded once per segment - with
+//     one row per block, as before, each thread re-read its 11 rows and the kernel ran at the L2 rate on 84 bytes per pixel
+//     (1.55 ms per 2160p launch for 4.4 GB of HBM traffic); the row entering the window is requested a step ahead;
+//   * the three vertical results go through LDS (double-buffered: one barrier per row), and the horizontal 11-tap part (double
+//     accumulators, as OpenCV) reads its neighbours there.
+// Same operations in the same order as the one-row form: bit-identical output.  The intermediate [h][w][3] plane never goes to
+// HBM: 4 + 20 bytes per pixel.
 constexpr int POLY_OUT = 256 - 2 * POLY_N;   // 246
-__global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ I, float* __restrict__ R, int h, int w,
+constexpr int POLY_RING = 2 * POLY_N + 1;    // 11
+__global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ I, float* __restrict__ R, int h, int w, int seg,
                                                       PolyConsts pc) {
-    __shared__ float lt[3][256];
+    __shared__ float lt[2][3][256];
     const int tid = threadIdx.x;
-    const int x = blockIdx.x * POLY_OUT - POLY_N + tid;     // grid (w / 246, h, images)
+    const int x = blockIdx.x * POLY_OUT - POLY_N + tid;     // grid (w / 246, h / seg, images)
     const int xc = clampi(x, 0, w - 1);
-    const int y = blockIdx.y;
-    const float* img = I + (int64_t)blockIdx.z * ((int64_t)w * h) + xc;
-    float t0 = img[(int64_t)y * w] * pc.g[0], t1 = 0.f, t2 = 0.f;
+    const int y0 = blockIdx.y * seg;
+    const int y1 = y0 + seg < h ? y0 + seg : h;
+    const float* col = I + (int64_t)blockIdx.z * ((int64_t)w * h) + xc;
+    const bool writer = tid >= POLY_N && tid < 256 - POLY_N && x < w;
+    float ring[POLY_RING];    // at the row y = y0 + s: slot (s + i) % 11 holds row y - 5 + i (clamped), i = 0 .. 10
 #pragma unroll
-    for (int k = 1; k <= POLY_N; ++k) {
-        const float up = img[(int64_t)(y - k < 0 ? 0 : y - k) * w];
-        const float dn = img[(int64_t)(y + k > h - 1 ? h - 1 : y + k) * w];
-        const float p = up + dn;
-        t0 += pc.g[k] * p;
-        t1 += pc.xg[k] * (dn - up);
-        t2 += pc.xxg[k] * p;
-    }
-    lt[0][tid] = t0;
-    lt[1][tid] = t1;
-    lt[2][tid] = t2;
-    __syncthreads();
-    if (tid < POLY_N || tid >= 256 - POLY_N || x >= w) return;
-    double b1 = t0 * pc.g[0], b2 = 0, b3 = t1 * pc.g[0], b4 = 0, b5 = t2 * pc.g[0], b6 = 0;
+    for (int i = 0; i < POLY_RING; ++i) ring[i] = col[(int64_t)clampi(y0 - POLY_N + i, 0, h - 1) * w];
+    float nxt = col[(int64_t)clampi(y0 + POLY_N + 1, 0, h - 1) * w];   // enters the window at the next row
+    int par = 0;
+    for (int yb = y0; yb < y1; yb += POLY_RING) {
 #pragma unroll
-    for (int k = 1; k <= POLY_N; ++k) {
-        const float p0 = lt[0][tid + k], m0 = lt[0][tid - k];
-        const float p1 = lt[1][tid + k], m1 = lt[1][tid - k];
-        const float p2 = lt[2][tid + k], m2 = lt[2][tid - k];
-        const double tg = p0 + m0;
-        b1 += tg * pc.g[k];
-        b4 += tg * pc.xxg[k];
-        b2 += (p0 - m0) * pc.xg[k];
-        b3 += (p1 + m1) * pc.g[k];
-        b6 += (p1 - m1) * pc.xg[k];
-        b5 += (p2 + m2) * pc.g[k];
+        for (int j = 0; j < POLY_RING; ++j) {
+            const int y = yb + j;
+            if (y < y1) {                                   // uniform over the block
+                const float entering = nxt;
+                nxt = col[(int64_t)clampi(y + POLY_N + 2, 0, h - 1) * w];
+                float t0 = ring[(j + POLY_N) % POLY_RING] * pc.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int k = 1; k <= POLY_N; ++k) {
+                    const float up = ring[(j + POLY_N - k) % POLY_RING];
+                    const float dn = ring[(j + POLY_N + k) % POLY_RING];
+                    const float p = up + dn;
+                    t0 += pc.g[k] * p;
+                    t1 += pc.xg[k] * (dn - up);
+                    t2 += pc.xxg[k] * p;
+                }
+                ring[j] = entering;                         // row y + 6 takes the slot of row y - 5
+                lt[par][0][tid] = t0;
+                lt[par][1][tid] = t1;
+                lt[par][2][tid] = t2;
+                __syncthreads();
+                if (writer) {
+                    double b1 = t0 * pc.g[0], b2 = 0, b3 = t1 * pc.g[0], b4 = 0, b5 = t2 * pc.g[0], b6 = 0;
+#pragma unroll
+                    for (int k = 1; k <= POLY_N; ++k) {
+                        const float p0 = lt[par][0][tid + k], m0 = lt[par][0][tid - k];
+                        const float p1 = lt[par][1][tid + k], m1 = lt[par][1][tid - k];
+                        const float p2 = lt[par][2][tid + k], m2 = lt[par][2][tid - k];
+                        const double tg = p0 + m0;
+                        b1 += tg * pc.g[k];
+                        b4 += tg * pc.xxg[k];
+                        b2 += (p0 - m0) * pc.xg[k];
+                        b3 += (p1 + m1) * pc.g[k];
+                        b6 += (p1 - m1) * pc.xg[k];
+                        b5 += (p2 + m2) * pc.g[k];
+                    }
+                    float* o = R + (((int64_t)blockIdx.z * h + y) * w + x) * 5;
+                    o[1] = (float)(b2 * pc.ig11);
+                    o[0] = (float)(b3 * pc.ig11);
+                    o[3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+                    o[2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+                    o[4] = (float)(b6 * pc.ig55);
+                }
+                par ^= 1;   // the next row writes the other buffer: its barrier orders these reads before the buffer's reuse
+            }
+        }
     }
-    float* o = R + (((int64_t)blockIdx.z * h + y) * w + x) * 5;
-    o[1] = (float)(b2 * pc.ig11);
-    o[0] = (float)(b3 * pc.ig11);
-    o[3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-    o[2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-    o[4] = (float)(b6 * pc.ig55);
 }
 
 // FarnebackUpdateMatrices for one pixel: R0 = its 5 expansion coefficients in frame 0, R1 = frame 1's coefficient image,
@@ -736,7 +762,12 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
                 Isrc = I;
             }
         }
-        hipLaunchKernelGGL(poly_expansion, dim3((w + POLY_OUT - 1) / POLY_OUT, hh, P * 2), dim3(256), 0, s, Isrc, R, hh, w, pc);
+        {
+            int seg = 66;   // a multiple of the 11-row ring period; shorter segments when the level is small (enough blocks for 256 CUs)
+            const int bands = (w + POLY_OUT - 1) / POLY_OUT;
+            while (seg > 11 && (int64_t)bands * ((hh + seg - 1) / seg) * P * 2 < 2048) seg -= 11;
+            hipLaunchKernelGGL(poly_expansion, dim3(bands, (hh + seg - 1) / seg, P * 2), dim3(256), 0, s, Isrc, R, hh, w, seg, pc);
+        }
         // measurement (relax_profile_read kind 5): the dominant kernel of the stage, with its algorithmic bytes: per pixel
         // 2 x 5 floats of R at the pixel + 5 floats of R1 gathered at the displaced position (counted once: neighbours share
         // the lines) ... = 40 + 8 (flow) + 20 (M written) = 68 bytes
