@@ -144,7 +144,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topn(const uint32_t* __res
     // scores are < 2^18 (16*16*3*255 = 195840); two 10-bit levels cover 2^20
     uint32_t thr = 0;        // the want-th largest score
     uint32_t need_ties = 0;  // how many entries == thr are selected (lowest indices first)
-    if (want == npatch) {
+    if (want == 0) {
+        thr = 0xffffffffu;        // nothing is selected (top_n = 0): no score exceeds or equals this
+        need_ties = 0;            // (the digit search below never finds a bin for remaining = 0 and would leave thr undefined)
+    } else if (want == npatch) {
         thr = 0;
         need_ties = 0xffffffffu;  // everything is selected
     } else {
