@@ -95,3 +95,103 @@ def test_flow_on_small_and_odd_frames(h, w, pairs, seed):
         want = flow_ref.farneback(flow_ref.bgr2gray(a), flow_ref.bgr2gray(b))
         err = np.abs(flow[i].cpu().numpy() - want)
         assert err.max() < 2e-3 and err.mean() < 2e-5, (h, w, err.max(), err.mean())
+
+
+# ---- contraction kernels on random geometries -----------------------------------------------------------------------------
+import torch.nn.functional as F  # noqa: E402
+
+from relax_vqa_amd.engine import pack_conv_weight  # noqa: E402
+from tests.gpu_common import assert_close  # noqa: E402
+
+
+def _randn(g, *shape, scale=1.0):
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+@settings(max_examples=60, **COMMON)
+@given(nimg=st.integers(1, 4), h=st.integers(3, 30), w=st.integers(3, 30), cin=st.sampled_from([32, 64, 96, 128, 256]),
+       cout=st.sampled_from([64, 128, 192, 256, 512]), k=st.sampled_from([1, 3]), stride=st.sampled_from([1, 2]),
+       act=st.sampled_from([0, 1]), with_res=st.booleans(), precision=st.sampled_from(["bf16x6", "fp32"]), seed=st.integers(0, 2 ** 31 - 1))
+def test_conv2d_on_random_geometries(nimg, h, w, cin, cout, k, stride, act, with_res, precision, seed):
+    """Implicit-GEMM convolution on random image sizes (rows of a tile straddle images, every tap mask pattern at the borders,
+    non-square maps, row counts far from a multiple of the tile), channel counts of every tile variant, stride 1 / 2, 1x1 and 3x3,
+    with and without residual: against an fp64 convolution."""
+    pad = 1 if k == 3 else 0
+    if precision == "fp32" and k == 3 and cin & (cin - 1):
+        return      # the exact-fp32 kernel takes power-of-two channel counts for KHxKW > 1 (it says so: tests/test_gpu_errors_and_dist.py)
+    g = np.random.default_rng(seed)
+    x = _randn(g, nimg, cin, h, w)
+    wt = _randn(g, cout, cin, k, k, scale=(cin * k * k) ** -0.5)
+    b = _randn(g, cout)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad)
+    res = _randn(g, *ref.shape) if with_res else None
+    if with_res:
+        ref = ref + res.double()
+    if act == 1:
+        ref = F.relu(ref)
+    eng = engine()
+    eng.set_precision(precision)
+    got = eng.op_conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), torch.from_numpy(pack_conv_weight(wt.numpy())).cuda(), b.cuda(),
+                             res.permute(0, 2, 3, 1).contiguous().cuda() if with_res else None, cout, k, k, stride, pad, act=act)
+    assert_close(got.permute(0, 3, 1, 2), ref.float().numpy(), f"{precision} conv {nimg}x{h}x{w}x{cin}->{cout} k{k}s{stride} act{act} res{with_res}")
+
+
+@settings(max_examples=60, **COMMON)
+@given(m=st.integers(1, 1500), n=st.sampled_from([64, 128, 192, 256, 320, 768]), k=st.sampled_from([16, 32, 48, 64, 160, 768, 1024]),
+       act=st.sampled_from([0, 1, 2]), with_bias=st.booleans(), with_res=st.booleans(), precision=st.sampled_from(["bf16x6", "fp32"]),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_gemm_on_random_shapes(m, n, k, act, with_bias, with_res, precision, seed):
+    """out = act(A W^T + bias + residual) on random row counts (partial tiles, fewer rows than a tile, tail split-K) and every
+    tile variant, against an fp64 product."""
+    if precision == "fp32" and k % 32:
+        return
+    g = np.random.default_rng(seed)
+    A, W = _randn(g, m, k), _randn(g, n, k, scale=k ** -0.5)
+    b = _randn(g, n) if with_bias else None
+    r = _randn(g, m, n) if with_res else None
+    y = A.double() @ W.double().T
+    if with_bias:
+        y = y + b.double()
+    if with_res:
+        y = y + r.double()
+    want = [y, F.relu(y), F.gelu(y)][act].float().numpy()
+    eng = engine()
+    eng.set_precision(precision)
+    got = eng.op_gemm(A.cuda(), W.cuda(), b.cuda() if with_bias else None, r.cuda() if with_res else None, act=act)
+    assert_close(got, want, f"{precision} gemm {m}x{n}x{k} act{act} bias{with_bias} res{with_res}")
+
+
+@settings(max_examples=30, **COMMON)
+@given(n_img=st.integers(1, 5), heads=st.sampled_from([1, 3, 6, 12]), scale=st.floats(0.05, 5.0), outlier=st.booleans(),
+       precision=st.sampled_from(["bf16x6", "fp32"]), seed=st.integers(0, 2 ** 31 - 1))
+def test_attention_on_random_inputs(n_img, heads, scale, outlier, precision, seed):
+    """softmax(q k^T / 8) v for random image / head counts and logit magnitudes from near-uniform to near one-hot rows; with
+    `outlier` one query and one key carry 6x larger entries (dominant logits of a few hundred: the max-subtraction path; much larger
+    ones lose digits in ANY fp32 evaluation of the logit itself - 30x was tried: 1.04x the elementwise bar on the exact-fp32 path)."""
+    g = np.random.default_rng(seed)
+    dim = heads * 64
+    qkv = _randn(g, n_img * 197, 3 * dim, scale=scale)
+    if outlier:
+        qkv[int(g.integers(0, n_img * 197)), :dim] *= 6.0
+        qkv[int(g.integers(0, n_img * 197)), dim:2 * dim] *= 6.0
+    t = qkv.double().reshape(n_img, 197, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (((t[0] @ t[1].transpose(-2, -1)) * 64 ** -0.5).softmax(dim=-1) @ t[2]).transpose(1, 2).reshape(n_img * 197, dim)
+    eng = engine()
+    eng.set_precision(precision)
+    got = eng.op_attention(qkv.cuda(), n_img, heads)
+    assert_close(got, ref.float().numpy(), f"{precision} attention n={n_img} heads={heads} scale={scale:.2f} outlier={outlier}")
+
+
+@settings(max_examples=40, **COMMON)
+@given(rows=st.integers(1, 700), dim=st.sampled_from([64, 192, 384, 768]), spread=st.floats(1e-3, 1e3), offset=st.floats(-100, 100),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_layernorm_on_random_rows(rows, dim, spread, offset, seed):
+    """LayerNorm (eps 1e-6) on rows of any scale and offset, gammas of mixed sign, against fp64."""
+    g = np.random.default_rng(seed)
+    x = _randn(g, rows, dim, scale=spread) + np.float32(offset)
+    gamma, beta = _randn(g, dim), _randn(g, dim)
+    ref = F.layer_norm(x.double(), (dim,), gamma.double(), beta.double(), 1e-6)
+    got = engine().op_layernorm(x.cuda(), gamma.cuda(), beta.cuda(), 1e-6)
+    # a large offset against a small spread loses digits in ANY fp32 evaluation of (x - mean): compare at that resolution
+    tol = max(1e-4, 4e-7 * (abs(offset) + spread) / spread)
+    assert np.allclose(got.cpu().numpy(), ref.float().numpy(), rtol=tol, atol=tol * 3), (rows, dim, spread, offset)
