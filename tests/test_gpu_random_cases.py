@@ -195,3 +195,35 @@ def test_layernorm_on_random_rows(rows, dim, spread, offset, seed):
     # a large offset against a small spread loses digits in ANY fp32 evaluation of (x - mean): compare at that resolution
     tol = max(1e-4, 4e-7 * (abs(offset) + spread) / spread)
     assert np.allclose(got.cpu().numpy(), ref.float().numpy(), rtol=tol, atol=tol * 3), (rows, dim, spread, offset)
+
+
+# ---- whole clips: ragged batches ----------------------------------------------------------------------------------------
+from tests.gpu_common import rn50_weights, synth, vit_weights  # noqa: E402
+
+
+@settings(max_examples=8, **COMMON)
+@given(shapes=st.lists(st.tuples(st.integers(1, 5), st.integers(16, 300), st.integers(16, 400)), min_size=1, max_size=4),
+       seed=st.integers(0, 10 ** 6))
+def test_clip_vectors_on_ragged_batches(shapes, seed):
+    """Clips with different numbers of pairs and different frame sizes (down to a single patch) in ONE batched pass: with the tail
+    split-K off every clip's 19779-d vector is bit-identical to running the clip alone; the first clip is also checked against
+    the oracle pipeline (fragments -> ResNet-50 / ViT features -> per-clip mean)."""
+    from oracle import pipeline_ref
+    rn_sd = rn50_weights()
+    vit_sd = vit_weights("vit_base")
+    eng = engine()
+    clips_np = [synth.synthetic_clip(t, h, w, clip_id=seed + i) for i, (t, h, w) in enumerate(shapes)]
+    clips = [torch.from_numpy(c).cuda() for c in clips_np]
+    eng.set_option("gemm_split_k", 0)
+    try:
+        both = eng.clip_vectors(clips)
+        for i, c in enumerate(clips):
+            assert torch.equal(eng.clip_vectors([c])[0], both[i]), f"clip {i} of {shapes} depends on its batch"
+    finally:
+        eng.set_option("gemm_split_k", 1)
+    assert both.shape == (len(clips), 19779) and bool(torch.isfinite(both).all())
+    if shapes[0][0] <= 2:       # the oracle runs both backbones on the CPU: only short first clips
+        feats = pipeline_ref.clip_features(clips_np[0], rn_sd, vit_sd, schedule="dedup")
+        want = np.concatenate([feats["resnet"], feats["vit"]], axis=1).mean(axis=0)
+        got = both[0].cpu().numpy()
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-4
