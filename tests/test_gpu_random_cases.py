@@ -227,3 +227,30 @@ def test_clip_vectors_on_ragged_batches(shapes, seed):
         want = np.concatenate([feats["resnet"], feats["vit"]], axis=1).mean(axis=0)
         got = both[0].cpu().numpy()
         assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-4
+
+
+# ---- quality head: missing values -----------------------------------------------------------------------------------------
+@settings(max_examples=25, **COMMON)
+@given(n=st.integers(1, 70), feats=st.sampled_from([256, 4608, 19779]), hidden=st.sampled_from([128, 256, 512]), bad=st.floats(0.0, 0.3),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_head_with_random_nan_patterns(n, feats, hidden, bad, seed):
+    """NaN -> imputer mean -> MinMaxScaler -> MLP (src/demo_test.py:177-208) for random batch sizes, input widths and fractions of missing
+    entries (up to whole rows), against the oracle restatement of the reference's head.  (+-inf is outside the reference's domain:
+    its SimpleImputer raises on it.)"""
+    from oracle import mlp_ref
+    g = np.random.default_rng(seed)
+    sd = synth.mlp_head_state_dict(feats, hidden, seed=seed % 1000)
+    scale = g.uniform(0.01, 2.0, feats)
+    mn = g.uniform(-1, 1, feats)
+    imput = g.standard_normal(feats)
+    x = (g.standard_normal((n, feats)) * 3).astype(np.float32)
+    mask = g.random((n, feats)) < bad
+    x[mask] = np.nan
+    if n > 1 and bad > 0.15:
+        x[0] = np.nan
+    eng = engine()
+    eng.load_mlp_head(sd, scale, mn, imput)
+    got = eng.mlp_head(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = mlp_ref.predict(sd, x, imput, scale, mn)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-3 * (1 + np.abs(want).max()))
