@@ -254,3 +254,26 @@ def test_head_with_random_nan_patterns(n, feats, hidden, bad, seed):
     want = mlp_ref.predict(sd, x, imput, scale, mn)
     assert np.isfinite(got).all()
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-3 * (1 + np.abs(want).max()))
+
+
+# ---- full ReLaX vectors (flow + whole frames) -----------------------------------------------------------------------------
+@settings(max_examples=6, **COMMON)
+@given(shapes=st.lists(st.tuples(st.integers(1, 4), st.integers(16, 260), st.integers(16, 330)), min_size=1, max_size=3),
+       max_pairs=st.sampled_from([0, 1, 2, 3]), seed=st.integers(0, 10 ** 6))
+def test_full_clip_vectors_on_ragged_batches_and_flow_chunking(shapes, max_pairs, seed):
+    """The 35203-d vectors (whole-frame resize, Farneback flow fragments, both backbones) of a ragged batch: bit-identical to clip by
+    clip with the tail split-K off, and independent of how many pairs the optical flow takes per launch (`flow_max_pairs`)."""
+    rn50_weights()
+    vit_weights("vit_base")
+    eng = engine()
+    clips = [torch.from_numpy(synth.synthetic_clip(t, h, w, clip_id=seed + i)).cuda() for i, (t, h, w) in enumerate(shapes)]
+    eng.set_option("gemm_split_k", 0)
+    try:
+        both = eng.full_clip_vectors(clips, flow=True)
+        eng.set_option("flow_max_pairs", max_pairs)
+        for i, c in enumerate(clips):
+            assert torch.equal(eng.full_clip_vectors([c], flow=True)[0], both[i]), f"clip {i} of {shapes} depends on its batch / flow chunking"
+    finally:
+        eng.set_option("gemm_split_k", 1)
+        eng.set_option("flow_max_pairs", 0)
+    assert both.shape == (len(clips), 35203) and bool(torch.isfinite(both).all())
