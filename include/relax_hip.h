@@ -75,7 +75,9 @@ int relax_reserve(relax_handle* h, int max_images);
  * the chip; results stay deterministic for a given batch, but the K-summation order of tail tiles then depends on the
  * batch size - set 0 when features must be bit-identical across batch compositions (e.g. comparing sharded runs).
  * "gemm_variant", "gemm_variant_n64", "gemm_group_m", "gemm_prio": tuning knobs (tile variants are listed in csrc/gemm.hip;
- * none of them changes results beyond fp32 rounding). */
+ * none of them changes results beyond fp32 rounding).  "flow_max_pairs": cap on the pairs one optical-flow launch takes
+ * (0 = by workspace size).  "debug_poison" (test mode, default 0): every workspace request fills the buffer with 0xFF bytes
+ * first (synchronously), so a read of workspace that was not written in the same call shows up in the results. */
 int relax_set_option(relax_handle* h, const char* key, int value);
 /* Reads an option back (bench.py reports the arithmetic the ENGINE is in, not the one its command line asked for). */
 int relax_get_option(relax_handle* h, const char* key, int* value);

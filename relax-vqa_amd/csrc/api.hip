@@ -18,8 +18,19 @@ void set_error(relax_handle* h, const char* fmt, ...) {
     else g_create_error = buf;
 }
 
+// "debug_poison" (relax_set_option / RELAX_DEBUG_POISON=1): every workspace request fills the whole buffer with 0xFF bytes (NaN as
+// fp32, -1 as an index) first, so a kernel that reads workspace it did not write this call shows up in the parity tests instead of
+// passing on whatever the previous call left there.  Synchronous and slow: a test mode, never on in the product path.
+static int poison_buf(relax_handle* h, DevBuf& b) {
+    if (!h->gemm.debug_poison || !b.p) return RELAX_OK;
+    RELAX_HIP_CHECK(h, hipDeviceSynchronize());
+    RELAX_HIP_CHECK(h, hipMemset(b.p, 0xFF, b.bytes));
+    RELAX_HIP_CHECK(h, hipDeviceSynchronize());
+    return RELAX_OK;
+}
+
 int ensure_buf(relax_handle* h, DevBuf& b, size_t bytes) {
-    if (b.bytes >= bytes) return RELAX_OK;
+    if (b.bytes >= bytes) return poison_buf(h, b);
     if (b.p) {
         RELAX_HIP_CHECK(h, hipDeviceSynchronize());
         RELAX_HIP_CHECK(h, hipFree(b.p));
@@ -33,7 +44,7 @@ int ensure_buf(relax_handle* h, DevBuf& b, size_t bytes) {
         return RELAX_ERR_NOMEM;
     }
     b.bytes = bytes;
-    return RELAX_OK;
+    return poison_buf(h, b);
 }
 
 int upload(relax_handle* h, const float* host, size_t n, float** dev, std::vector<void*>& allocs) {
@@ -152,6 +163,7 @@ int relax_create(int device, relax_handle** out) {
     if (const char* e = getenv("RELAX_GEMM_PRIO")) h->gemm.prio = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_PHASE")) h->gemm.phase = atoi(e) >= 2 && atoi(e) <= 8 ? atoi(e) : 0;
     if (const char* e = getenv("RELAX_GEMM_STAGGER")) h->gemm.stagger = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("RELAX_DEBUG_POISON")) h->gemm.debug_poison = atoi(e) != 0;
     *out = h;
     return RELAX_OK;
 }
@@ -213,6 +225,7 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     else if (k == "gemm_stagger") h->gemm.stagger = value > 0 ? value : 0;
     else if (k == "gemm_phase") h->gemm.phase = value >= 2 && value <= 8 ? value : 0;
     else if (k == "flow_max_pairs") h->gemm.flow_max_pairs = value > 0 ? value : 0;
+    else if (k == "debug_poison") h->gemm.debug_poison = value != 0;
     else {
         set_error(h, "relax_set_option: unknown option '%s'", key);
         return RELAX_ERR_INVALID;
@@ -242,6 +255,7 @@ int relax_get_option(relax_handle* h, const char* key, int* value) {
     else if (k == "gemm_stagger") *value = h->gemm.stagger;
     else if (k == "gemm_phase") *value = h->gemm.phase;
     else if (k == "flow_max_pairs") *value = h->gemm.flow_max_pairs;
+    else if (k == "debug_poison") *value = h->gemm.debug_poison;
     else {
         set_error(h, "relax_get_option: unknown option '%s'", key);
         return RELAX_ERR_INVALID;

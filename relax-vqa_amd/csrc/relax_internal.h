@@ -179,6 +179,7 @@ struct GemmOptions {
     int prio = 0;      // "gemm_prio": s_setprio around the MFMA cluster
     int flow_max_pairs = 0;  // "flow_max_pairs": cap on the pairs per optical-flow chunk (0 = by workspace size only)
     int phase = 0;     // "gemm_phase": bf16x6 phase start: S K-slices per early-split tile so that the CUs run 1/S of a tile apart (0 = off)
+    int debug_poison = 0;  // "debug_poison": fill every workspace with 0xFF bytes when it is requested (test mode: reads of unwritten workspace surface as NaN)
     int stagger = 0;   // "gemm_stagger": bf16x6 per-XCD stagger of the first round of tiles, in % of one tile time (0 = off)
 };
 }  // namespace relax

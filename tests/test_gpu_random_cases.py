@@ -277,3 +277,25 @@ def test_full_clip_vectors_on_ragged_batches_and_flow_chunking(shapes, max_pairs
         eng.set_option("gemm_split_k", 1)
         eng.set_option("flow_max_pairs", 0)
     assert both.shape == (len(clips), 35203) and bool(torch.isfinite(both).all())
+
+
+def test_results_do_not_depend_on_what_the_workspaces_held():
+    """`debug_poison` fills every workspace with 0xFF bytes (NaN / -1) whenever an entry point requests it.  A kernel that read
+    workspace it had not written in the same call would turn that into NaNs or different bits; the vectors must not move."""
+    rn50_weights()
+    vit_weights("vit_base")
+    eng = engine()
+    clips = [torch.from_numpy(synth.synthetic_clip(t, h, w, clip_id=300 + i)).cuda() for i, (t, h, w) in enumerate([(3, 272, 400), (2, 96, 130), (1, 16, 16)])]
+    a = eng.clip_vectors(clips)
+    fa = eng.full_clip_vectors(clips, flow=True)
+    ga = eng.op_gemm(torch.ones(700, 768, device="cuda"), torch.ones(768, 768, device="cuda"))
+    eng.set_option("debug_poison", 1)
+    try:
+        assert eng.get_option("debug_poison") == 1
+        b = eng.clip_vectors(clips)
+        fb = eng.full_clip_vectors(clips, flow=True)
+        gb = eng.op_gemm(torch.ones(700, 768, device="cuda"), torch.ones(768, 768, device="cuda"))
+    finally:
+        eng.set_option("debug_poison", 0)
+    assert torch.equal(a, b) and torch.equal(fa, fb) and torch.equal(ga, gb)
+    assert bool(torch.isfinite(b).all()) and bool(torch.isfinite(fb).all())
