@@ -54,3 +54,36 @@ def each_precision(request):
     from tests.gpu_common import engine
     engine().set_precision(request.param)
     return request.param
+
+
+class _PoisonedTorch:
+    """RELAX_TEST_POISON_OUT=1: the engine's output tensors (torch.empty in relax-vqa_amd/engine.py) start as 0xFF bytes (NaN / -1 /
+    255) instead of whatever the caching allocator hands back - an entry point that leaves part of an output unwritten then fails
+    its parity test instead of passing on a lucky buffer.  Test mode only."""
+
+    def __init__(self, torch):
+        self._t = torch
+
+    def __getattr__(self, name):
+        return getattr(self._t, name)
+
+    def _fill(self, t):
+        if t.device.type == "cuda" and t.numel():
+            t.view(self._t.uint8).fill_(255) if t.is_contiguous() else t.fill_(float("nan") if t.is_floating_point() else -1)
+        return t
+
+    def empty(self, *a, **k):
+        return self._fill(self._t.empty(*a, **k))
+
+    def empty_like(self, *a, **k):
+        return self._fill(self._t.empty_like(*a, **k))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _poisoned_outputs():
+    if os.environ.get("RELAX_TEST_POISON_OUT") == "1" and _have_gpu():
+        import torch
+        import relax_vqa_amd  # noqa: F401
+        from relax_vqa_amd import engine as engine_module
+        engine_module.torch = _PoisonedTorch(torch)
+    yield
