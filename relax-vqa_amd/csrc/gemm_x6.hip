@@ -42,7 +42,7 @@
 #define X6_STAMP(i_)
 #endif
 #ifndef RELAX_X6_ABLATE
-#define RELAX_X6_ABLATE 0   // build-time experiments: 1 no DMA in the K loop (WRONG results), 2 every DMA re-reads K step 0 (WRONG), 4 pin the instruction order of a pipeline region with sched_group_barrier, 8 GELU = identity (WRONG), 16 non-temporal fp32 output stores, 32 split-plane output as linear 1 KiB-per-wave stores (WRONG layout; worth 0.4 % of a ViT pass: the 32-byte runs of the plane stores are not what bounds the epilogue)
+#define RELAX_X6_ABLATE 0   // build-time experiments: 1 no DMA in the K loop (WRONG results), 2 every DMA re-reads K step 0 (WRONG), 4 pin the instruction order of a pipeline region with sched_group_barrier, 8 GELU = identity (WRONG), 16 non-temporal fp32 output stores, 64 only the three largest of the six partial products (WRONG: what a three-product arithmetic would run at in this kernel), 32 split-plane output as linear 1 KiB-per-wave stores (WRONG layout; worth 0.4 % of a ViT pass: the 32-byte runs of the plane stores are not what bounds the epilogue)
 #endif
 
 namespace relax {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     // the six partial products, smallest first: (A plane, B plane) = (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi);
     // product type outermost: XT*YH independent accumulators between two MFMAs on the same one
 #define X6_MFMAS(set_, yf_, half_)                                                                                      \
-    _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                                     \
+    _Pragma("unroll") for (int t = (RELAX_X6_ABLATE & 64) ? 3 : 0; t < 6; ++t) {   /* 64: only the three largest products (WRONG) */ \
         const int pa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0;                                                         \
         const int pb = t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0;                                                         \
         _Pragma("unroll") for (int x = 0; x < XT; ++x) _Pragma("unroll") for (int y = 0; y < YH; ++y) {                 \
