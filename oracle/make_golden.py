@@ -21,7 +21,6 @@ import os
 import shutil
 import sys
 import tempfile
-import types
 from unittest import mock
 
 sys.dont_write_bytecode = True

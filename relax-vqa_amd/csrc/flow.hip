@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void mag_minmax(const float* __restrict__ flow
     smax[threadIdx.x] = hi;
     __syncthreads();
     for (int s = 128; s >= 1; s >>= 1) {
-        if (threadIdx.x < s) {
+        if ((int)threadIdx.x < s) {
             smin[threadIdx.x] = smin[threadIdx.x + s] < smin[threadIdx.x] ? smin[threadIdx.x + s] : smin[threadIdx.x];
             smax[threadIdx.x] = smax[threadIdx.x + s] > smax[threadIdx.x] ? smax[threadIdx.x + s] : smax[threadIdx.x];
         }

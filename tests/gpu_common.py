@@ -1,6 +1,5 @@
 """Shared helpers for the -m gpu parity tests (HIP path vs oracle through the C-ABI)."""
 import numpy as np
-import pytest
 import torch
 
 import relax_vqa_amd  # noqa: F401

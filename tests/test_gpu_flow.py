@@ -8,7 +8,7 @@ import torch
 from PIL import Image
 
 from oracle import flow_ref, fragment_ref
-from tests.gpu_common import engine, synth
+from tests.gpu_common import engine
 
 pytestmark = pytest.mark.gpu
 

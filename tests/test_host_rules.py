@@ -1,6 +1,4 @@
 """Host-side rules of the reference-named API that need no GPU: frame-id parsing, missing weights, empty shards."""
-import os
-
 import pytest
 
 import relax_vqa_amd  # noqa: F401

@@ -2,9 +2,13 @@
 """Index-overflow check at batch sizes far beyond the bench's (GPU box only): 64 and 96 clips of 1080p x 32 pairs in ONE pass
 (4096 / 6144 fragments per backbone pass, activations of tens of GB) must give bit-identical rows to a 2-clip pass with the tail
 split-K off; same for the full 35203-d vectors with 12 clips per pass.  Measured: identical."""
-import sys, os, torch, numpy as np
+import os
+import sys
+
+import torch
+
 sys.path.insert(0, os.getcwd())
-import relax_vqa_amd
+import relax_vqa_amd  # noqa: F401  (registers the package alias)
 from relax_vqa_amd import synth
 from relax_vqa_amd.engine import RelaxEngine
 eng = RelaxEngine(0)

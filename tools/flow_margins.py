@@ -1,7 +1,6 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from PIL import Image
-import relax_vqa_amd
+import relax_vqa_amd  # noqa: F401
 from oracle import flow_ref, fragment_ref
 from tests.gpu_common import engine
 from tests.test_gpu_flow import _smooth_pair, _load

@@ -3,7 +3,7 @@
 torch.cuda.graph and compares eager and replayed time:  python tools/graph_try.py [clips_per_step]   (GPU box only)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import relax_vqa_amd
+import relax_vqa_amd  # noqa: F401
 from relax_vqa_amd import synth
 from relax_vqa_amd.engine import RelaxEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
