@@ -86,7 +86,7 @@ struct ConvDescX6 {
 // ---- model weights ------------------------------------------------------------------------------
 struct ConvW {          // one folded conv (+BN) of ResNet-50
     float* w = nullptr;     // device [Cout][Kpad]
-    void* w_sp3 = nullptr;  // the same as split planes (bf16x6 kernel); null for conv1 (Cin = 4 stays on the fp32 kernel)
+    void* w_sp3 = nullptr;  // the same as split planes (bf16x6 kernel); conv1: [64][224], k = ky*32 + kx*3 + c (conv1_x6.hip)
     float* bias = nullptr;  // device [Cout] (null for the raw conv1)
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, Kpad = 0;
 };
@@ -227,6 +227,9 @@ inline int launch_gemm(relax_handle* h, const float* A, const float* W, const fl
 // bf16x6 contraction kernel (gemm_x6.hip)
 int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s);
 int launch_to_sp3(relax_handle* h, const float* x, int64_t ld, void* y, int64_t rows, int K, hipStream_t s);
+// conv1_x6.hip: ResNet-50 conv1 on the bf16x6 arithmetic, straight from the uint8 fragments
+int make_conv1_x6_weights(relax_handle* h, const float* w_packed, int kpad, void** w_sp3_out, std::vector<void*>& allocs);
+int launch_conv1_x6(relax_handle* h, const uint8_t* frags, const void* w_sp3, float* out, float* gap_groups, int N, hipStream_t s);
 inline int launch_gemm_x6(relax_handle* h, const void* A_sp3, const void* W_sp3, const float* bias, const float* residual,
                           float* out, void* out_sp3, int M, int N, int K, int act, hipStream_t s) {
     ConvDescX6 d{};

@@ -249,7 +249,10 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
             cin = width * 4;
         }
     }
-    // split planes of every convolution but conv1 for the bf16x6 kernel (made on the device from the packed fp32 copy)
+    // split planes for the bf16x6 kernels (made on the device from the packed fp32 copies): conv1 in its own K layout ...
+    rc = make_conv1_x6_weights(h, rn.conv1.w, rn.conv1.Kpad, &rn.conv1.w_sp3, rn.allocs);
+    if (rc != RELAX_OK) { free_resnet(h); return rc; }
+    // ... every other convolution as [Cout][K] rows
     for (Bottleneck& blk : rn.blocks) {
         for (ConvW* c : {&blk.c1, &blk.c2, &blk.c3, &blk.down}) {
             if (!c->w) continue;
@@ -310,15 +313,14 @@ int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float*
         return RELAX_OK;
     };
 
-    const int64_t npix = (int64_t)N * 224 * 224;
-    hipLaunchKernelGGL(rn_preprocess, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, frags, X0, npix);
-    RELAX_HIP_CHECK(h, hipGetLastError());
-    // conv1 7x7/2 (raw), algorithmic FLOPs use the real 3 input channels
-    RELAX_TRY(run_conv(h, rn.conv1, X0, N, 224, 224, nullptr, bufA, 0, s, 2.0 * N * 112.0 * 112.0 * 64.0 * 147.0));
-    RELAX_TRY(emit_tap(0, bufA));
     if (h->gemm.precision == 2) {
-        // bf16x6: conv1 (Cin = 4) stays on the exact-fp32 kernel; from the max-pool on, every convolution input travels as
-        // split planes written by its producer, and block outputs are written twice (fp32: residual / taps; planes: next convs)
+        // bf16x6.  conv1 7x7/2 (raw) straight from the uint8 fragments (conv1_x6.hip: preprocess, im2col, split and contraction in one
+        // kernel, the 16-pixel sums of the tap's spatial mean formed in its epilogue); from the max-pool on, every convolution input
+        // travels as split planes written by its producer, and block outputs are written twice (fp32: residual / taps; planes: next convs)
+        float* gap0 = T2 + kT2 * n;   // = the fp32 carving's gapws: free until the blocks carve the arena anew below
+        RELAX_TRY(launch_conv1_x6(h, frags, rn.conv1.w_sp3, bufA, layer_stack ? gap0 : nullptr, N, s));
+        if (layer_stack) RELAX_TRY(launch_gap_groups_finish(h, gap0, layer_stack, N, 112 * 112, 64, RELAX_RN50_LAYER_STACK_DIM, s));
+        if (taps_nchw && taps_nchw[0]) RELAX_TRY(launch_nhwc_to_nchw(h, bufA, taps_nchw[0], N, 112 * 112, 64, s));
         float* f32a = bufB;                                   // block in / out, fp32 (ping-pong with f32b)
         float* f32b = bufD;
         float* D = bufA;                                      // downsample branch, fp32 (conv1's raw map is dead after the pool)
@@ -388,6 +390,12 @@ int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float*
         }
         return RELAX_OK;
     }
+    const int64_t npix = (int64_t)N * 224 * 224;
+    hipLaunchKernelGGL(rn_preprocess, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, frags, X0, npix);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    // conv1 7x7/2 (raw), algorithmic FLOPs use the real 3 input channels
+    RELAX_TRY(run_conv(h, rn.conv1, X0, N, 224, 224, nullptr, bufA, 0, s, 2.0 * N * 112.0 * 112.0 * 64.0 * 147.0));
+    RELAX_TRY(emit_tap(0, bufA));
     RELAX_TRY(launch_bn_relu_maxpool(h, bufA, rn.bn1_scale, rn.bn1_shift, bufB, N, 112, 112, 64, s));
     float* cur = bufB;
     float* other = bufA;
