@@ -35,7 +35,7 @@ constexpr int C1_PROW = C1_PCOLS + 2;               // 692 (even: 8-byte aligned
 constexpr int C1_PROWS = 13;                        // 2 * 3 + 7: a tile spans at most 4 output rows
 constexpr int C1_W_BYTES = 64 * C1_WROW;
 constexpr int C1_PATCH_FLOATS = C1_PROWS * C1_PROW + 64;   // slack: the padded k columns of the last row read past its end
-constexpr size_t C1_LDS = C1_W_BYTES + 2 * sizeof(float) * C1_PATCH_FLOATS;   // weights + two patch buffers: 159.5 KB
+constexpr size_t C1_LDS = C1_W_BYTES + 2 * sizeof(float) * C1_PATCH_FLOATS + 3 * 256 * sizeof(float);   // weights + two patch buffers + the normalisation table: 158.8 of 160 KiB
 
 // fp32 weights [64][Kpad] of the exact-fp32 kernel, k = (ky*7 + kx)*4 + c  ->  [64][224], k = ky*32 + kx*3 + c (zeros elsewhere)
 __global__ __launch_bounds__(256) void conv1_repack(const float* __restrict__ w, int kpad, float* __restrict__ out) {
@@ -49,14 +49,15 @@ __global__ __launch_bounds__(256) void conv1_repack(const float* __restrict__ w,
 }
 
 // one dword = 4 consecutive bytes k = 4d .. 4d+3 of a 672-byte BGR image row -> normalised RGB floats at their patch positions
-__device__ inline void conv1_put4(float* prow, int d, unsigned v, bool valid) {
+// (k = 3 px + c, c: 0 = B, 1 = G, 2 = R  ->  patch column 9 + 3 px + (2 - c) = 11 + k - 2c).  lut[c][byte] = ((byte / 255) - mean_c) /
+// std_c, computed once per workgroup with the operations of rn_preprocess (two fp32 divisions per value are ~25 instructions:
+// looked up, not redone 20 times per thread and tile)
+__device__ inline void conv1_put4(float* prow, int d, unsigned v, bool valid, const float* lut) {
+    const int d3 = d % 3;                                  // 4d mod 3
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int k = 4 * d + b;
-        const int px = k / 3, c = k - 3 * px;              // c: 0 = B, 1 = G, 2 = R
-        const float u = (float)((v >> (8 * b)) & 255u) / 255.0f;                                     // as rn_preprocess
-        const float n = c == 2 ? (u - 0.485f) / 0.229f : c == 1 ? (u - 0.456f) / 0.224f : (u - 0.406f) / 0.225f;
-        prow[9 + 3 * px + (2 - c)] = valid ? n : 0.f;      // zero padding of the NORMALISED tensor above / below the image
+        const int c = (d3 + b) % 3;
+        prow[11 + 4 * d + b - 2 * c] = valid ? lut[c * 256 + ((v >> (8 * b)) & 255u)] : 0.f;   // zeros above / below the image
     }
 }
 
@@ -81,6 +82,12 @@ __global__ __launch_bounds__(512) void conv1_x6(const uint8_t* __restrict__ frag
             *reinterpret_cast<const sp3_u32x4*>(w_sp3 + ((int64_t)n * (C1_CHUNKS * 6) + q) * 16);
     }
     for (int i = tid; i < 2 * C1_PATCH_FLOATS; i += 512) patch0[i] = 0.f;
+    float* lut = patch0 + 2 * C1_PATCH_FLOATS;
+    for (int i = tid; i < 3 * 256; i += 512) {
+        const int c = i >> 8;
+        const float u = (float)(i & 255) / 255.0f;                                                      // as rn_preprocess
+        lut[i] = c == 2 ? (u - 0.485f) / 0.229f : c == 1 ? (u - 0.456f) / 0.224f : (u - 0.406f) / 0.225f;
+    }
     __syncthreads();
 
     // the input rows of a tile as raw dwords in registers (requested before the MFMA loop of the tile before, written after it)
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(512) void conv1_x6(const uint8_t* __restrict__ frag
         for (int i = 0; i < C1_LOADS; ++i) {
             const int e = tid + 512 * i;
             const int row = e / C1_ROW_DW, d = e - row * C1_ROW_DW;
-            if (row < rows) conv1_put4(patch + row * C1_PROW, d, raw[i], (unsigned)(iy0 + row) < (unsigned)C1_HW);
+            if (row < rows) conv1_put4(patch + row * C1_PROW, d, raw[i], (unsigned)(iy0 + row) < (unsigned)C1_HW, lut);
         }
     };
 
@@ -146,18 +153,27 @@ __global__ __launch_bounds__(512) void conv1_x6(const uint8_t* __restrict__ frag
                 const c1_bf16x8 Ah = __builtin_bit_cast(c1_bf16x8, ah), Am = __builtin_bit_cast(c1_bf16x8, am),
                                 Al = __builtin_bit_cast(c1_bf16x8, al);
                 const int chunk = ky * 2 + jc;
+                c1_bf16x8 Bh[2], Bm[2], Bl[2];
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
                     const char* wp = wl + (cb * 32 + r) * C1_WROW + chunk * kChunkBytes + half * 16;
-                    const c1_bf16x8 Bh = *reinterpret_cast<const c1_bf16x8*>(wp), Bm = *reinterpret_cast<const c1_bf16x8*>(wp + 32),
-                                    Bl = *reinterpret_cast<const c1_bf16x8*>(wp + 64);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[cb], 0, 0, 0);
+                    Bh[cb] = *reinterpret_cast<const c1_bf16x8*>(wp);
+                    Bm[cb] = *reinterpret_cast<const c1_bf16x8*>(wp + 32);
+                    Bl[cb] = *reinterpret_cast<const c1_bf16x8*>(wp + 64);
                 }
+                // the six partial products, smallest first; the two accumulators alternate (no MFMA waits on the one before it)
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[1], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm[1], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[1], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh[1], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm[1], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[1], acc[1], 0, 0, 0);
             }
         }
         // acc[cb][i]: channel cb*32 + r of pixel  32*wave + (i & 3) + 8 * (i >> 2) + 4 * half
