@@ -52,7 +52,7 @@ def hbm2(fetch_dir, write_dir, tag, workload="config3", clips=8, precision="bf16
     for k in sorted(f, key=lambda k: -f[k]):
         lines.append(f"{k:70s} dispatches {n[k]:4d}  fetch_KiB(raw) {f[k]:12.0f}  write_KiB {w.get(k, 0):12.0f}  corrected MB/dispatch "
                      f"{(2 * f[k] + w.get(k, 0)) * 1024 / n[k] / 1e6:10.1f}")
-        if k.startswith(main_prefix):
+        if any(k.startswith(pfx) for pfx in main_prefix.split("|")):     # several kernels: prefixes separated by |
             main_bytes += (2 * f[k] + w.get(k, 0)) * 1024
             main_n += n[k]
     per = main_bytes / max(main_n, 1)
