@@ -16,6 +16,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 (the bf16x6 contraction kernel gemm_x6: fp32-grade products on the bf16 matrix cores, timed live with HIP events on the
 launch stream) and `cpu_baseline` (the CPU oracle, reference-faithful schedule, on a bounded sample of the same workload).
 The exact-fp32-MFMA path (`--precision fp32`) is measured beside the headline as `exact_fp32_mode`.
+The default N = 1 run also times a few steps of the other BASELINE configurations (`other_workloads`: config 2, the config-4
+clip shape, the config-5 recipe at 2160p) so that the driver's record carries them, not only builder-run files.
+
+  python bench.py --gpus N --workload config4 --dataset-clips 1200
+BASELINE config 4 as written (strong scaling): a KoNViD-1k-shaped list of 1200 clips sharded over the ranks
+(relax-vqa_amd/dataset.py), batches of --clips-per-step through the engine, ONE all-gather of the [1200, 19779] matrix;
+prints clips/s over the whole pass with `all_gather_ms` beside it.
 """
 import argparse
 import json
@@ -104,7 +111,7 @@ def _cpu_model():
 
 def hbm_traffic_per_launch(workload, clips_per_step, precision):
     """PMC-measured HBM bytes per contraction launch, if a committed profile exists for this exact workload and precision."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -144,7 +151,7 @@ def launch_check(rank, world):
     t0 = time.perf_counter()
     out = rdist.gather_clip_vectors(local, world * 2, rank, world) if world > 1 else local
     if world > 1:
-        dist.barrier()
+        rdist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = rdist.all_reduce_max(elapsed, dev)
@@ -154,7 +161,7 @@ def launch_check(rank, world):
         print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": world,
                           "backend": dist.get_backend() if world > 1 else None, "pids_distinct": True}))
     if world > 1:
-        dist.barrier()
+        rdist.barrier()
         dist.destroy_process_group()
 
 
@@ -174,6 +181,14 @@ def main():
                          "(tests/test_gpu_x6.py); fp32: exact fp32 MFMA; bf16x3: lower precision, never the headline")
     ap.add_argument("--clips-per-step", type=int, default=16,
                     help="clips each rank pushes through the engine per step (one batched pass: B*2*T fragments)")
+    ap.add_argument("--dataset-clips", type=int, default=0,
+                    help="dataset mode (BASELINE config 4 as written): this many clips sharded over the ranks, one all-gather of the "
+                         "[n, F] matrix at the end; strong scaling; --steps is ignored (the pass is ceil(n / ranks / clips-per-step) batches)")
+    ap.add_argument("--resident-clips", type=int, default=0, help="distinct synthetic clips kept in HBM per rank (default 2; dataset mode 4)")
+    ap.add_argument("--gemm-split-k", type=int, default=1, choices=[0, 1],
+                    help="0: no tail split-K - bits independent of the batch composition, i.e. of the number of ranks")
+    ap.add_argument("--dump-matrix", default=None, help="dataset mode: rank 0 saves the gathered [n, F] matrix as .npy (tests)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the short extra measurements of configs 2 / 4 / 5")
     ap.add_argument("--launch-check", action="store_true",
                     help="only rehearse the N-rank launch + collectives (no engine, no GPU needed): tests/test_bench_launch.py")
     args = ap.parse_args()
@@ -199,59 +214,72 @@ def main():
     torch.cuda.set_device(local_rank)
     eng = RelaxEngine(local_rank)
     rn_sd = synth.resnet50_state_dict()
-    vit_sd = synth.vit_state_dict("vit_base") if use_vit else None
+    vit_sd = synth.vit_state_dict("vit_base")
     eng.load_resnet50(rn_sd)
-    if use_vit:
-        eng.load_vit(vit_sd, "vit_base")
+    eng.load_vit(vit_sd, "vit_base")       # every workload but config 2 needs it (other_workloads included)
     B = args.clips_per_step
     eng.reserve(2 * T * B)
     eng.set_precision(args.precision)
+    eng.set_option("gemm_split_k", args.gemm_split_k)
     precision = eng.precision()          # what the ENGINE computes in (read back from the library, not the flag)
     assert precision == args.precision, (precision, args.precision)
     x3, x6 = precision == "bf16x3", precision == "bf16x6"
 
-    # two distinct resident clips per rank, alternated (inputs are in HBM before the timed region starts)
-    n_resident = 2
-    clips = [torch.from_numpy(synth.synthetic_clip(T, H, W, clip_id=rank * n_resident + i, distinct=4)).cuda()
-             for i in range(n_resident)]
-    feat_dim = 15171 + (4608 if use_vit else 0)
-
-    full = args.workload.startswith("full")
-    if full:
-        feat_dim = 35203
-
-    def step(i):
-        batch = [clips[(i * B + j) % n_resident] for j in range(B)]
-        if full:
-            vecs = eng.full_clip_vectors(batch, flow=True)
-        else:
-            vecs = eng.clip_vectors(batch, resnet=True, vit=use_vit)          # [B, feat_dim]
-        if world > 1:
-            return rdist.gather_clip_vectors(vecs, world * B, rank, world)
-        return vecs
-
     def barrier():
         if world > 1:
-            dist.barrier()
+            rdist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    out = None
-    for i in range(args.steps):
-        out = step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gemm_ms, gemm_flops, gemm_launches = eng.profile_read(3 if x6 else 0)
-    frag_ms, frag_bytes, frag_launches = eng.profile_read(1)
-    _, gemm_alg_bytes, _ = eng.profile_read(4 if x6 else 2)
-    flow_ms, flow_bytes, flow_launches = eng.profile_read(5)
-    other_ms, other_flops, other_launches = eng.profile_read(0 if x6 else 3)   # contraction launches on the other kernel (conv1)
+    if args.dataset_clips:
+        dataset_mode(args, eng, rank, world, barrier, precision)
+        return
+
+    def make_step(workload, clips_per_step, n_resident=2, seed_base=0, distinct=4):
+        """-> (step(i), feature dim).  Two distinct resident clips per rank, alternated (inputs are in HBM before timing starts)."""
+        h_, w_, t_, vit_ = WORKLOADS[workload]
+        resident = [torch.from_numpy(synth.synthetic_clip(t_, h_, w_, clip_id=seed_base + rank * n_resident + i, distinct=distinct)).cuda()
+                    for i in range(n_resident)]
+        is_full = workload.startswith("full")
+
+        def step(i):
+            batch = [resident[(i * clips_per_step + j) % n_resident] for j in range(clips_per_step)]
+            if is_full:
+                vecs = eng.full_clip_vectors(batch, flow=True)
+            else:
+                vecs = eng.clip_vectors(batch, resnet=True, vit=vit_)          # [B, feat_dim]
+            if world > 1:
+                return rdist.gather_clip_vectors(vecs, world * clips_per_step, rank, world)
+            return vecs
+        return step, (35203 if is_full else 15171 + (4608 if vit_ else 0)), resident
+
+    def timed(step, steps, warmup):
+        """warmup untimed steps, then exactly `steps` steps between two barrier + synchronize brackets; the contraction / fragment /
+        flow kernels of the timed steps are also timed one by one with HIP events on the launch stream."""
+        for i in range(warmup):
+            step(i)
+        barrier()
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        out = None
+        for i in range(steps):
+            out = step(i)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = {"gemm": eng.profile_read(3 if x6 else 0), "frag": eng.profile_read(1), "gemm_bytes": eng.profile_read(4 if x6 else 2),
+                "flow": eng.profile_read(5), "other": eng.profile_read(0 if x6 else 3)}
+        eng.profile_enable(False)
+        return elapsed, out, prof
+
+    n_resident = args.resident_clips or 2
+    step, feat_dim, clips = make_step(args.workload, B, n_resident)
+    full = args.workload.startswith("full")
+    elapsed, out, prof = timed(step, args.steps, args.warmup)
+    gemm_ms, gemm_flops, gemm_launches = prof["gemm"]
+    frag_ms, frag_bytes, frag_launches = prof["frag"]
+    _, gemm_alg_bytes, _ = prof["gemm_bytes"]
+    flow_ms, flow_bytes, flow_launches = prof["flow"]
+    other_ms, other_flops, other_launches = prof["other"]   # contraction launches on the other kernel family
     assert eng.precision() == precision
-    eng.profile_enable(False)
     assert out.shape == (world * B, feat_dim) and bool(torch.isfinite(out).all())
 
     # metric (ii) of SURVEY §8(d): the same steps with every clip copied from pinned host memory on a side stream
@@ -294,6 +322,30 @@ def main():
                 "contraction_algorithmic_tflops": f_flops / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0,
                 "frac_of_fp32_mfma_peak": (f_flops / (f_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS) if (f_ms > 0 and other == "fp32") else None}
 
+    # the other BASELINE configurations on this GPU, a few steps each (the headline stays config 3)
+    others = None
+    if world == 1 and not args.no_other_workloads and args.workload == "config3" and x6:
+        del clips, step
+        others = {}
+        for name, b_o in (("config2", 16), ("config4", 16), ("full2160p", 2)):
+            torch.cuda.empty_cache()
+            step_o, dim_o, clips_o = make_step(name, b_o, 2, seed_base=50, distinct=2 if name == "full2160p" else 4)
+            e_o, out_o, prof_o = timed(step_o, 3, 1)
+            assert out_o.shape == (b_o, dim_o) and bool(torch.isfinite(out_o).all())
+            g_ms, g_flops, g_n = prof_o["gemm"]
+            rec = {"value": 3 * b_o / e_o, "unit": "clips/s", "ms_per_step": e_o / 3 * 1e3, "clips_per_step": b_o, "steps": 3,
+                   "feature_dim": dim_o,
+                   "roofline": {"bound": "mfma", "kernel": "gemm_x6 + conv1_x6", "unit": "TFLOP/s", "peak": BF16_MATRIX_PEAK_TFLOPS,
+                                "achieved": 6 * g_flops / (g_ms * 1e-3) / 1e12, "frac": 6 * g_flops / (g_ms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS,
+                                "kernel_time_share_of_step": g_ms * 1e-3 / e_o}}
+            fl_ms, fl_bytes, fl_n = prof_o["flow"]
+            if fl_n:
+                rec["roofline_flow_stage"] = {"bound": "hbm", "kernel": FLOW_KERNEL, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                                              "achieved": fl_bytes / (fl_ms * 1e-3) / 1e9, "frac": fl_bytes / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                              "kernel_time_share_of_step": fl_ms * 1e-3 / e_o}
+            others[name] = rec
+            del step_o, clips_o, out_o
+
     if world > 1:
         elapsed = rdist.all_reduce_max(elapsed, "cuda")
 
@@ -307,12 +359,9 @@ def main():
             "value": clips_total / elapsed, "unit": "clips/s", "n_gpus": world, "rccl_ranks": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into two bf16 terms, fp32 accumulate; reduced precision)",
-                      "bf16x6": "f32 (fp32 operands as 3 bf16 planes, 6 partial products on the bf16 MFMA, fp32 accumulate: fp32-grade)"}[precision],
+            "dtype": DTYPE_TEXT[precision],
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: synthetic {W}x{H} clips, {T} (frame,next) pairs, residual fragments + "
-                                   f"ResNet-50 layer-stack/pool" + (" + ViT-B/16 pool" if use_vit else "") +
-                                   ", random-init weights", "clips_per_step_per_gpu": B, "pairs_per_clip": T,
+            "config": {"workload": workload_text(args.workload), "clips_per_step_per_gpu": B, "pairs_per_clip": T,
                        "feature_dim": feat_dim, "parallelism": f"clip-sharded dp{world}, RCCL all-gather of per-clip vectors"},
             "roofline": {
                 "bound": "mfma",
@@ -326,7 +375,8 @@ def main():
                 "algorithmic_tflops": achieved,
                 "traffic": hbm_traffic_per_launch(args.workload, B, precision),
                 "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (own passes, FETCH doubled "
-                                "per the gfx950 guide), measured once for this workload and precision: profiles/r02_hbm_traffic.json",
+                                "per the gfx950 guide), measured for this workload, batch and precision by tools/profile_round3.sh: "
+                                "profiles/r03_hbm_traffic.json (null when no committed profile matches the run)",
                 "algorithmic_bytes_per_launch": gemm_alg_bytes / max(gemm_launches, 1),
                 "launches": gemm_launches, "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                 "algorithmic_gflop_per_launch": gemm_flops / max(gemm_launches, 1) / 1e9,
@@ -344,7 +394,7 @@ def main():
         }
         if full and flow_launches:
             result["roofline_flow_stage"] = {
-                "bound": "hbm", "kernel": "update_matrices_k (Farneback: matrix entries from the two polynomial expansions and the flow)",
+                "bound": "hbm", "kernel": FLOW_KERNEL,
                 "achieved": flow_bytes / (flow_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": flow_bytes / (flow_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                 "algorithmic_bytes_per_pixel_level_iteration": 68, "launches": flow_launches,
@@ -353,12 +403,73 @@ def main():
             result["exact_fp32_mode" if other == "fp32" else "bf16x6_mode"] = fast
         if h2d is not None:
             result["with_pinned_host_to_device_copy"] = h2d
+        if others is not None:
+            result["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(H, W, T, use_vit, rn_sd, vit_sd, args.cpu_sample_pairs)
+            result["cpu_baseline"] = cpu_baseline(H, W, T, use_vit, rn_sd, vit_sd if use_vit else None, args.cpu_sample_pairs)
             result["speedup_vs_cpu_faithful"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
     if world > 1:
-        dist.barrier()
+        rdist.barrier()
+        dist.destroy_process_group()
+
+
+FLOW_KERNEL = "update_matrices_k (Farneback: matrix entries from the two polynomial expansions and the flow)"
+DTYPE_TEXT = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into two bf16 terms, fp32 accumulate; reduced precision)",
+              "bf16x6": "f32 (fp32 operands as 3 bf16 planes, 6 partial products on the bf16 MFMA, fp32 accumulate: fp32-grade)"}
+
+
+def workload_text(name):
+    H, W, T, use_vit = WORKLOADS[name]
+    return (f"{name}: synthetic {W}x{H} clips, {T} (frame,next) pairs, residual fragments + ResNet-50 layer-stack/pool"
+            + (" + ViT-B/16 pool" if use_vit else "")
+            + (" + whole-frame features + Farneback flow fragments (35203-d)" if name.startswith("full") else "") + ", random-init weights")
+
+
+def dataset_mode(args, eng, rank, world, barrier, precision):
+    """BASELINE config 4 as written: --dataset-clips clips sharded over the ranks (relax-vqa_amd/dataset.py), ONE all-gather of the
+    [n, F] matrix; strong scaling: value = n clips / the time of the whole pass (max over ranks), warm-up batches untimed."""
+    from relax_vqa_amd import dataset
+    H, W, T, use_vit = WORKLOADS[args.workload]
+    full = args.workload.startswith("full")
+    n = args.dataset_clips
+    B = args.clips_per_step
+    n_resident = args.resident_clips or 4
+    # every rank holds the same few distinct clips; clip i of the list is resident[i % n_resident] (the list is synthetic: what is
+    # measured is the pass over n clips, and a rank count must not change which pixels clip i has)
+    resident = [torch.from_numpy(synth.synthetic_clip(T, H, W, clip_id=700 + i, distinct=4)).cuda() for i in range(n_resident)]
+    source = lambda i: resident[i % n_resident]   # noqa: E731
+    kw = dict(clips_per_step=B, resnet=True, vit=use_vit, full=full, rank=rank, world=world)
+    for _ in range(args.warmup):
+        dataset.extract_dataset_clips(source, min(B * world, n), eng, **kw)
+    barrier()
+    timings = {}
+    t0 = time.perf_counter()
+    matrix, errors = dataset.extract_dataset_clips(source, n, eng, timings=timings, **kw)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gather_s = timings["all_gather_s"]
+    if world > 1:
+        elapsed = rdist.all_reduce_max(elapsed, "cuda")
+        gather_s = rdist.all_reduce_max(gather_s, "cuda")
+    F = dataset.feature_dim(eng, True, use_vit, full)
+    assert matrix.shape == (n, F) and not errors and bool(torch.isfinite(matrix).all()), (matrix.shape, errors[:3])
+    if rank == 0:
+        if args.dump_matrix:
+            np.save(args.dump_matrix, matrix.cpu().numpy())
+        per_rank = -(-n // world)
+        print(json.dumps({
+            "metric": f"clips/sec feature extraction, dataset pass ({args.workload}, {n} clips sharded over the ranks)",
+            "value": n / elapsed, "unit": "clips/s", "n_gpus": world, "rccl_ranks": world, "steps": -(-per_rank // B),
+            "warmup": args.warmup, "ms_per_step": elapsed / (-(-per_rank // B)) * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": DTYPE_TEXT[precision], "data": "synthetic",
+            "config": {"workload": workload_text(args.workload) + f"; {n} clips, contiguous shards of <= {per_rank}",
+                       "dataset_clips": n, "clips_per_step_per_gpu": B, "pairs_per_clip": T, "feature_dim": F, "distinct_clips": n_resident,
+                       "parallelism": f"clip-sharded dp{world}, one RCCL all-gather of the [{n}, {F}] matrix"},
+            "all_gather_ms": gather_s * 1e3, "extract_s": timings["extract_s"], "errors": len(errors),
+            "gemm_split_k": args.gemm_split_k}))
+    if world > 1:
+        rdist.barrier()
         dist.destroy_process_group()
 
 

@@ -74,8 +74,8 @@ int relax_reserve(relax_handle* h, int max_images);
  * "gemm_split_k" (default 1): cut the tail tiles of a contraction along K so the last round fills
  * the chip; results stay deterministic for a given batch, but the K-summation order of tail tiles then depends on the
  * batch size - set 0 when features must be bit-identical across batch compositions (e.g. comparing sharded runs).
- * "gemm_variant", "gemm_variant_n64", "gemm_group_m", "gemm_prio": tuning knobs (tile variants are listed in csrc/gemm.hip;
- * none of them changes results beyond fp32 rounding).  "flow_max_pairs": cap on the pairs one optical-flow launch takes
+ * "gemm_variant", "gemm_variant_n64" (exact-fp32 kernel only), "gemm_group_m": tuning knobs (tile variants are listed in
+ * csrc/gemm.hip; none of them changes results beyond fp32 rounding).  "flow_max_pairs": cap on the pairs one optical-flow launch takes
  * (0 = by workspace size).  "debug_poison" (test mode, default 0): every workspace request fills the buffer with 0xFF bytes
  * first (synchronously), so a read of workspace that was not written in the same call shows up in the results. */
 int relax_set_option(relax_handle* h, const char* key, int value);
@@ -182,11 +182,16 @@ int relax_mlp_head(relax_handle* h, const float* features, int n, float* scores,
 
 /* ---- operator level (what the backbones are built from; parity-tested one by one) ------------ */
 /* out[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + residual[M,N]);  act: 0 none, 1 relu, 2 gelu(erf).
- * fp32 in, fp32 MFMA accumulate.  K % 32 == 0, N % 64 == 0.  bias/residual may be NULL. */
+ * fp32 in, fp32 MFMA accumulate.  K % 32 == 0 (bf16x6: K % 16 == 0), N % 64 == 0.  bias/residual may be NULL; every pointer
+ * 16-byte aligned.  These operator-level entry points are test / bench paths: under "gemm_precision" 2 (default) BOTH
+ * operands are converted to split planes on every call (two extra kernels, (M+N)*K*6 bytes; the model drivers keep weights
+ * and activations in that format instead), into a workspace the handle owns - like every entry point they must not run
+ * concurrently on two streams of one handle.  Finite operands up to 3.38e38 (csrc/sp3.h); beyond: "gemm_precision" 0. */
 int relax_op_gemm(relax_handle* h, const float* A, const float* W, const float* bias, const float* residual,
                   float* out, int M, int N, int K, int act, relax_stream stream);
 /* NHWC conv as implicit GEMM: in [Nimg,H,W,Cin], w [Cout, KH*KW*Cin (padded to %32)] (k = (dy*KW+dx)*Cin+c),
- * out [Nimg,Ho,Wo,Cout].  Cin a power of two >= 4 when KH*KW > 1. */
+ * out [Nimg,Ho,Wo,Cout].  Cin a power of two >= 4 when KH*KW > 1.  Under "gemm_precision" 2 the bf16x6 kernel takes
+ * geometries with Cin % 16 == 0, KH*KW <= 32 and Cout % 64 == 0; every other one runs on the exact-fp32 kernel. */
 int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const float* bias,
                          const float* residual, float* out, int Nimg, int H, int W, int Cin, int Cout,
                          int KH, int KW, int stride, int pad, int act, relax_stream stream);

@@ -160,9 +160,6 @@ int relax_create(int device, relax_handle** out) {
     if (const char* e = getenv("RELAX_GEMM_VARIANT")) h->gemm.variant = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_VARIANT_N64")) h->gemm.variant_n64 = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_GROUP_M")) h->gemm.group_m = atoi(e) > 0 ? atoi(e) : 1;
-    if (const char* e = getenv("RELAX_GEMM_PRIO")) h->gemm.prio = atoi(e);
-    if (const char* e = getenv("RELAX_GEMM_PHASE")) h->gemm.phase = atoi(e) >= 2 && atoi(e) <= 8 ? atoi(e) : 0;
-    if (const char* e = getenv("RELAX_GEMM_STAGGER")) h->gemm.stagger = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("RELAX_DEBUG_POISON")) h->gemm.debug_poison = atoi(e) != 0;
     *out = h;
     return RELAX_OK;
@@ -221,9 +218,6 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     else if (k == "gemm_variant") h->gemm.variant = value;
     else if (k == "gemm_variant_n64") h->gemm.variant_n64 = value;
     else if (k == "gemm_group_m") h->gemm.group_m = value > 0 ? value : 1;
-    else if (k == "gemm_prio") h->gemm.prio = value;
-    else if (k == "gemm_stagger") h->gemm.stagger = value > 0 ? value : 0;
-    else if (k == "gemm_phase") h->gemm.phase = value >= 2 && value <= 8 ? value : 0;
     else if (k == "flow_max_pairs") h->gemm.flow_max_pairs = value > 0 ? value : 0;
     else if (k == "debug_poison") h->gemm.debug_poison = value != 0;
     else {
@@ -251,9 +245,6 @@ int relax_get_option(relax_handle* h, const char* key, int* value) {
     else if (k == "gemm_variant") *value = h->gemm.variant;
     else if (k == "gemm_variant_n64") *value = h->gemm.variant_n64;
     else if (k == "gemm_group_m") *value = h->gemm.group_m;
-    else if (k == "gemm_prio") *value = h->gemm.prio;
-    else if (k == "gemm_stagger") *value = h->gemm.stagger;
-    else if (k == "gemm_phase") *value = h->gemm.phase;
     else if (k == "flow_max_pairs") *value = h->gemm.flow_max_pairs;
     else if (k == "debug_poison") *value = h->gemm.debug_poison;
     else {

@@ -16,6 +16,7 @@
 // Defaults (launch_conv): fp32 128x128 tile, 4 waves, BK = 16, three workgroups per CU; 128x64 for N % 128 != 0;
 // opt-in bf16x3 precision: 256x256 tile on 8 waves for large plain GEMMs, 128-wide tiles otherwise.
 #include "relax_internal.h"
+#include "host_logic.h"
 #include "gelu.h"
 
 #ifndef RELAX_F32_ABLATE
@@ -52,7 +53,6 @@ struct GemmParams {
     int tiles_m, tiles_n, ntiles, group_m;
     int full_tiles;  // tiles [0, full_tiles) run the whole K loop and the epilogue in-kernel
     int nsplit;      // tiles [full_tiles, ntiles) are cut into nsplit K slices (raw partial sums)
-    int prio;        // experiment knob: raise wave priority around the MFMA cluster
     unsigned long long* stamps;   // RELAX_GEMM_STAMPS builds only: per-workgroup phase timestamps
 };
 
@@ -242,7 +242,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
     {  \
         const float* As = smem + (cur_) * STAGE + (wm * TM * 32) * LDK + frag_off;  \
         const float* Bs = smem + (cur_) * STAGE + BM * LDK + (wn * TN * 32) * LDK + frag_off;  \
-        if (p.prio) __builtin_amdgcn_s_setprio(1);  \
         if constexpr (PREC == 0) {  \
 _Pragma("unroll")  \
             for (int q = 0; q < BK / 8; ++q) {  \
@@ -287,7 +286,6 @@ _Pragma("unroll")  \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? al[i] : ah[i], t == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);  \
             }  \
         }  \
-        if (p.prio) __builtin_amdgcn_s_setprio(0);  \
     }
 
     // bf16x3 steady-state step: MFMAs on LDS buffer cur_, with the staged registers (ra, rb) of the NEXT tile split and
@@ -545,35 +543,19 @@ static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hip
     p.tiles_m = (p.M + BM - 1) / BM;
     p.ntiles = p.tiles_m * p.tiles_n;
     p.group_m = h->gemm.group_m;
-    p.prio = h->gemm.prio;
     p.full_tiles = p.ntiles;
     p.nsplit = 1;
     p.partial = nullptr;
     // Tail split-K: the last partial round of tiles would leave most CUs idle; cut those tiles along K so
-    // that the tail fills the chip once with short work units (partials summed in order by splitk_finish).
-    const int slots = blocks_per_cu * 256;
-    const int nk = p.Kpad / BK;
-    const int rem = p.ntiles % slots;
-    if (h->gemm.split_k && rem > 0) {
-        // time of the tail in rounds if its tiles are cut into S slices: ceil(rem*S/slots)/S, plus ~4 % of a round per
-        // extra slice for writing/re-reading the partial tiles; keep S = 1 unless splitting clearly wins
-        int best_s = 1;
-        double best = 1.0;
-        const int smax = nk / 4 < 16 ? nk / 4 : 16;
-        for (int S = 2; S <= smax; ++S) {
-            const double t = (double)((rem * S + slots - 1) / slots) / S + 0.04 * S;
-            if (t < best - 0.05) {
-                best = t;
-                best_s = S;
-            }
-        }
-        if (best_s >= 2) {
-            const size_t need = sizeof(float) * (size_t)rem * best_s * BM * BN;
-            RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
-            p.partial = static_cast<float*>(h->splitk_ws.p);
-            p.full_tiles = p.ntiles - rem;
-            p.nsplit = best_s;
-        }
+    // that the tail fills the chip once with short work units (partials summed in order by splitk_finish).  Cost model:
+    // host_logic.cpp (shared with gemm_x6.hip).
+    const host::TailSplit ts = host::choose_tail_split(p.ntiles, blocks_per_cu * 256, p.Kpad / BK, 4, h->gemm.split_k != 0);
+    if (ts.nsplit > 1) {
+        const size_t need = sizeof(float) * (size_t)(p.ntiles - ts.full_tiles) * ts.nsplit * BM * BN;
+        RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
+        p.partial = static_cast<float*>(h->splitk_ws.p);
+        p.full_tiles = ts.full_tiles;
+        p.nsplit = ts.nsplit;
     }
     constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * (BK + 4);
     static bool attr_set[kMaxDevices] = {};   // per (kernel instantiation, device): the attribute lives on the device's code object
@@ -741,7 +723,10 @@ int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const
     d.Kpad = ((KH * KW * Cin + 31) / 32) * 32;
     d.bias = bias; d.residual = residual; d.out = out; d.act = act;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (h->gemm.precision == 2 && Cin % 16 == 0 && d.Kpad == KH * KW * Cin) {
+    // bf16x6 where the split-plane kernel takes the geometry (16-channel chunks, at most 32 taps, 64-column tiles); anything
+    // else - e.g. a 7x7 filter, Cin = 8 - runs on the exact-fp32 kernel as it did before bf16x6 became the default
+    if (h->gemm.precision == 2 && Cin % 16 == 0 && d.Kpad == KH * KW * Cin && KH * KW <= 32 && Cout % 64 == 0 &&
+        (KH * KW > 1 || pad == 0)) {
         // operator-level entry under "bf16x6": input and weights are converted to split planes here
         const size_t a_bytes = (size_t)Nimg * H * W * Cin * 6, w_bytes = (size_t)Cout * d.Kpad * 6;
         RELAX_TRY(ensure_buf(h, h->sp3_ws, a_bytes + w_bytes + 256));

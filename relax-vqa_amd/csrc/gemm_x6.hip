@@ -31,8 +31,10 @@
 // epilogue goes through LDS in 64-row passes so that every store instruction writes whole 512-byte row segments, and
 // can add bias / an sp3 or fp32 residual, apply ReLU / GELU, write fp32 and / or sp3, and emit 16-row column sums for
 // the global-average-pool taps.  What was measured and NOT adopted (three stages, staggered starts, pinned
-// instruction order, non-temporal stores) is in DESIGN.md section 3.2.
+// instruction order, non-temporal stores, 128x256 tiles on two workgroups per CU, K-slice phase starts) is recorded in
+// DESIGN.md section 3.2; none of that code is kept here.
 #include "relax_internal.h"
+#include "host_logic.h"
 #include "sp3.h"
 #include "gelu.h"
 
@@ -40,9 +42,6 @@
 #define X6_STAMP(i_) if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime()
 #else
 #define X6_STAMP(i_)
-#endif
-#ifndef RELAX_X6_ABLATE
-#define RELAX_X6_ABLATE 0   // build-time experiments: 1 no DMA in the K loop (WRONG results), 2 every DMA re-reads K step 0 (WRONG), 4 pin the instruction order of a pipeline region with sched_group_barrier, 8 GELU = identity (WRONG), 16 non-temporal fp32 output stores, 64 only the three largest of the six partial products (WRONG: what a three-product arithmetic would run at in this kernel), 32 split-plane output as linear 1 KiB-per-wave stores (WRONG layout; worth 0.4 % of a ViT pass: the 32-byte runs of the plane stores are not what bounds the epilogue)
 #endif
 
 namespace relax {
@@ -91,9 +90,6 @@ struct X6Params {
     int act;
     int tiles_m, tiles_n, ntiles, group_m;
     int full_tiles, nsplit;
-    int f0, pu;                   // launch order: f0 full tiles, then pu split units (phase start, see launch_x6_variant), then the rest
-    int stagger;                  // cycles of one tile: XCD x delays its first round by x/8 of it (0 = off)
-    int first_round;              // workgroups resident at launch (256 CUs x workgroups per CU)
     unsigned long long* stamps;   // RELAX_X6_STAMPS builds only
 };
 
@@ -103,10 +99,7 @@ __device__ inline int xcd_remap6(int b, int nwg) {
     return base + (b >> 3);
 }
 
-__device__ inline f32x4 act_gelu4(const f32x4 v) {
-    if (RELAX_X6_ABLATE & 8) return v;   // build experiment: what the exact-erf GELU costs in the epilogue (WRONG results)
-    return gelu_erf4(v);
-}
+__device__ inline f32x4 act_gelu4(const f32x4 v) { return gelu_erf4(v); }
 
 // global -> LDS without registers: 16 bytes per lane to LDS address M0 + 16 * lane; the source is base(rsrc) + voff + soff,
 // and a lane whose voff is beyond the resource's byte count gets zeros (rows past M, padding taps)
@@ -138,12 +131,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int YH = YT / 2;
     constexpr int ROWS = BM + BN;
     constexpr int STAGE = ROWS * kChunkBytes;
-    constexpr int NSTAGE = 2;                     // a third stage (8-wave tile: 144 KB, DMA two steps ahead) measured no faster
-    constexpr int PIECES = ROWS * 6 / 64;         // 1 KiB DMA pieces per stage
+        constexpr int PIECES = ROWS * 6 / 64;         // 1 KiB DMA pieces per stage
     constexpr int A_PIECES = BM * 6 / 64;
     constexpr int PPW = (PIECES + NW - 1) / NW;   // pieces per wave (a wave short of real pieces issues dummy ones)
     constexpr int A_PPW = A_PIECES / NW;
-    constexpr int DUMMY = NSTAGE * STAGE;         // 1 KiB nobody reads
+    constexpr int DUMMY = 2 * STAGE;              // 1 KiB nobody reads
     static_assert(ROWS % 32 == 0 && TM >= 1 && TN >= 1 && YT % 2 == 0 && A_PIECES % NW == 0, "tile / wave layout mismatch");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -157,13 +149,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     {
         const int nk_all = p.K >> 4;
         const int b = blockIdx.x;
-        const bool early_split = b >= p.f0 && b < p.f0 + p.pu;
-        if (!early_split && b < p.pu + p.full_tiles) {
-            tile = xcd_remap6(b < p.f0 ? b : b - p.pu, p.full_tiles);
+        if (b < p.full_tiles) {
+            tile = xcd_remap6(b, p.full_tiles);
             kt_begin = 0;
             kt_end = nk_all;
         } else {
-            const int u = early_split ? b - p.f0 : b - p.full_tiles;
+            const int u = b - p.full_tiles;
             split_tile = u / p.nsplit;
             slice = u - split_tile * p.nsplit;
             tile = p.full_tiles + split_tile;
@@ -190,22 +181,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
     }
 #endif
-
-    // Launched together, the workgroups of a round run in lockstep and reach their epilogues at the same moment: 256 CUs
-    // then write (and re-read, for a residual) their tiles at once, and the epilogue takes as long as HBM needs for the
-    // burst (measured 48k cycles per 256x256 tile against ~15k when the memory system is quiet).  Lockstep INSIDE an XCD is
-    // wanted (the workgroups of an XCD share A / W tiles through its L2 while they walk K together), so the first round
-    // is staggered per XCD: XCD x starts x/8 of a tile later, which spreads the eight bursts over the tile time for the
-    // rest of the launch.  Speed heuristic only.
-    if (p.stagger > 0 && (int)blockIdx.x < p.first_round) {
-        if (tid == 0) {
-            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7;   // HW_REG_XCC_ID
-            const unsigned long long wait = (unsigned long long)p.stagger * xcc / 8;
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
-        }
-        __syncthreads();
-    }
 
     // ---- DMA descriptors.  Piece j of this wave (global piece wave + NW*j) covers LDS bytes [piece*1024, +1024) of a
     // stage; lane l fills unit u = piece*64 + l = (tile row u/6, physical unit u%6); physical unit (plane q, half h')
@@ -293,7 +268,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 X6_DMA(rsrc_w, dst_, voff[j], lin_);                                                                    \
             }                                                                                                           \
         }                                                                                                               \
-        if (!(RELAX_X6_ABLATE & 2)) ++d_kt;                                                                             \
+        ++d_kt;                                                                                                         \
         if (TAPS) {                                                                                                     \
             ++d_tap;                                                                                                    \
             ++d_dx;                                                                                                     \
@@ -333,7 +308,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     // the six partial products, smallest first: (A plane, B plane) = (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi);
     // product type outermost: XT*YH independent accumulators between two MFMAs on the same one
 #define X6_MFMAS(set_, yf_, half_)                                                                                      \
-    _Pragma("unroll") for (int t = (RELAX_X6_ABLATE & 64) ? 3 : 0; t < 6; ++t) {   /* 64: only the three largest products (WRONG) */ \
+    _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                                     \
         const int pa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0;                                                         \
         const int pb = t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0;                                                         \
         _Pragma("unroll") for (int x = 0; x < XT; ++x) _Pragma("unroll") for (int y = 0; y < YH; ++y) {                 \
@@ -345,24 +320,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                                                                                    acc[(half_) * YH + y][x], 0, 0, 0);  \
         }                                                                                                               \
     }
-    // one K step on stage xs_ (= its parity): has_next_ / has_d_ are literal `true` in the steady state (branch-free body)
     // One pipeline region = everything between two barriers: [wait, barrier, DMA of step k+2, reads of X and Y-half-0 of step
     // k+1, M1(k), reads of Y-half-1 of step k+1, M0(k+1)].  xs_ = parity (= LDS stage) of step k.  has_next_ / has_d_ are
-    // literal `true` in the steady state (branch-free).  Rotating the loop this way (one basic block per region) was worth
-    // 2.5 % by itself; PINNING the order inside a region with sched_group_barrier (build experiment RELAX_X6_ABLATE=4: reads of
-    // the next step first, the DMA pieces spread one per three MFMAs, Y-half-1 reads two MFMAs apart) measured 7 % slower than
-    // what the compiler's scheduler does on its own, so it is off.  Masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read.
-#define X6_REGION(xs_, has_next_, has_d_, steady_)                                                                      \
+    // literal `true` in the steady state (branch-free, one basic block per region: the compiler's own interleaving of the
+    // block measured faster than any order pinned with sched_group_barrier).
+#define X6_REGION(xs_, has_next_, has_d_)                                                                               \
     {                                                                                                                   \
-        const int st_next_ = NSTAGE == 2 ? ((xs_) ^ 1) : (st_cur + 1 < NSTAGE ? st_cur + 1 : 0);                        \
-        const char* sn_ = smem + st_next_ * STAGE;                                                                      \
+        const char* sn_ = smem + ((xs_) ^ 1) * STAGE;                                                                   \
         if (has_next_) {                                                                                                \
-            /* own DMA pieces of step k+1 have landed (those of the steps after it stay in flight), own reads are done */ \
-            if (has_d_ || NSTAGE == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * PPW) : "memory"); \
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+            /* own DMA pieces of step k+1 have landed, own fragment reads are done */                                   \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
             __builtin_amdgcn_s_barrier();                                                                               \
-            /* every wave has stage k in registers: it is free for step k + NSTAGE */                                  \
-            if (has_d_ && !(RELAX_X6_ABLATE & 1)) X6_ISSUE(NSTAGE == 2 ? (xs_) : st_cur);                               \
+            /* every wave has stage k in registers: it is free for step k + 2 */                                        \
+            if (has_d_) X6_ISSUE(xs_);                                                                                  \
             X6_READ_X((xs_) ^ 1, sn_);                                                                                  \
             X6_READ_Y(yf0, 0, sn_);                                                                                     \
         }                                                                                                               \
@@ -371,37 +341,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             X6_READ_Y(yf1, 1, sn_);                                                                                     \
             X6_MFMAS((xs_) ^ 1, yf0, 0);                                                                                \
         }                                                                                                               \
-        st_cur = st_next_;                                                                                              \
-        if (steady_ && (RELAX_X6_ABLATE & 4)) {   /* experiment only: measured 7 % SLOWER than the compiler's own order */                                                                        \
-            constexpr int NREAD_ = (XT + YH) * 3;      /* X' and Y-half-0 fragments of the next step */                 \
-            constexpr int NM_ = XT * YH * 6;           /* MFMAs of a half step */                                       \
-            constexpr int M_DMA_ = (NM_ - NREAD_ / 2) / PPW > 0 ? (NM_ - NREAD_ / 2) / PPW : 1;                         \
-            _Pragma("unroll") for (int i_ = 0; i_ < NREAD_ / 2; ++i_) {                                                 \
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                      \
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
-            }                                                                                                           \
-            _Pragma("unroll") for (int i_ = 0; i_ < PPW; ++i_) {                                                        \
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                      \
-                __builtin_amdgcn_sched_group_barrier(0x008, M_DMA_, 0);                                                 \
-            }                                                                                                           \
-            if (NM_ - NREAD_ / 2 - M_DMA_ * PPW > 0)                                                                    \
-                __builtin_amdgcn_sched_group_barrier(0x008, NM_ - NREAD_ / 2 - M_DMA_ * PPW, 0);                        \
-            _Pragma("unroll") for (int i_ = 0; i_ < YH * 3; ++i_) {                                                     \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
-            }                                                                                                           \
-        }                                                                                                               \
     }
 
     const int nk = kt_end - kt_begin;
     X6_ISSUE(0);
     if (nk > 1) X6_ISSUE(1);
-    if (NSTAGE == 3 && nk > 2) X6_ISSUE(2);
-    if (NSTAGE == 3 && nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    int st_cur = 0;
     X6_READ_X(0, smem);
     X6_READ_Y(yf0, 0, smem);
     X6_STAMP(1);
@@ -409,14 +356,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     X6_READ_Y(yf1, 1, smem);
     X6_MFMAS(0, yf0, 0);          // M0 of step 0
     int k = 0;
-    // region k: has_next = step k+1 exists; has_d = step k + NSTAGE exists (its DMA is issued here)
-    for (; k + NSTAGE + 1 < nk; k += 2) {
-        X6_REGION(0, true, true, true);
-        X6_REGION(1, true, true, true);
+    // region k: has_next = step k+1 exists; has_d = step k+2 exists (its DMA is issued here)
+    for (; k + 3 < nk; k += 2) {
+        X6_REGION(0, true, true);
+        X6_REGION(1, true, true);
     }
     for (; k < nk; k += 2) {
-        X6_REGION(0, k + 1 < nk, k + NSTAGE < nk, false);
-        if (k + 1 < nk) X6_REGION(1, k + 2 < nk, k + 1 + NSTAGE < nk, false);
+        X6_REGION(0, k + 1 < nk, k + 2 < nk);
+        if (k + 1 < nk) X6_REGION(1, k + 2 < nk, k + 3 < nk);
     }
 #undef X6_REGION
 #undef X6_MFMAS
@@ -437,7 +384,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int EP_ROWS = 64;
     constexpr int C8 = BN / 8;
     static_assert(NT % C8 == 0 && (EP_ROWS * C8) % NT == 0, "epilogue chunk must divide over the workgroup");
-    static_assert(EP_ROWS * LDC * 4 <= NSTAGE * STAGE, "epilogue chunk must fit the staging LDS");
+    static_assert(EP_ROWS * LDC * 4 <= 2 * STAGE, "epilogue chunk must fit the staging LDS");
     constexpr int EP_STEP = NT / C8;
     constexpr int EP_ITERS = EP_ROWS / EP_STEP;
     const int half = lane >> 5;
@@ -533,26 +480,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             }
             const int64_t o = (int64_t)m * p.N + n0;
             if (p.out) {
-                if (RELAX_X6_ABLATE & 16) {   // build experiment: non-temporal stores
-                    __builtin_nontemporal_store(va, reinterpret_cast<f32x4*>(p.out + o + lcA));
-                    __builtin_nontemporal_store(vb, reinterpret_cast<f32x4*>(p.out + o + lcB));
-                } else {
-                    *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
-                    *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
-                }
+                *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
+                *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
             }
-            if (p.out_sp3) {
-                if (RELAX_X6_ABLATE & 32) {   // build experiment (WRONG layout): the same bytes as linear 1 KiB-per-wave stores
-                    sp3_u32x4 hi, mid, lo;
-                    split3_x8(va, vb, hi, mid, lo);
-                    char* d = p.out_sp3 + ((int64_t)(tm * p.tiles_n + tn) * (BM * BN * 6)) + (int64_t)((pass * EP_ITERS + it) * 3) * (NT * 16) + tid * 16;
-                    *reinterpret_cast<sp3_u32x4*>(d) = hi;
-                    *reinterpret_cast<sp3_u32x4*>(d + NT * 16) = mid;
-                    *reinterpret_cast<sp3_u32x4*>(d + 2 * NT * 16) = lo;
-                } else {
-                    store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lcA, va, vb);   // (planes: lcB = lcA + 4)
-                }
-            }
+            if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lcA, va, vb);   // (planes: lcB = lcA + 4)
             if (p.gap) {   // the finished values go back to the staging rows for the group sums below
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcA) = va;
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcB) = vb;
@@ -630,6 +561,36 @@ __global__ __launch_bounds__(256) void splitk_finish_x6(const X6Params p) {
     if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lc, va, vb);
 }
 
+#ifdef RELAX_X6_STAMPS
+// diagnostic build only: per-tile cycle stamps of the launch that just ran (prologue / K loop / epilogue)
+template <int BM, int BN>
+static int x6_report_stamps(relax_handle* h, const X6Params& p, int units, hipStream_t s) {
+    RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
+    std::vector<unsigned long long> hs(8 * (size_t)units);
+    RELAX_HIP_CHECK(h, hipMemcpy(hs.data(), p.stamps, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
+    double d[3] = {0, 0, 0};
+    for (int u = 0; u < p.full_tiles; ++u) {
+        const unsigned long long* t = &hs[8 * (size_t)u];
+        d[0] += (double)(t[1] - t[0]);
+        d[1] += (double)(t[2] - t[1]);
+        d[2] += (double)(t[3] - t[2]);
+    }
+    if (const char* dump = getenv("RELAX_X6_STAMP_DUMP")) {   // raw records of every launch, appended
+        if (FILE* f = fopen(dump, "ab")) {
+            const int hdr[8] = {p.M, p.N, p.K, BM, BN, units, p.full_tiles, 0};
+            fwrite(hdr, sizeof(hdr), 1, f);
+            fwrite(hs.data(), sizeof(hs[0]), hs.size(), f);
+            fclose(f);
+        }
+    }
+    const double n = p.full_tiles > 0 ? p.full_tiles : 1;
+    fprintf(stderr, "x6 %dx%dx%d tile %dx%d act %d res %d sp3out %d: cycles per tile: prologue %.0f, K loop %.0f (%d steps, %.0f per step), "
+            "epilogue %.0f\n", p.M, p.N, p.K, BM, BN, p.act, p.residual != nullptr, p.out_sp3 != nullptr, d[0] / n, d[1] / n,
+            p.K / 16, d[1] / n / (p.K / 16), d[2] / n);
+    return RELAX_OK;
+}
+#endif
+
 template <int BM, int BN, int WM, int WN, bool TAPS>
 static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
@@ -638,54 +599,18 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.ntiles = p.tiles_m * p.tiles_n;
     p.group_m = h->gemm.group_m;
-    p.full_tiles = p.ntiles;
-    p.nsplit = 1;
     p.partial = nullptr;
-    p.f0 = 0;
-    p.pu = 0;
-    const int slots = 256 * WG_PER_CU;
-    const int nk = p.K / 16;
-    const bool can_split = h->gemm.split_k && !p.gap && !p.residual_sp3;   // (the finish kernel knows neither of the two)
-    // Phase start ("gemm_phase" = S, one workgroup per CU): equal tiles keep all 256 CUs in lockstep, so every epilogue is a
-    // chip-wide burst of stores (and residual loads) that HBM serves in 40-50 k cycles while the matrix pipes idle.  Work that
-    // has to be done anyway - K slices of some tiles - is launched FIRST, arranged so that a third (quarter) of the CUs start
-    // on full tiles, the others on one, two (, three) short slices: from then on the CUs run 1/S of a tile apart and the
-    // bursts are spread over the tile time.  Launch order: f0 full tiles, pu split units, the other full tiles, the tail.
-    int phase_tiles = 0;
-    const int S_phase = h->gemm.phase;
-    if (can_split && WG_PER_CU == 1 && S_phase >= 2 && p.ntiles >= 3 * slots && nk >= 8 * S_phase) {
-        p.f0 = (slots / S_phase + 7) & ~7;
-        phase_tiles = ((slots * (S_phase - 1) / 2 + S_phase - 1) / S_phase + 7) & ~7;
-        p.pu = phase_tiles * S_phase;
-        p.nsplit = S_phase;
-    }
-    // Tail split-K (same cost model as gemm.hip): the last partial round of tiles is cut along K
-    const int rem = (p.ntiles - phase_tiles) % slots;
-    int best_s = 1;
-    if (can_split && rem > 0) {
-        double best = 1.0;
-        const int smax = nk / 8 < 16 ? nk / 8 : 16;
-        for (int S = 2; S <= smax; ++S) {
-            const double t = (double)((rem * S + slots - 1) / slots) / S + 0.04 * S;
-            if (t < best - 0.05) {
-                best = t;
-                best_s = S;
-            }
-        }
-        if (phase_tiles) best_s = S_phase;   // one slice count per launch (one finish kernel)
-    }
-    const int split_tiles = phase_tiles + (best_s >= 2 ? rem : 0);
-    if (split_tiles > 0) {
-        p.nsplit = phase_tiles ? S_phase : best_s;
-        const size_t need = sizeof(float) * (size_t)split_tiles * p.nsplit * BM * BN;
+    // Tail split-K: the last, partial round of tiles is cut along K (cost model: host_logic.cpp, shared with gemm.hip);
+    // splitk_finish_x6 knows neither the fused group sums nor a split-plane residual, so those launches run unsplit
+    const bool can_split = h->gemm.split_k && !p.gap && !p.residual_sp3;
+    const host::TailSplit ts = host::choose_tail_split(p.ntiles, 256 * WG_PER_CU, p.K / 16, 8, can_split);
+    p.full_tiles = ts.full_tiles;
+    p.nsplit = ts.nsplit;
+    if (p.nsplit > 1) {
+        const size_t need = sizeof(float) * (size_t)(p.ntiles - p.full_tiles) * p.nsplit * BM * BN;
         RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
         p.partial = static_cast<float*>(h->splitk_ws.p);
-        p.full_tiles = p.ntiles - split_tiles;
     }
-    // per-XCD stagger of the first round: one tile = its K loop at the full matrix rate (32 cycles per MFMA, two waves per SIMD)
-    // plus an epilogue; "gemm_stagger" scales it in percent
-    p.stagger = h->gemm.stagger ? (int)(((int64_t)nk * (BM / 64) * (BN / 64) * 6 * 32 * 2 / (NT / 128) + 20000) * h->gemm.stagger / 100) : 0;
-    p.first_round = slots;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * kChunkBytes + 1024;
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
@@ -700,30 +625,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
 #endif
     hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS>), dim3(units), dim3(NT), lds, s, p);
 #ifdef RELAX_X6_STAMPS
-    {
-        RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
-        std::vector<unsigned long long> hs(8 * (size_t)units);
-        RELAX_HIP_CHECK(h, hipMemcpy(hs.data(), p.stamps, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
-        double d[3] = {0, 0, 0};
-        for (int u = 0; u < p.full_tiles; ++u) {
-            const unsigned long long* t = &hs[8 * (size_t)u];
-            d[0] += (double)(t[1] - t[0]);
-            d[1] += (double)(t[2] - t[1]);
-            d[2] += (double)(t[3] - t[2]);
-        }
-        if (const char* dump = getenv("RELAX_X6_STAMP_DUMP")) {   // raw records of every launch, appended
-            if (FILE* f = fopen(dump, "ab")) {
-                const int hdr[8] = {p.M, p.N, p.K, BM, BN, units, p.full_tiles, p.stagger};
-                fwrite(hdr, sizeof(hdr), 1, f);
-                fwrite(hs.data(), sizeof(hs[0]), hs.size(), f);
-                fclose(f);
-            }
-        }
-        const double n = p.full_tiles > 0 ? p.full_tiles : 1;
-        fprintf(stderr, "x6 %dx%dx%d tile %dx%d act %d res %d sp3out %d: cycles per tile: prologue %.0f, K loop %.0f (%d steps, %.0f per step), "
-                "epilogue %.0f\n", p.M, p.N, p.K, BM, BN, p.act, p.residual != nullptr, p.out_sp3 != nullptr, d[0] / n, d[1] / n,
-                p.K / 16, d[1] / n / (p.K / 16), d[2] / n);
-    }
+    RELAX_TRY((x6_report_stamps<BM, BN>(h, p, units, s)));
 #endif
     if (p.nsplit > 1)
         hipLaunchKernelGGL((splitk_finish_x6<BM, BN>), dim3(BM * BN / 8 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
@@ -754,6 +656,11 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, !d.gap_groups || ((d.Ho * d.Wo) % 16 == 0 && p.M % 16 == 0), "x6 conv: the fused spatial mean needs Ho*Wo %% 16 == 0");
     RELAX_REQUIRE(h, !taps || (d.pad >= 0 && d.KH * d.KW <= 32), "x6 conv: bad padding, or more than 32 taps (%dx%d)", d.KH, d.KW);
     RELAX_REQUIRE(h, taps || d.pad == 0, "x6 conv: 1x1 with padding is not supported");
+    // every operand is read / written in 16-byte units (LDS-DMA pieces, f32x4 bias / residual / output accesses, plane units)
+    auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    RELAX_REQUIRE(h, aligned16(d.in) && aligned16(d.w) && aligned16(d.bias) && aligned16(d.residual) && aligned16(d.residual_sp3) &&
+                         aligned16(d.out) && aligned16(d.out_sp3) && aligned16(d.gap_groups),
+                  "x6 conv/gemm: every operand pointer must be 16-byte aligned");
     const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)p.K;
     // algorithmic HBM bytes: activation in (6 B per value), weights, outputs (+ residual), each touched once
     const double bytes = 6.0 * ((double)d.Nimg * d.H * d.W * d.Cin + (double)p.N * p.K) +
@@ -761,13 +668,10 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     int span;
     RELAX_TRY(prof_begin(h, s, 2, flops, &span, bytes));
     int rc;
-    // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA: K loop at 85 % of the
-    // matrix rate).  The alternative measured against it, two 4-wave workgroups per CU on 128x256 tiles ("gemm_variant" 2),
-    // hides its epilogues under the other workgroup's MFMAs but needs 1.5x the DMA pieces per MFMA: 4 % slower on the ViT.
-    if (p.N % 256 == 0 && h->gemm.variant != 2)
+    // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA); N = 128 / 64 layers: the same
+    // loop on four waves, two workgroups per CU
+    if (p.N % 256 == 0)
         rc = taps ? launch_x6_variant<256, 256, 2, 4, true>(h, p, s) : launch_x6_variant<256, 256, 2, 4, false>(h, p, s);
-    else if (p.N % 256 == 0)
-        rc = taps ? launch_x6_variant<128, 256, 2, 2, true>(h, p, s) : launch_x6_variant<128, 256, 2, 2, false>(h, p, s);
     else if (p.N % 128 == 0)
         rc = taps ? launch_x6_variant<256, 128, 2, 2, true>(h, p, s) : launch_x6_variant<256, 128, 2, 2, false>(h, p, s);
     else

@@ -7,6 +7,7 @@
 #include <cmath>
 
 #include "relax_internal.h"
+#include "host_logic.h"
 
 namespace relax {
 
@@ -55,30 +56,21 @@ int relax_load_mlp_head(relax_handle* h, const float* const* tensors, const char
                   "relax_load_mlp_head: bad arguments");
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
     free_head(h);
-    std::map<std::string, std::pair<const float*, int64_t>> sd;
+    host::StateDict sd;
     for (int i = 0; i < n; ++i) {
-        std::string k = names[i];
-        if (k == "n_averaged") continue;
-        if (k.rfind("module.", 0) == 0) k = k.substr(7);
-        sd[k] = {tensors[i], numels[i]};
+        if (names[i] && std::string(names[i]) == "n_averaged") continue;
+        sd.add(names[i], tensors[i], numels[i], /*strip_module=*/true);
     }
     auto get = [&](const char* key, int64_t numel) -> const float* {
-        auto it = sd.find(key);
-        if (it == sd.end()) {
-            set_error(h, "mlp head state dict: missing key '%s'", key);
-            return nullptr;
-        }
-        if (numel > 0 && it->second.second != numel) {
-            set_error(h, "mlp head state dict: key '%s' has %lld elements, expected %lld", key,
-                      (long long)it->second.second, (long long)numel);
-            return nullptr;
-        }
-        return it->second.first;
+        std::string err;
+        const float* p = sd.get(key, numel, err, "mlp head state dict");
+        if (!p) set_error(h, "%s", err.c_str());
+        return p;
     };
     const int F = input_features;
-    auto w1it = sd.find("fc1.weight");
-    RELAX_REQUIRE(h, w1it != sd.end() && w1it->second.second % F == 0, "mlp head: fc1.weight missing or not [hidden,%d]", F);
-    const int H1 = (int)(w1it->second.second / F);
+    const int64_t nw1 = sd.numel("fc1.weight");
+    RELAX_REQUIRE(h, nw1 > 0 && nw1 % F == 0, "mlp head: fc1.weight missing or not [hidden,%d]", F);
+    const int H1 = (int)(nw1 / F);
     const int H2 = H1 / 2;
     RELAX_REQUIRE(h, H1 % 64 == 0 && H2 % 64 == 0, "mlp head: hidden sizes %d/%d must be multiples of 64", H1, H2);
     const float *w1 = get("fc1.weight", (int64_t)H1 * F), *b1 = get("fc1.bias", H1);
@@ -92,13 +84,9 @@ int relax_load_mlp_head(relax_handle* h, const float* const* tensors, const char
     hw.Fpad = ((F + 31) / 32) * 32;
     hw.H1 = H1;
     hw.H2 = H2;
-    // fold BatchNorm1d (eval) into fc1: y = (x W^T + b - mu) * s + beta, s = gamma / sqrt(var + eps)
-    std::vector<float> w1p((size_t)H1 * hw.Fpad, 0.f), b1p(H1);
-    for (int o = 0; o < H1; ++o) {
-        const float s = g[o] / std::sqrt(var[o] + 1e-5f);
-        for (int f = 0; f < F; ++f) w1p[(size_t)o * hw.Fpad + f] = w1[(size_t)o * F + f] * s;
-        b1p[o] = (b1[o] - mu[o]) * s + be[o];
-    }
+    // fold BatchNorm1d (eval) into fc1: y = (x W^T + b - mu) * s + beta, s = gamma / sqrt(var + eps)   (host_logic.cpp)
+    std::vector<float> w1p((size_t)H1 * hw.Fpad), b1p(H1);
+    host::fold_fc_bn(w1, b1, g, be, mu, var, 1e-5f, H1, F, hw.Fpad, w1p.data(), b1p.data());
     int rc = upload(h, w1p.data(), w1p.size(), &hw.w1, hw.allocs);
     if (rc == RELAX_OK) rc = upload(h, b1p.data(), H1, &hw.b1, hw.allocs);
     if (rc == RELAX_OK) rc = upload(h, w2, (size_t)H2 * H1, &hw.w2, hw.allocs);

@@ -173,14 +173,11 @@ namespace relax {
 struct GemmOptions {
     int precision = 2; // "gemm_precision": 2 = bf16x6 (default, fp32-grade), 0 = exact fp32 MFMA, 1 = bf16x3 split products (~1e-5 relative)
     int split_k = 1;   // "gemm_split_k": tail split-K on (1) / off (0: K sums are batch-invariant bit for bit)
-    int variant = -1;  // "gemm_variant": pin the tile variant for N % 128 == 0 problems, -1 = automatic
+    int variant = -1;  // "gemm_variant": exact-fp32 kernel only: pin the tile variant for N % 128 == 0 problems, -1 = automatic
     int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)
     int group_m = 8;   // "gemm_group_m": row-tiles per L2 group
-    int prio = 0;      // "gemm_prio": s_setprio around the MFMA cluster
     int flow_max_pairs = 0;  // "flow_max_pairs": cap on the pairs per optical-flow chunk (0 = by workspace size only)
-    int phase = 0;     // "gemm_phase": bf16x6 phase start: S K-slices per early-split tile so that the CUs run 1/S of a tile apart (0 = off)
     int debug_poison = 0;  // "debug_poison": fill every workspace with 0xFF bytes when it is requested (test mode: reads of unwritten workspace surface as NaN)
-    int stagger = 0;   // "gemm_stagger": bf16x6 per-XCD stagger of the first round of tiles, in % of one tile time (0 = off)
 };
 }  // namespace relax
 

@@ -12,6 +12,7 @@
 #include <cmath>
 
 #include "relax_internal.h"
+#include "host_logic.h"
 
 namespace relax {
 
@@ -90,51 +91,35 @@ __global__ __launch_bounds__(256) void rn_pool_stats(const float* __restrict__ a
 }
 
 // ---- weights ---------------------------------------------------------------------------------------
-struct HostSD {
-    std::map<std::string, std::pair<const float*, int64_t>> t;
-    const float* get(relax_handle* h, const std::string& k, int64_t numel) const {
-        auto it = t.find(k);
-        if (it == t.end()) {
-            set_error(h, "state dict: missing key '%s'", k.c_str());
-            return nullptr;
-        }
-        if (it->second.second != numel) {
-            set_error(h, "state dict: key '%s' has %lld elements, expected %lld", k.c_str(),
-                      (long long)it->second.second, (long long)numel);
-            return nullptr;
-        }
-        return it->second.first;
-    }
-};
+// (key matching, BatchNorm folding and the OIHW -> [Cout][K] packing are host_logic.cpp: pure C++, sanitizer-tested on the CPU)
+using HostSD = host::StateDict;
+
+static const float* sd_get(relax_handle* h, const HostSD& sd, const std::string& k, int64_t numel) {
+    std::string err;
+    const float* p = sd.get(k, numel, err);
+    if (!p) set_error(h, "%s", err.c_str());
+    return p;
+}
 
 static constexpr float kBnEps = 1e-5f;
 
 // conv (OIHW) [+ BN] -> device [Cout][Kpad] (+ bias).  cin_pad >= cin (conv1: 3 -> 4).
 static int make_conv(relax_handle* h, const HostSD& sd, const std::string& conv, const std::string& bn, int cout,
                      int cin, int cin_pad, int k, int stride, int pad, ConvW* out, std::vector<void*>& allocs) {
-    const float* w = sd.get(h, conv + ".weight", (int64_t)cout * cin * k * k);
+    const float* w = sd_get(h, sd, conv + ".weight", (int64_t)cout * cin * k * k);
     if (!w) return RELAX_ERR_INVALID;
     std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
     if (!bn.empty()) {
-        const float* g = sd.get(h, bn + ".weight", cout);
-        const float* b = sd.get(h, bn + ".bias", cout);
-        const float* mu = sd.get(h, bn + ".running_mean", cout);
-        const float* var = sd.get(h, bn + ".running_var", cout);
-        if (!g || !b || !mu || !var) return RELAX_ERR_INVALID;
-        for (int o = 0; o < cout; ++o) {
-            scale[o] = g[o] / std::sqrt(var[o] + kBnEps);
-            shift[o] = b[o] - mu[o] * scale[o];
-        }
+        const float* g = sd_get(h, sd, bn + ".weight", cout);
+        const float* b = g ? sd_get(h, sd, bn + ".bias", cout) : nullptr;
+        const float* mu = b ? sd_get(h, sd, bn + ".running_mean", cout) : nullptr;
+        const float* var = mu ? sd_get(h, sd, bn + ".running_var", cout) : nullptr;
+        if (!var) return RELAX_ERR_INVALID;
+        host::fold_bn(g, b, mu, var, kBnEps, cout, scale.data(), shift.data());
     }
-    const int kreal = k * k * cin_pad;
-    const int kpad = ((kreal + 31) / 32) * 32;
-    std::vector<float> packed((size_t)cout * kpad, 0.f);
-    for (int o = 0; o < cout; ++o)
-        for (int c = 0; c < cin; ++c)
-            for (int dy = 0; dy < k; ++dy)
-                for (int dx = 0; dx < k; ++dx)
-                    packed[(size_t)o * kpad + (size_t)(dy * k + dx) * cin_pad + c] =
-                        w[(((size_t)o * cin + c) * k + dy) * k + dx] * scale[o];
+    const int kpad = host::conv_kpad(k, cin_pad);
+    std::vector<float> packed((size_t)cout * kpad);
+    host::pack_conv_oihw(w, scale.data(), cout, cin, cin_pad, k, kpad, packed.data());
     out->Cin = cin_pad; out->Cout = cout; out->KH = k; out->KW = k; out->stride = stride; out->pad = pad;
     out->Kpad = kpad;
     RELAX_TRY(upload(h, packed.data(), packed.size(), &out->w, allocs));
@@ -203,21 +188,18 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
     free_resnet(h);
     HostSD sd;
-    for (int i = 0; i < n; ++i) sd.t[names[i]] = {tensors[i], numels[i]};
+    for (int i = 0; i < n; ++i) sd.add(names[i], tensors[i], numels[i]);
     ResNet50W& rn = h->rn;
     int rc = make_conv(h, sd, "conv1", "", 64, 3, 4, 7, 2, 3, &rn.conv1, rn.allocs);
     if (rc != RELAX_OK) { free_resnet(h); return rc; }
     {
-        const float* g = sd.get(h, "bn1.weight", 64);
-        const float* b = sd.get(h, "bn1.bias", 64);
-        const float* mu = sd.get(h, "bn1.running_mean", 64);
-        const float* var = sd.get(h, "bn1.running_var", 64);
-        if (!g || !b || !mu || !var) { free_resnet(h); return RELAX_ERR_INVALID; }
+        const float* g = sd_get(h, sd, "bn1.weight", 64);
+        const float* b = g ? sd_get(h, sd, "bn1.bias", 64) : nullptr;
+        const float* mu = b ? sd_get(h, sd, "bn1.running_mean", 64) : nullptr;
+        const float* var = mu ? sd_get(h, sd, "bn1.running_var", 64) : nullptr;
+        if (!var) { free_resnet(h); return RELAX_ERR_INVALID; }
         std::vector<float> sc(64), sh(64);
-        for (int o = 0; o < 64; ++o) {
-            sc[o] = g[o] / std::sqrt(var[o] + kBnEps);
-            sh[o] = b[o] - mu[o] * sc[o];
-        }
+        host::fold_bn(g, b, mu, var, kBnEps, 64, sc.data(), sh.data());
         rc = upload(h, sc.data(), 64, &rn.bn1_scale, rn.allocs);
         if (rc == RELAX_OK) rc = upload(h, sh.data(), 64, &rn.bn1_shift, rn.allocs);
         if (rc != RELAX_OK) { free_resnet(h); return rc; }

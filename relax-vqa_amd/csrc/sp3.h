@@ -2,6 +2,11 @@
 // left (3 x 8 = 24 significant bits: the split is exact).  A row of K values is stored as K/16 chunks of 96 bytes,
 //        chunk = [16 x bf16 hi][16 x bf16 mid][16 x bf16 lo]
 // so that one 16-deep K step of one row is 96 contiguous bytes whose 16-byte units are MFMA fragments (gemm_x6.hip).
+// Range: exact for finite |x| <= 3.3895e38 (the largest bf16; beyond it the round-to-nearest of `hi` is +-inf and the value
+// becomes NaN - the 0.4 % of the fp32 range above it is not reachable by normalised pixels, LayerNorm outputs or trained
+// weights, and relax_set_option(h, "gemm_precision", 0) runs the exact-fp32 kernels for data that needs it); the `lo` plane of
+// values below 2^-110 is a bf16 subnormal (the product it would contribute is below 2^-133 of the operand scale).  NaN / inf
+// inputs stay NaN / inf (v_cvt_pk_bf16_f32 keeps them), as on the fp32 path.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

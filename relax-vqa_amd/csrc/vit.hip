@@ -8,6 +8,7 @@
 //   :234-239  final LayerNorm (eps 1e-6, :287-289), patch tokens x[:,1:]
 //   src/main_fragment_pool.py:124-133  mean / max / population-std over the 196 tokens
 #include "relax_internal.h"
+#include "host_logic.h"
 #include "sp3.h"
 
 namespace relax {
@@ -161,25 +162,20 @@ int relax_load_vit(relax_handle* h, const float* const* tensors, const char* con
     RELAX_REQUIRE(h, dim <= 768 && depth > 0, "relax_load_vit: dim=%d depth=%d unsupported", dim, depth);
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
     free_vit(h);
-    std::map<std::string, std::pair<const float*, int64_t>> sd;
-    for (int i = 0; i < n; ++i) sd[names[i]] = {tensors[i], numels[i]};
+    host::StateDict sd;
+    for (int i = 0; i < n; ++i) sd.add(names[i], tensors[i], numels[i]);
     VitW& v = h->vit;
     int rc = RELAX_OK;
     auto up = [&](const std::string& key, int64_t numel, float** dst) {
         if (rc != RELAX_OK) return;
-        auto it = sd.find(key);
-        if (it == sd.end()) {
-            set_error(h, "vit state dict: missing key '%s'", key.c_str());
+        std::string err;
+        const float* src = sd.get(key, numel, err, "vit state dict");
+        if (!src) {
+            set_error(h, "%s", err.c_str());
             rc = RELAX_ERR_INVALID;
             return;
         }
-        if (it->second.second != numel) {
-            set_error(h, "vit state dict: key '%s' has %lld elements, expected %lld", key.c_str(),
-                      (long long)it->second.second, (long long)numel);
-            rc = RELAX_ERR_INVALID;
-            return;
-        }
-        rc = upload(h, it->second.first, (size_t)numel, dst, v.allocs);
+        rc = upload(h, src, (size_t)numel, dst, v.allocs);
     };
     auto lin = [&](const std::string& p, int in, int out, LinearW* l) {
         l->in = in;

@@ -28,6 +28,26 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def barrier():
+    """dist.barrier(); under nccl (RCCL) the device is named so that the barrier's collective runs on this rank's GPU and not
+    on whichever device torch guesses (a warning today, a hang when the guess is another rank's GPU)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_backend() == "nccl" and torch.cuda.is_available():
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier()
+
+
+def gather_objects(obj, world, group=None):
+    """-> [obj of rank 0, ..., obj of rank world-1] on every rank (small python objects: the per-rank error lists)."""
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
 def _host_staged(t):
     """gloo has no device collectives for every op: stage CUDA tensors through host memory under that backend."""
     return t.is_cuda and dist.get_backend() == "gloo"

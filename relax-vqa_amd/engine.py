@@ -342,10 +342,14 @@ class RelaxEngine:
             self._check(rc, "relax_segment_mean")
         return out
 
-    def clip_vectors(self, clips, resnet=True, vit=True):
+    def clip_vectors(self, clips, resnet=True, vit=True, per_frame=False):
         """Several clips (list of uint8 [T,2,H,W,3] device tensors, any mix of resolutions) in ONE batched pass of
         both backbones -> fp32 [len(clips), F] per-clip mean vectors.  Bigger batches fill the 256 CUs better
-        (more tiles per launch, fewer partial rounds); results per clip do not depend on the batching."""
+        (more tiles per launch, fewer partial rounds).  A clip's row equals the row it gets alone to fp32 rounding; it is
+        bit-identical across batch compositions (and therefore across ranks of a sharded run) only with
+        set_option("gemm_split_k", 0): the default tail split cuts the last tiles of a GEMM along K by the batch size.
+        per_frame=True: -> (matrix, [fp32 [T_i, F] per clip]) - the per-frame rows the reference saves per video
+        (src/main_fragment_layerstack.py:345-354) next to their means."""
         counts = [int(c.shape[0]) for c in clips]
         n = sum(counts)
         both = torch.empty((2 * n, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device)   # [originals | residuals]
@@ -363,7 +367,20 @@ class RelaxEngine:
         if vit:
             _, pooled = self.vit_features(both, tokens=False, pooled=True)
             blocks += [(pooled, 0, col), (pooled, n, col + 3 * self.vit_dim)]
-        return self._segment_means(out, blocks, counts)
+        self._segment_means(out, blocks, counts)
+        if not per_frame:
+            return out
+        return out, self._per_frame_rows(blocks, counts)
+
+    @staticmethod
+    def _per_frame_rows(blocks, counts):
+        """blocks as for _segment_means -> per clip the [T, F] matrix of its frames (file output only: aten copies)."""
+        rows, at = [], 0
+        order = sorted(blocks, key=lambda b: b[2])
+        for t in counts:
+            rows.append(torch.cat([src[row0 + at:row0 + at + t] for src, row0, _ in order], dim=1))
+            at += t
+        return rows
 
     def whole_frame_features(self, frames):
         """frames uint8 [N,H,W,3] BGR (whole sampled frames) -> (ResNet-50 layer-stack fp32 [N,13120], ViT pooled
@@ -384,7 +401,8 @@ class RelaxEngine:
 
     def full_clip_vectors(self, clips, flow=True, flow_images=None, whole_frames=None):
         """Several clips -> fp32 [len(clips), 35203] in ONE batched pass of each backbone (3*T fragments / frames per
-        clip: original fragment, residual fragment, whole frame).  Same layout as full_clip_vector.
+        clip: original fragment, residual fragment, whole frame).  Same layout as full_clip_vector.  Batch-invariant to
+        fp32 rounding; bit for bit only with set_option("gemm_split_k", 0) (see clip_vectors).
         whole_frames: optional list of uint8 [Ts,H,W,3] per clip - ALL sampled frames (src/demo_test.py:76-87 averages the
         whole-frame features over every sampled frame, including a last one that has no `next` partner and therefore no
         pair); default: the first frame of every pair."""

@@ -15,12 +15,35 @@ log = logging.getLogger("relax_vqa_amd")
 _state = {"engine": None, "rn": False, "vit": None}
 
 
+_WRAPPER_KEYS = ("state_dict", "model", "teacher", "student")   # torch.save({"state_dict": ...}), DINO full checkpoints
+_KEY_PREFIXES = ("module.", "backbone.")                        # DataParallel / DINO's MultiCropWrapper
+
+
 def _load_file(path):
+    """A checkpoint file -> {torchvision / DINO key: fp32 array}.  The reference loads `models.resnet50(pretrained=True)`
+    (src/extractor/visualise_resnet.py:21) and the DINO hub file with `load_state_dict(strict=True)`
+    (src/extractor/visualise_vit_layer.py:326-328): plain state dicts.  Files saved around them are accepted too: one
+    level of {"state_dict" | "model" | "teacher" | "student": ...} wrapping and `module.` / `backbone.` key prefixes."""
     import torch
-    sd = torch.load(path, map_location="cpu")
-    if isinstance(sd, dict) and "state_dict" in sd:
-        sd = sd["state_dict"]
-    return {k: v.numpy() if hasattr(v, "numpy") else np.asarray(v) for k, v in sd.items()}
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    if not isinstance(sd, dict):
+        raise RuntimeError(f"{path}: expected a state dict, found {type(sd).__name__}")
+    for k in _WRAPPER_KEYS:
+        if isinstance(sd.get(k), dict):
+            sd = sd[k]
+            break
+    out = {}
+    for k, v in sd.items():
+        if not hasattr(v, "shape"):
+            continue                                     # epoch counters and the like
+        stripped = True
+        while stripped:
+            stripped = False
+            for p in _KEY_PREFIXES:
+                if k.startswith(p):
+                    k, stripped = k[len(p):], True
+        out[k] = v.numpy() if hasattr(v, "numpy") else np.asarray(v)
+    return out
 
 
 def get_engine(device=None):
@@ -73,6 +96,12 @@ def set_weights(resnet50=None, vit=None, vit_name="vit_base"):
         eng.load_vit(vit, vit_name)
         _state["vit"] = vit_name
     return eng
+
+
+def reset_weights():
+    """Forget which weights are loaded: the next ensure_resnet50() / ensure_vit() reads RELAX_*_WEIGHTS again."""
+    _state["rn"] = False
+    _state["vit"] = None
 
 
 def read_image_bgr(image_path):

@@ -56,6 +56,18 @@ def each_precision(request):
     return request.param
 
 
+@pytest.fixture(params=[1, 0], ids=["tail_split_on", "tail_split_off"])
+def each_split_k(request):
+    """Backbone parity on BOTH finishing paths of the contraction kernel: with the tail split on (default) small GEMMs are cut
+    along K and finished by splitk_finish_x6; with it off EVERY tile - also at 1-8 images - runs the in-kernel epilogue of an
+    unsplit tile, which is the path the bench batch spends its time in (csrc/gemm_x6.hip)."""
+    from tests.gpu_common import engine
+    eng = engine()
+    eng.set_option("gemm_split_k", request.param)
+    yield request.param
+    eng.set_option("gemm_split_k", 1)
+
+
 class _PoisonedTorch:
     """RELAX_TEST_POISON_OUT=1: the engine's output tensors (torch.empty in relax-vqa_amd/engine.py) start as 0xFF bytes (NaN / -1 /
     255) instead of whatever the caching allocator hands back - an entry point that leaves part of an output unwritten then fails

@@ -1,0 +1,144 @@
+"""The dataset driver (relax-vqa_amd/dataset.py: BASELINE config 4 as written) on CPU with a stand-in engine: sharding, batching,
+per-frame files + resume, the NaN-row failure contract and the all-gather, at world size 1 and 2 (gloo).  The stand-in computes
+per-frame rows from the clip's bytes, so any mix-up of clips, rows or ranks changes values."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.io
+import torch
+import torch.multiprocessing as mp
+
+import relax_vqa_amd  # noqa: F401
+from relax_vqa_amd import dataset, sampling
+
+F = 11
+
+
+class FakeEngine:
+    """clip_vectors(list of clips) -> [len, F] means of per-frame rows; raises on a 'poisoned' clip (first byte 255) the way a
+    failing engine call would take a whole batch down."""
+    device = torch.device("cpu")
+    vit_dim = None
+
+    def __init__(self):
+        self.batches = []
+
+    @staticmethod
+    def _rows(clip):
+        c = torch.as_tensor(np.asarray(clip)).to(torch.float64)
+        base = c.reshape(c.shape[0], -1).mean(dim=1, keepdim=True)
+        return (base * torch.arange(1, F + 1, dtype=torch.float64)).to(torch.float32)
+
+    def clip_vectors(self, clips, resnet=True, vit=True, per_frame=False):
+        self.batches.append(len(clips))
+        for c in clips:
+            if int(np.asarray(c).reshape(-1)[0]) == 255:
+                raise RuntimeError("relax_fragment_pairs failed (-2): injected fault")
+        rows = [self._rows(c) for c in clips]
+        out = torch.stack([r.mean(dim=0) for r in rows])
+        return (out, rows) if per_frame else out
+
+
+def _clip(i):
+    if i == 3:
+        raise OSError(f"cannot decode video_{i + 1}.mp4")
+    g = np.random.default_rng(i)
+    t = 1 + i % 4                                            # ragged: 1..4 pairs
+    c = g.integers(0, 255, (t, 2, 16 + 16 * (i % 2), 32, 3), dtype=np.uint8)
+    if i == 5:
+        c.reshape(-1)[0] = 255                               # the engine itself fails on this one
+    if i == 6:
+        return c[:, :1]                                      # malformed: no `next` frame
+    return c
+
+
+def _want(n):
+    want = np.full((n, F), np.nan, dtype=np.float32)
+    for i in range(n):
+        if i in (3, 5, 6):
+            continue
+        want[i] = FakeEngine._rows(_clip(i)).mean(dim=0).numpy()
+    return want
+
+
+def _patched(monkeypatch_dim=None):
+    dataset.feature_dim = lambda engine, resnet=True, vit=True, full=False: F   # the stand-in's width
+
+
+def test_single_rank_ragged_clips_failures_files_and_resume(tmp_path):
+    _patched()
+    eng = FakeEngine()
+    n = 10
+    out_dir = str(tmp_path / "feats")
+    mat = str(tmp_path / "m" / "konvid.mat")
+    matrix, errors = dataset.extract_dataset_clips(_clip, n, eng, clips_per_step=4, out_dir=out_dir, network_name="resnet50",
+                                                   mat_path=mat, data_name="konvid_1k", rank=0, world=1)
+    want = _want(n)
+    assert np.array_equal(matrix.numpy(), want, equal_nan=True)
+    assert [i for i, _ in errors] == [3, 5, 6]
+    assert "cannot decode" in errors[0][1] and "injected fault" in errors[1][1] and "[T,2,H,W,3]" in errors[2][1]
+    # the batch that held the poisoned clip was retried clip by clip: its healthy neighbours kept their rows
+    assert not np.isnan(want[4]).any() and np.array_equal(matrix[4].numpy(), want[4])
+    # per-frame files under the reference's names, means of the files == rows (extract_npy2mat.py:121-126)
+    for i in range(n):
+        path = os.path.join(out_dir, sampling.feature_file_name(i, "resnet50"))
+        assert os.path.exists(path) == (i not in (3, 5, 6))
+        if i not in (3, 5, 6):
+            rows = np.load(path)
+            assert rows.shape == (1 + i % 4, F) and np.allclose(rows.mean(axis=0), want[i])
+    m = scipy.io.loadmat(mat)["konvid_1k"]
+    assert m.shape == (n, F) and m.dtype == np.float64 and np.array_equal(m, want.astype(np.float64), equal_nan=True)
+    # resume: nothing healthy is recomputed, the failures are tried again
+    eng2 = FakeEngine()
+    again, errors2 = dataset.extract_dataset_clips(_clip, n, eng2, clips_per_step=4, out_dir=out_dir, skip_existing=True,
+                                                   rank=0, world=1)
+    assert sum(eng2.batches) == 1 and [i for i, _ in errors2] == [3, 5, 6]      # only clip 5 reaches the engine (and fails)
+    assert np.allclose(again.numpy(), want, equal_nan=True)
+
+
+def test_sequence_input_and_empty_shards():
+    _patched()
+    clips = [_clip(i) for i in (0, 1)]
+    m, e = dataset.extract_dataset_clips(clips, 2, FakeEngine(), rank=0, world=1)
+    assert m.shape == (2, F) and not e
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import relax_vqa_amd  # noqa: F401
+    from relax_vqa_amd import dataset as ds
+    from relax_vqa_amd import distributed as rd
+    rd.init_from_env(backend="gloo")
+    ds.feature_dim = lambda engine, resnet=True, vit=True, full=False: F
+    eng = FakeEngine()
+    matrix, errors = ds.extract_dataset_clips(_clip, n, eng, clips_per_step=2)        # rank / world from the process group
+    q.put((rank, matrix.numpy().copy(), errors, sum(eng.batches)))
+    rd.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1, 9])
+def test_two_ranks_equal_one_rank_bit_for_bit(n):
+    """n = 1: rank 1's shard is empty and the run still completes (a dataset smaller than the node must not hang the gather)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _want(n)
+    for rank, matrix, errors, _ in results:
+        assert np.array_equal(matrix, want, equal_nan=True), f"rank {rank}"
+        assert [i for i, _ in errors] == [i for i in (3, 5, 6) if i < n]              # every rank holds the whole error list

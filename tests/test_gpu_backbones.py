@@ -22,7 +22,7 @@ def _fragments(n, seed=0):
 
 
 @pytest.mark.parametrize("adversarial", [False, True])
-def test_resnet50_taps_and_features(each_precision, adversarial):
+def test_resnet50_taps_and_features(each_precision, each_split_k, adversarial):
     """Every hooked activation and both feature vectors, on the regular synthetic weights and on the adversarial set (BatchNorm
     variances over 1e-3..10, gammas of mixed sign), on both arithmetics."""
     sd = rn50_weights(adversarial)
@@ -70,7 +70,7 @@ def test_resnet50_pool_only_and_batch_independence(each_precision):
 
 @pytest.mark.parametrize("adversarial", [False, True])
 @pytest.mark.parametrize("name,heads", [("vit_tiny", 3), ("vit_base", 12)])
-def test_vit_matches_reference_golden_tokens(golden_dir, name, heads, each_precision, adversarial):
+def test_vit_matches_reference_golden_tokens(golden_dir, name, heads, each_precision, each_split_k, adversarial):
     """Tokens computed by the reference's own VisionTransformer class; the adversarial weights drive the attention kernel's
     max subtraction / exp2 path with logits of +-20 (near one-hot softmax rows)."""
     vit_weights(name, adversarial)
@@ -81,7 +81,7 @@ def test_vit_matches_reference_golden_tokens(golden_dir, name, heads, each_preci
     assert_close(pooled, want, f"{name} pooled vs reference process_video_feature")
 
 
-def test_vit_base_oracle_batch(each_precision):
+def test_vit_base_oracle_batch(each_precision, each_split_k):
     sd = vit_weights("vit_base")
     frags = _fragments(3, seed=2)
     tokens, pooled = engine().vit_features(torch.from_numpy(frags).cuda(), tokens=True, pooled=True)

@@ -66,7 +66,7 @@ def test_config5_two_clips_of_32_pairs_deterministic_and_batch_invariant():
     assert_close(split, both.cpu().numpy(), "tail split-K on vs off at config 5", rtol=1e-4, atol_frac=1e-5)
 
 
-def test_config5_every_block_of_the_35203_vector_against_the_oracle(each_precision):
+def test_config5_every_block_of_the_35203_vector_against_the_oracle(each_precision, each_split_k):
     """One 2160p pair, block by block against the oracle: whole-frame RN50 layer stack | whole-frame ViT | fragment layer stack
     | residual(+flow) pool | ViT of both fragments.  The flow images come from the GPU (checked against the oracle above) and
     go to both sides, so the comparison does not hinge on a near-tie between two flow patches."""

@@ -1,0 +1,121 @@
+"""BASELINE config 4 as written, on the GPU: the dataset driver (relax-vqa_amd/dataset.py) over the real engine - ragged clips,
+the NaN-row failure contract, per-frame files - and the strong-scaling bench mode with two ranks sharing the box's one GPU.
+Reference: the per-video loop src/main_fragment_layerstack.py:269-361 and src/data_processing/extract_npy2mat.py:117-130."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from relax_vqa_amd import dataset, sampling
+from tests.gpu_common import assert_close, engine, rn50_weights, synth, vit_weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clips():
+    shapes = [(3, 240, 320), (1, 272, 400), (4, 240, 320), (2, 540, 960), (2, 256, 256)]
+    return [synth.synthetic_clip(t, h, w, clip_id=600 + i) for i, (t, h, w) in enumerate(shapes)]
+
+
+def test_dataset_rows_equal_clip_vector_and_a_bad_clip_is_a_nan_row(tmp_path):
+    rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    good = _clips()
+
+    def source(i):
+        if i == 2:
+            raise OSError("video_3.mp4: moov atom not found")
+        if i == 4:
+            return good[4].astype(np.float32)               # wrong dtype: rejected before it can poison a batch
+        return torch.from_numpy(good[i]).cuda() if i % 2 else good[i]      # device tensors and host arrays both
+
+    out_dir = str(tmp_path / "features")
+    eng.set_option("gemm_split_k", 0)                        # bits independent of the batch composition
+    try:
+        matrix, errors = dataset.extract_dataset_clips(source, 5, eng, clips_per_step=3, out_dir=out_dir, network_name="resnet50",
+                                                       rank=0, world=1)
+        assert matrix.shape == (5, 19779) and matrix.device.type == "cuda"
+        assert [i for i, _ in errors] == [2, 4] and "moov atom" in errors[0][1] and "uint8" in errors[1][1]
+        assert bool(torch.isnan(matrix[[2, 4]]).all())
+        for i in (0, 1, 3):
+            frames = torch.from_numpy(good[i]).cuda()
+            assert torch.equal(matrix[i], eng.clip_vector(frames)), f"row {i} differs from the clip processed alone"
+            rows = np.load(os.path.join(out_dir, sampling.feature_file_name(i, "resnet50")))
+            f = eng.extract_clip(frames)
+            want = torch.cat([f["resnet"], f["vit"]], dim=1).cpu().numpy()
+            assert rows.shape == want.shape and np.array_equal(rows, want), f"per-frame file of clip {i}"
+        assert not os.path.exists(os.path.join(out_dir, sampling.feature_file_name(2, "resnet50")))
+        # resume from the files: nothing healthy goes through the engine again, same matrix to fp32 rounding of the host mean
+        calls = []
+        orig = eng.clip_vectors
+        eng.clip_vectors = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            again, errors2 = dataset.extract_dataset_clips(source, 5, eng, clips_per_step=3, out_dir=out_dir, skip_existing=True,
+                                                           rank=0, world=1)
+        finally:
+            del eng.clip_vectors
+        assert not calls and [i for i, _ in errors2] == [2, 4]
+        ok = [0, 1, 3]
+        assert_close(again[ok], matrix[ok].cpu().numpy(), "resumed rows", rtol=1e-5, atol_frac=1e-6)
+    finally:
+        eng.set_option("gemm_split_k", 1)
+
+
+def test_dataset_full_vectors_and_the_quality_head_on_a_matrix_with_a_failed_clip():
+    """full=True gives the 35203-d rows; the NaN row of a failed clip goes through relax_mlp_head's imputer and comes out as the
+    score of the training means - a number, as in the reference (src/model_regression.py:123-126 zeroes NaN / inf)."""
+    rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    good = _clips()
+    src = lambda i: None if i == 1 else good[i]            # noqa: E731  (None: "not an array")
+    matrix, errors = dataset.extract_dataset_clips(src, 3, eng, clips_per_step=2, full=True, rank=0, world=1)
+    assert matrix.shape == (3, 35203) and [i for i, _ in errors] == [1]
+    assert bool(torch.isfinite(matrix[[0, 2]]).all()) and bool(torch.isnan(matrix[1]).all())
+    assert_close(matrix[0], eng.full_clip_vector(torch.from_numpy(good[0]).cuda(), flow=True).cpu().numpy(), "full row 0",
+                 rtol=1e-4, atol_frac=1e-5)
+    g = np.random.default_rng(5)
+    eng.load_mlp_head(synth.mlp_head_state_dict(), scaler_scale=g.uniform(0.5, 2.0, 35203), scaler_min=g.uniform(-1, 1, 35203),
+                      imputer_statistics=g.standard_normal(35203))
+    scores = eng.mlp_head(matrix)
+    assert scores.shape == (3,) and bool(torch.isfinite(scores).all())
+
+
+def _bench_dataset(n_ranks, dump, extra_env=None):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--workload", "config4", "--dataset-clips", "7",
+            "--clips-per-step", "2", "--warmup", "1", "--gemm-split-k", "0", "--resident-clips", "3", "--dump-matrix", dump]
+    if n_ranks > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_dataset_mode_two_ranks_on_one_gpu_equal_one_rank_bit_for_bit(tmp_path):
+    """`bench.py --dataset-clips` (strong scaling): 7 config-4 clips over 1 rank and over 2 ranks that share this box's GPU
+    (gloo, host-staged all-gather - RCCL refuses duplicate devices; on an 8-GPU node the same code takes the nccl branch).  With
+    the tail split off a clip's bits do not depend on its batch, so the two [7, 19779] matrices must be identical."""
+    one = _bench_dataset(1, str(tmp_path / "one.npy"))
+    two = _bench_dataset(2, str(tmp_path / "two.npy"), {"RELAX_DIST_BACKEND": "gloo"})
+    for rec, n in ((one, 1), (two, 2)):
+        assert rec["scaling"] == "strong" and rec["n_gpus"] == n and rec["rccl_ranks"] == n and rec["value"] > 0
+        assert rec["config"]["dataset_clips"] == 7 and rec["errors"] == 0 and rec["all_gather_ms"] >= 0
+    a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
+    assert a.shape == (7, 19779) and np.isfinite(a).all()
+    assert np.array_equal(a, b), "sharding over two ranks changed the matrix"
+    assert not np.array_equal(a[0], a[1]) and np.array_equal(a[0], a[3])      # 3 distinct clips, clip i = resident[i % 3]

@@ -227,6 +227,39 @@ def test_conv2d_nhwc_under_x6(Nimg, H, Cin, Cout, k, stride, pad):
     assert e6.mean().item() <= 1.05 * e32.mean().item() + 1e-12 and e6.max().item() <= 1.5 * e32.max().item() + 1e-12
 
 
+@pytest.mark.parametrize("Nimg,H,Cin,Cout,k,stride,pad", [(2, 28, 32, 64, 7, 2, 3),      # 49 taps: beyond the kernel's 32-tap mask
+                                                          (2, 20, 8, 64, 3, 1, 1),       # Cin = 8: no 16-channel chunk
+                                                          (2, 14, 64, 64, 1, 1, 0)])     # (control: this one IS a bf16x6 shape)
+def test_conv_geometries_outside_the_x6_kernel_fall_back_to_the_fp32_kernel(Nimg, H, Cin, Cout, k, stride, pad):
+    """Round-2 advice: under the default arithmetic relax_op_conv2d_nhwc must keep accepting what the fp32 kernel accepted
+    (e.g. a 7x7 filter with Cin % 32 == 0) instead of failing with 'more than 32 taps'."""
+    eng = engine()
+    assert eng.precision() == "bf16x6"
+    x = _rand(Nimg, Cin, H, H, seed=17)
+    w = _rand(Cout, Cin, k, k, seed=18, scale=(Cin * k * k) ** -0.5)
+    ref = F.conv2d(x.double(), w.double(), None, stride=stride, padding=pad).float().numpy()
+    got = eng.op_conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda(), torch.from_numpy(pack_conv_weight(w.numpy())).cuda(), None, None,
+                             Cout, k, k, stride, pad, act=0).permute(0, 3, 1, 2)
+    assert_close(got, ref, f"conv {Cin}->{Cout} k{k} under the default precision")
+
+
+def test_misaligned_operands_are_refused_not_faulted():
+    """Round-2 advice: the bf16x6 launcher reads and writes 16-byte units; a view that starts 4 bytes into a buffer must come back
+    as RELAX_ERR_INVALID, not as a GPU fault."""
+    eng = engine()
+    A, W = _rand(64, 64, seed=1).cuda(), _rand(64, 64, seed=2).cuda()
+    flat = torch.zeros(64 * 64 + 4, device="cuda")
+    skew = flat[1:1 + 64 * 64].view(64, 64)                       # 4-byte offset
+    assert skew.data_ptr() % 16 == 4
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        eng.op_gemm(A, W, out=skew)
+    bias = torch.zeros(65, device="cuda")[1:]
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        eng.op_gemm(A, W, bias=bias)
+    torch.cuda.synchronize()
+    assert_close(eng.op_gemm(A, W), (A.double() @ W.double().T).float().cpu().numpy(), "the handle still works")
+
+
 def test_resnet50_every_tap_under_x6_and_error_against_fp64():
     """All 15 hooked activations + the 13120 / 2051 features on the bf16x6 path: inside the 1e-3 bar against the fp32 oracle;
     and against an fp64 run of the oracle, beside the two fp32 implementations at hand: this library's exact-fp32 MFMA path (an

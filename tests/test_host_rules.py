@@ -55,3 +55,29 @@ def test_process_wide_engine_follows_local_rank(monkeypatch):
     runtime.get_engine()
     assert seen["device"] == 5
     monkeypatch.setitem(runtime._state, "engine", None)
+
+
+def test_checkpoint_file_forms_unwrap_to_the_same_state_dict(tmp_path):
+    """runtime._load_file: plain state dict, {"state_dict": ...}, DINO's {"teacher": {"backbone.*"}}, DataParallel's module.* -
+    all give the plain torchvision / DINO keys (src/extractor/visualise_resnet.py:21, visualise_vit_layer.py:326-328)."""
+    import numpy as np
+    import torch
+    from relax_vqa_amd import runtime
+    sd = {"conv1.weight": torch.randn(4, 3, 2, 2), "bn1.running_var": torch.rand(4), "bn1.num_batches_tracked": torch.tensor(3)}
+    forms = {
+        "plain.pth": sd,
+        "wrapped.pth": {"state_dict": sd, "epoch": 12},
+        "module.pth": {"module." + k: v for k, v in sd.items()},
+        "dino.pth": {"teacher": {"backbone." + k: v for k, v in sd.items()}, "student": {"module.backbone.x": torch.zeros(1)}},
+        "both.pth": {"model": {"module.backbone." + k: v for k, v in sd.items()}},
+    }
+    for name, obj in forms.items():
+        path = str(tmp_path / name)
+        torch.save(obj, path)
+        got = runtime._load_file(path)
+        assert set(got) == set(sd), name
+        for k in sd:
+            assert np.array_equal(got[k], sd[k].numpy()), (name, k)
+    torch.save([1, 2, 3], str(tmp_path / "list.pth"))
+    with pytest.raises(RuntimeError, match="expected a state dict"):
+        runtime._load_file(str(tmp_path / "list.pth"))

@@ -4,7 +4,8 @@
 #   tools/build_ablations.sh f32:<n>        fp32 loop ablations (-DRELAX_F32_ABLATE=n, WRONG results)
 #   tools/build_ablations.sh stamps         fp32 / bf16x3 kernel with per-phase timestamps
 #   tools/build_ablations.sh x6stamps       bf16x6 kernel with per-phase cycle stamps (prints per launch, syncs)
-#   tools/build_ablations.sh x6:<n>         bf16x6 ablations (-DRELAX_X6_ABLATE=n, WRONG results)
+#   (the bf16x6 loop ablations of round 2 - RELAX_X6_ABLATE - were deleted from gemm_x6.hip in round 3 together with the other
+#    experiment branches; their measurements are in DESIGN.md section 3.2 and the code is in the history: commit a51794b)
 #   tools/build_ablations.sh att_stamps     attention kernel with per-phase cycle shares
 # use: RELAX_HIP_LIB=tools/abl/librelax_<name>.so python tools/gemm_bench.py ...
 set -e
@@ -12,7 +13,7 @@ cd "$(dirname "$0")/../relax-vqa_amd/csrc"
 make -s
 mkdir -p ../../tools/abl
 CC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-function"
-OBJS="api.o fragment.o flow.o resize.o gemm.o gemm_x6.o attention_x6.o layers.o resnet50.o vit.o head.o"
+OBJS="api.o fragment.o flow.o resize.o gemm.o gemm_x6.o conv1_x6.o attention_x6.o layers.o resnet50.o vit.o head.o host_logic.o"
 link() {  # link <replaced object> <new object> <output name>
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 ${OBJS/$1/$2} -o ../../tools/abl/librelax_$3.so
 }
@@ -20,8 +21,6 @@ for n in "$@"; do
   case "$n" in
     stamps) $CC -DRELAX_GEMM_STAMPS -c gemm.hip -o /tmp/gemm_stamps.o; link gemm.o /tmp/gemm_stamps.o stamps ;;
     x6stamps) $CC -DRELAX_X6_STAMPS -c gemm_x6.hip -o /tmp/gemm_x6_stamps.o; link gemm_x6.o /tmp/gemm_x6_stamps.o x6stamps ;;
-    x6stamps:*) $CC -DRELAX_X6_STAMPS -DRELAX_X6_ABLATE=${n#x6stamps:} -c gemm_x6.hip -o /tmp/gemm_x6_stamps.o; link gemm_x6.o /tmp/gemm_x6_stamps.o x6stamps${n#x6stamps:} ;;
-    x6:*) $CC -DRELAX_X6_ABLATE=${n#x6:} -c gemm_x6.hip -o /tmp/gemm_x6_abl.o; link gemm_x6.o /tmp/gemm_x6_abl.o x6abl${n#x6:} ;;
     f32:*) $CC -DRELAX_F32_ABLATE=${n#f32:} -c gemm.hip -o /tmp/gemm_f32abl.o; link gemm.o /tmp/gemm_f32abl.o f32abl${n#f32:} ;;
     att_stamps) $CC -DRELAX_ATT_STAMPS=0 -c layers.hip -o /tmp/layers_stamps.o; link layers.o /tmp/layers_stamps.o att_stamps ;;
     *) $CC -DRELAX_X3_ABLATE=$n -c gemm.hip -o /tmp/gemm_abl$n.o; link gemm.o /tmp/gemm_abl$n.o abl$n ;;
