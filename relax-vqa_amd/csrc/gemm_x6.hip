@@ -48,6 +48,7 @@ namespace relax {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -118,7 +119,7 @@ constexpr int64_t kMaxRecords = 0x7ffffff0;
 // (the loop body is rotated: one "region" = barrier .. next barrier = M1(k) + M0(k+1) is one basic block, which the compiler's
 // scheduler interleaves better than any order pinned by hand)
 // X = the operand with fewer fragments per wave (double-buffered in registers), Y = the other one (two halves).
-template <int BM, int BN, int WM, int WN, bool TAPS>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (it has no __amdgpu_buffer_rsrc_t and emits no stub for a body that names it)
     constexpr int NW = WM * WN;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int A_PPW = A_PIECES / NW;
     constexpr int DUMMY = 2 * STAGE;              // 1 KiB nobody reads
     static_assert(ROWS % 32 == 0 && TM >= 1 && TN >= 1 && YT % 2 == 0 && A_PIECES % NW == 0, "tile / wave layout mismatch");
+    static_assert(!M16 || (TM == 4 && TN == 2 && PPW <= 7), "the 16x16x32 loop is written for 128 x 64 per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         const int u = piece * 64 + lane;
         const int trow = u / 6;
         const int c = u - trow * 6;
-        const int unit_off = (c >> 1) * 32 + (((c & 1) ^ ((trow >> 3) & 1)) << 4);
+        const int unit_off = (c >> 1) * 32 + (((c & 1) ^ (M16 ? 0 : ((trow >> 3) & 1))) << 4);   // (M16: linear image, see below)
         if (j < A_PPW) {
             const int m = m0 + trow;
             a_taps[j] = 0u;
@@ -249,25 +251,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         d_dx = d_tap - d_dy * p.KW;
     }
 
-#define X6_ISSUE(st_)                                                                                                   \
+#define X6_ISSUE_PIECE(st_, j_)                                                                                         \
     {                                                                                                                   \
         const int lin_ = (TAPS ? d_tap * cin_chunks + d_cc : d_kt) * kChunkBytes;                                       \
         const int tapoff_ = TAPS ? (d_dy * p.W + d_dx) * (int)pix_bytes + d_cc * kChunkBytes : 0;                        \
-        _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                                               \
-            const int piece_ = wave + NW * j;                                                                           \
-            const int dst_ = piece_ < PIECES ? (st_) * STAGE + piece_ * 1024 : DUMMY;                                   \
-            if (j < A_PPW) {                                                                                            \
-                if (TAPS) {                                                                                             \
-                    const int jj_ = j < A_PPW ? j : 0;                                                                  \
-                    const bool ok_ = (a_taps[jj_] >> d_tap) & 1u;                                                         \
-                    X6_DMA(rsrc_a, dst_, ok_ ? voff[j] + (unsigned)tapoff_ : kOutOfRange, 0);                            \
-                } else {                                                                                                \
-                    X6_DMA(rsrc_a, dst_, voff[j], lin_);                                                                \
-                }                                                                                                       \
+        const int piece_ = wave + NW * (j_);                                                                            \
+        const int dst_ = piece_ < PIECES ? (st_) * STAGE + piece_ * 1024 : DUMMY;                                       \
+        if ((j_) < A_PPW) {                                                                                             \
+            if (TAPS) {                                                                                                 \
+                const int jj_ = (j_) < A_PPW ? (j_) : 0;                                                                \
+                const bool ok_ = (a_taps[jj_] >> d_tap) & 1u;                                                           \
+                X6_DMA(rsrc_a, dst_, ok_ ? voff[j_] + (unsigned)tapoff_ : kOutOfRange, 0);                              \
             } else {                                                                                                    \
-                X6_DMA(rsrc_w, dst_, voff[j], lin_);                                                                    \
+                X6_DMA(rsrc_a, dst_, voff[j_], lin_);                                                                   \
             }                                                                                                           \
+        } else {                                                                                                        \
+            X6_DMA(rsrc_w, dst_, voff[j_], lin_);                                                                       \
         }                                                                                                               \
+    }
+#define X6_ISSUE_ADVANCE()                                                                                              \
+    {                                                                                                                   \
         ++d_kt;                                                                                                         \
         if (TAPS) {                                                                                                     \
             ++d_tap;                                                                                                    \
@@ -281,8 +284,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             d_cc += wt_ ? 1 : 0;                                                                                        \
         }                                                                                                               \
     }
+#define X6_ISSUE(st_)                                                                                                   \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j) X6_ISSUE_PIECE(st_, j);                                         \
+        X6_ISSUE_ADVANCE();                                                                                             \
+    }
 
     floatx16 acc[TM][TN];
+    floatx4 acc16[M16 ? 8 : 1][4];   // M16: 16-row A fragments x 16-column B fragments of the wave's 128 x 64
+#pragma unroll
+    for (int i = 0; i < (M16 ? 8 : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -343,12 +358,98 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         }                                                                                                               \
     }
 
+    // ---- the same loop on v_mfma_f32_16x16x32_bf16 (M16).  The 32-deep K of that instruction takes TWO planes of a 16-deep
+    // chunk: lanes with k group g = lane >> 4 < 2 read the halves of the first plane of a pair, g >= 2 those of the second, so
+    //     A[lo|hi] B[hi|lo] = al bh + ah bl,   A[mid|hi] B[hi|mid] = am bh + ah bm,   A[hi|mid] B[hi|mid] = ah bh + am bm
+    // are the six partial products in three instructions per 16 x 16 outputs (same FLOPs, same order smallest first; measured
+    // error against fp64 equal to the 32x32x16 form: tools/micro/mfma_shape.hip).  The chip holds a higher clock on this shape
+    // on real data: the K loop takes 3.8 - 4.3 k cycles per step here against 3.55 k on the 32x32x16 loop and still finishes a
+    // ViT pass 2.7 % sooner (profiles/r03_mfma_shape.txt).  B (2 forms x 4 fragments) is double-buffered in registers across steps, A (3 forms) streams one 16-row
+    // fragment at a time, two buffers.  The LDS image is linear here (no half swap: these reads are conflict-free on it).
+    const int r16 = lane & 15, g16 = lane >> 4, second16 = g16 >> 1;
+    const int rowoff16 = r16 * kChunkBytes + ((g16 & 1) << 4);
+    const int a16 = (wm * TM * 32) * kChunkBytes + rowoff16;
+    const int b16 = (BM + wn * TN * 32) * kChunkBytes + rowoff16;
+    const int a_hm = a16 + (second16 ? 32 : 0), a_mh = a16 + (second16 ? 0 : 32), a_lh = a16 + (second16 ? 0 : 64);
+    const int b_hm = b16 + (second16 ? 32 : 0), b_hl = b16 + (second16 ? 64 : 0);
+    bf16x8 xb[2][4][2], ya[2][3];
+#define X6_READ_XB(set_, sp_)                                                                                           \
+    _Pragma("unroll") for (int y = 0; y < 4; ++y) {                                                                     \
+        xb[set_][y][0] = *reinterpret_cast<const bf16x8*>((sp_) + b_hm + y * 16 * kChunkBytes);                         \
+        xb[set_][y][1] = *reinterpret_cast<const bf16x8*>((sp_) + b_hl + y * 16 * kChunkBytes);                         \
+    }
+#define X6_READ_A16(buf_, e_, sp_)                                                                                      \
+    {                                                                                                                   \
+        ya[buf_][0] = *reinterpret_cast<const bf16x8*>((sp_) + a_hm + (e_) * 16 * kChunkBytes);                         \
+        ya[buf_][1] = *reinterpret_cast<const bf16x8*>((sp_) + a_mh + (e_) * 16 * kChunkBytes);                         \
+        ya[buf_][2] = *reinterpret_cast<const bf16x8*>((sp_) + a_lh + (e_) * 16 * kChunkBytes);                         \
+        __builtin_amdgcn_sched_barrier(0);   /* issued HERE, a whole MFMA group ahead of their use */                  \
+    }
+#define X6_MFMAS16(set_, buf_, e_)                                                                                      \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                                   \
+            acc16[e_][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya[buf_][2], xb[set_][y][1], acc16[e_][y], 0, 0, 0); \
+        _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                                   \
+            acc16[e_][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya[buf_][1], xb[set_][y][0], acc16[e_][y], 0, 0, 0); \
+        _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                                   \
+            acc16[e_][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya[buf_][0], xb[set_][y][0], acc16[e_][y], 0, 0, 0); \
+        /* nothing moves across: left alone, the scheduler regroups the loop by form (one read, four MFMAs, wait, ...) to save */ \
+        /* registers and exposes the LDS latency every 64 cycles */                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }
+    // region: [wait, barrier, DMA of step k+2, B forms and A fragment 0 of step k+1, fragment 7 of step k, then fragments 0..6 of
+    // step k+1 each behind the read of the next one]
+#define X6_REGION16(xs_, has_next_, has_d_)                                                                             \
+    {                                                                                                                   \
+        const char* sn_ = smem + ((xs_) ^ 1) * STAGE;                                                                   \
+        if (has_next_) {                                                                                                \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+            __builtin_amdgcn_s_barrier();                                                                               \
+            X6_READ_XB((xs_) ^ 1, sn_);                                                                                 \
+            X6_READ_A16(0, 0, sn_);                                                                                     \
+            /* the DMA of step k+2 into the stage just freed, in the first two MFMA groups of the region: the issue */ \
+            /* cost of a piece hides under the group's MFMAs (all six right behind the barrier stall both waves of */  \
+            /* a SIMD: this MFMA shape leaves 8 of every 16 cycles for other instructions, the 32x32x16 one 24 of  */  \
+            /* 32), and every piece has most of a step to land                                                      */  \
+            if (has_d_) { _Pragma("unroll") for (int j = 0; j < (PPW + 1) / 2; ++j) X6_ISSUE_PIECE(xs_, j); }           \
+        }                                                                                                               \
+        X6_MFMAS16(xs_, 1, 7);                                                                                          \
+        if (has_next_) {                                                                                                \
+            _Pragma("unroll") for (int e = 0; e < 7; ++e) {                                                             \
+                X6_READ_A16((e + 1) & 1, e + 1, sn_);                                                                   \
+                if (has_d_ && e == 0) { _Pragma("unroll") for (int j = (PPW + 1) / 2; j < PPW; ++j) X6_ISSUE_PIECE(xs_, j); } \
+                X6_MFMAS16((xs_) ^ 1, e & 1, e);                                                                        \
+            }                                                                                                           \
+            if (has_d_) X6_ISSUE_ADVANCE();                                                                             \
+        }                                                                                                               \
+    }
+
     const int nk = kt_end - kt_begin;
     X6_ISSUE(0);
     if (nk > 1) X6_ISSUE(1);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (M16) {
+        X6_READ_XB(0, smem);
+        X6_READ_A16(0, 0, smem);
+        X6_STAMP(1);
+#pragma unroll
+        for (int e = 0; e < 7; ++e) {
+            X6_READ_A16((e + 1) & 1, e + 1, smem);
+            X6_MFMAS16(0, e & 1, e);
+        }
+        // region k: xs = k & 1 (register set of B = LDS stage); has_next = step k+1 exists; has_d = step k+2 exists
+        int k = 0;
+        for (; k + 3 < nk; k += 2) {
+            X6_REGION16(0, true, true);
+            X6_REGION16(1, true, true);
+        }
+        for (; k < nk; k += 2) {
+            X6_REGION16(0, k + 1 < nk, k + 2 < nk);
+            if (k + 1 < nk) X6_REGION16(1, k + 2 < nk, k + 3 < nk);
+        }
+    } else {
     X6_READ_X(0, smem);
     X6_READ_Y(yf0, 0, smem);
     X6_STAMP(1);
@@ -365,11 +466,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         X6_REGION(0, k + 1 < nk, k + 2 < nk);
         if (k + 1 < nk) X6_REGION(1, k + 2 < nk, k + 3 < nk);
     }
+    }
+#undef X6_REGION16
+#undef X6_MFMAS16
+#undef X6_READ_A16
+#undef X6_READ_XB
 #undef X6_REGION
 #undef X6_MFMAS
 #undef X6_READ_X
 #undef X6_READ_Y
 #undef X6_ISSUE
+#undef X6_ISSUE_PIECE
+#undef X6_ISSUE_ADVANCE
     X6_STAMP(2);
     __syncthreads();   // no DMA is in flight and every fragment is in registers: the stages become the epilogue staging
 
@@ -439,6 +547,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 }
             }
         }
+        if constexpr (M16) {   // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int rb0 = wm * TM * 32 + x * 16;
+                if (rb0 / EP_ROWS == pass) {
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            stg[(rb0 % EP_ROWS + 4 * g16 + r) * LDC + wn * TN * 32 + y * 16 + r16] = acc16[x][y][r];
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int rb0 = (wm * TM + i) * 32;
@@ -449,6 +570,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                     for (int r = 0; r < 16; ++r)
                         stg[(rb0 % EP_ROWS + 4 * half + (r & 3) + 8 * (r >> 2)) * LDC + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
             }
+        }
         }
         __syncthreads();
 #pragma unroll
@@ -591,7 +713,7 @@ static int x6_report_stamps(relax_handle* h, const X6Params& p, int units, hipSt
 }
 #endif
 
-template <int BM, int BN, int WM, int WN, bool TAPS>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false>
 static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr int WG_PER_CU = NT == 256 ? 2 : 1;
@@ -614,7 +736,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     constexpr size_t lds = 2 * (size_t)(BM + BN) * kChunkBytes + 1024;
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[h->device] = true;
     }
@@ -623,7 +745,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * 8 * (size_t)units));
     p.stamps = static_cast<unsigned long long*>(h->scratch.p);
 #endif
-    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS>), dim3(units), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS, M16>), dim3(units), dim3(NT), lds, s, p);
 #ifdef RELAX_X6_STAMPS
     RELAX_TRY((x6_report_stamps<BM, BN>(h, p, units, s)));
 #endif
@@ -670,8 +792,8 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     int rc;
     // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA); N = 128 / 64 layers: the same
     // loop on four waves, two workgroups per CU
-    if (p.N % 256 == 0)
-        rc = taps ? launch_x6_variant<256, 256, 2, 4, true>(h, p, s) : launch_x6_variant<256, 256, 2, 4, false>(h, p, s);
+    if (p.N % 256 == 0)   // the 8-wave tile runs the 16x16x32 form of the loop
+        rc = taps ? launch_x6_variant<256, 256, 2, 4, true, true>(h, p, s) : launch_x6_variant<256, 256, 2, 4, false, true>(h, p, s);
     else if (p.N % 128 == 0)
         rc = taps ? launch_x6_variant<256, 128, 2, 2, true>(h, p, s) : launch_x6_variant<256, 128, 2, 2, false>(h, p, s);
     else

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void k(const u32x4* __restrict__ img, float
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
         const int r16 = lane & 15, g = lane >> 4;
         // lane (r, g): k group g of the 32-deep instruction = half (g & 1) of the first (g < 2) or the second (g >= 2) plane of the pair
-        const int half = (((g & 1) ^ (r16 >> 3)) & 1) << 4;
+        const int half = (V == 2 ? (g & 1) : (((g & 1) ^ (r16 >> 3)) & 1)) << 4;   // V == 2: linear image (no half swap): conflict-free for these reads
         const int second = g >> 1;
         const int rowoff = r16 * CHUNK + half;
         const int a_hm = (wm * 128) * CHUNK + rowoff + (second ? 32 : 0);   // A [hi | mid]
@@ -171,6 +171,7 @@ static double run(const char* what, const u32x4* d_img, float* d_out, unsigned l
 template <int V>
 static void check(const char* what, const u32x4* d_img, float* d_out, unsigned long long* d_cyc, const std::vector<double>& exact, int steps) {
     const size_t lds = NCHUNK * STAGE;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k<V>, dim3(1), dim3(512), lds, 0, d_img, d_out, d_cyc, steps);
     std::vector<float> got(256 * 256);
     (void)hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost);
@@ -190,7 +191,7 @@ int main() {
     std::normal_distribution<float> nd(0.f, 1.f);
     std::vector<float> val((size_t)NCHUNK * ROWS * 16);
     for (auto& v : val) v = nd(rng);
-    std::vector<unsigned short> img((size_t)NCHUNK * ROWS * 48);
+    std::vector<unsigned short> img((size_t)NCHUNK * ROWS * 48), img_lin((size_t)NCHUNK * ROWS * 48);
     std::vector<float> kept(val.size());   // hi + mid + lo (== val: the split is exact)
     for (int c = 0; c < NCHUNK; ++c)
         for (int r = 0; r < ROWS; ++r)
@@ -208,14 +209,20 @@ int main() {
                 row[0 * 16 + ph * 8 + j] = hi;
                 row[1 * 16 + ph * 8 + j] = mid;
                 row[2 * 16 + ph * 8 + j] = lo;
+                unsigned short* rl = &img_lin[((size_t)c * ROWS + r) * 48];
+                rl[0 * 16 + h * 8 + j] = hi;
+                rl[1 * 16 + h * 8 + j] = mid;
+                rl[2 * 16 + h * 8 + j] = lo;
             }
-    u32x4* d_img;
+    u32x4 *d_img, *d_lin;
     float* d_out;
     unsigned long long* d_cyc;
     (void)hipMalloc(&d_img, img.size() * 2);
     (void)hipMalloc(&d_out, 256 * 256 * 4);
     (void)hipMalloc(&d_cyc, 256 * 8);
     (void)hipMemcpy(d_img, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMalloc(&d_lin, img.size() * 2);
+    (void)hipMemcpy(d_lin, img_lin.data(), img.size() * 2, hipMemcpyHostToDevice);
     // numerics: `steps` K steps cycling over the NCHUNK chunks = (steps / NCHUNK) x the 32-deep product
     for (int steps : {2, 48, 192}) {
         std::vector<double> exact(256 * 256, 0.0);
@@ -229,11 +236,13 @@ int main() {
             }
         check<0>("32x32x16, six products", d_img, d_out, d_cyc, exact, steps);
         check<1>("16x16x32, three paired products", d_img, d_out, d_cyc, exact, steps);
+        check<2>("16x16x32 paired, linear image", d_lin, d_out, d_cyc, exact, steps);
     }
     const int iters = 20000;
     for (int rep = 0; rep < 3; ++rep) {
         run<0>("32x32x16, six products", d_img, d_out, d_cyc, iters);
         run<1>("16x16x32, three paired products", d_img, d_out, d_cyc, iters);
+        run<2>("16x16x32 paired, linear image", d_lin, d_out, d_cyc, iters);
     }
     return 0;
 }
