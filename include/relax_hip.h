@@ -163,6 +163,16 @@ int relax_resize_frames(relax_handle* h, const uint8_t* frames, int64_t item_str
 int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float* layer_stack, float* pool,
                             float* const* taps_nchw, relax_stream stream);
 
+/* The clip path asks different things of the two groups of its batch: the layer stack of the ORIGINAL fragments and the pool
+ * vector of the RESIDUAL fragments (src/main_fragment_layerstack.py:330-331: get_deep_feature(.., original_frag_path, ..,
+ * 'layer_stack') and get_deep_feature(.., merged_frag_path, .., 'pool'); :341-345).  ONE forward over all N images:
+ *   images [0, n_layer_stack)  -> layer_stack fp32 [n_layer_stack, 13120]
+ *   images [n_layer_stack, N)  -> pool        fp32 [N - n_layer_stack, 2051]
+ * Same values as relax_resnet50_features on the respective images; the taps of the second group are neither reduced nor written
+ * as fp32, the pool statistics of the first group are not formed.  Either group may be empty (its pointer may then be NULL). */
+int relax_resnet50_clip_features(relax_handle* h, const uint8_t* frags, int N, int n_layer_stack, float* layer_stack, float* pool,
+                                 relax_stream stream);
+
 /* ViT on N fragments.  tokens: fp32 [N,196,dim] final-norm patch tokens
  * (visualise_vit_layer.process_video_frame, :447-500) (may be NULL);
  * pooled: fp32 [N,3*dim] mean|max|std over tokens (main_fragment_pool.py:124-133) (may be NULL). */

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "relax_flow_to_rgb": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp, c_vp]),
     "relax_resize_frames": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
     "relax_resnet50_features": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, C.POINTER(c_vp), c_vp]),
+    "relax_resnet50_clip_features": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, c_vp, c_vp, c_vp]),
     "relax_vit_features": (C.c_int, [c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp]),
     "relax_load_mlp_head": (C.c_int, [c_vp, C.POINTER(c_vp), C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int,
                                       c_vp, c_vp, c_vp, C.c_int]),

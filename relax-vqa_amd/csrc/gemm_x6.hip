@@ -78,6 +78,8 @@ int launch_to_sp3(relax_handle* h, const float* x, int64_t ld, void* y, int64_t 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
 struct X6Params {
     const char* a;        // sp3 activations: [M][K*6 B] (plain) or NHWC pixels [Nimg*H*W][Cin*6 B] (implicit GEMM)
+    const char* a2;       // DUAL: a second activation source, NHWC pixels [Nimg*H2*W2][Cin2*6 B] sampled with stride2 at the output
+                          // pixels: the K steps past K1 read it (K = K1 + Cin2, weight rows concatenated the same way), or null
     const char* w;        // sp3 weights [N][K*6 B], k = (dy*KW+dx)*Cin + c (the K loop visits the 16-channel chunks tap-innermost)
     const float* bias;
     const float* residual;   // fp32 [M][N] or null
@@ -87,6 +89,9 @@ struct X6Params {
     char* out_sp3;           // sp3 [M][N*6 B] or null
     float* partial;          // split-K partial tiles
     int M, N, K;
+    int K1, H2, W2, Cin2, stride2;   // DUAL only
+    int out_rows, gap_rows;          // rows below these limits get the fp32 output / the group sums (default M)
+    int no_split;
     int H, W, Cin, Ho, Wo, KW, stride, pad;
     int act;
     int tiles_m, tiles_n, ntiles, group_m;
@@ -119,7 +124,7 @@ constexpr int64_t kMaxRecords = 0x7ffffff0;
 // (the loop body is rotated: one "region" = barrier .. next barrier = M1(k) + M0(k+1) is one basic block, which the compiler's
 // scheduler interleaves better than any order pinned by hand)
 // X = the operand with fewer fragments per wave (double-buffered in registers), Y = the other one (two halves).
-template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (it has no __amdgpu_buffer_rsrc_t and emits no stub for a body that names it)
     constexpr int NW = WM * WN;
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int DUMMY = 2 * STAGE;              // 1 KiB nobody reads
     static_assert(ROWS % 32 == 0 && TM >= 1 && TN >= 1 && YT % 2 == 0 && A_PIECES % NW == 0, "tile / wave layout mismatch");
     static_assert(!M16 || (TM == 4 && TN == 2 && PPW <= 7), "the 16x16x32 loop is written for 128 x 64 per wave");
+    static_assert(!DUAL || !TAPS, "a second activation source goes with 1x1 contractions");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -188,19 +194,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     // stage; lane l fills unit u = piece*64 + l = (tile row u/6, physical unit u%6); physical unit (plane q, half h')
     // holds logical half h = h' ^ bit3(row).  Pieces j < A_PPW belong to the activation rows, the rest to the weight rows.
     const bool pixels = TAPS || p.stride != 1;     // rows are output pixels of an NHWC image (else: plain matrix rows)
-    const int64_t row_bytes = (int64_t)p.K * 6;
+    const int64_t row_bytes = (int64_t)p.K * 6;                       // weight rows
+    const int64_t arow_bytes = (int64_t)(DUAL ? p.K1 : p.K) * 6;      // plain activation rows (DUAL: the first source's K1 values)
     const int64_t pix_bytes = (int64_t)p.Cin * 6;
-    const int img0 = pixels ? m0 / (p.Ho * p.Wo) : 0;
-    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
+    const int img0 = (pixels || DUAL) ? m0 / (p.Ho * p.Wo) : 0;
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w, rsrc_a2;
     {
-        const int64_t base = pixels ? (int64_t)img0 * p.H * p.W * pix_bytes : (int64_t)m0 * row_bytes;
-        const int64_t total = pixels ? (int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * pix_bytes : (int64_t)p.M * row_bytes;
+        const int64_t base = pixels ? (int64_t)img0 * p.H * p.W * pix_bytes : (int64_t)m0 * arow_bytes;
+        const int64_t total = pixels ? (int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * pix_bytes : (int64_t)p.M * arow_bytes;
         const int64_t left = total - base;
         rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a + base), 0, (int)(left < kMaxRecords ? left : kMaxRecords),
                                                    0x00020000);
         rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + (int64_t)n0 * row_bytes), 0, (int)(BN * row_bytes), 0x00020000);
+        if (DUAL) {
+            const int64_t pix2 = (int64_t)p.Cin2 * 6;
+            const int64_t base2 = (int64_t)img0 * p.H2 * p.W2 * pix2;
+            const int64_t left2 = (int64_t)(p.M / (p.Ho * p.Wo)) * p.H2 * p.W2 * pix2 - base2;
+            rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a2 + base2), 0, (int)(left2 < kMaxRecords ? left2 : kMaxRecords),
+                                                        0x00020000);
+        }
     }
     unsigned voff[PPW];
+    unsigned voff2[DUAL ? A_PPW : 1];   // DUAL: the same rows in the second source (pixels (oy, ox) * stride2 of their image)
     unsigned a_taps[A_PPW > 0 ? A_PPW : 1];   // implicit GEMM: bit t set = tap t of this piece's pixel lies inside the image (KH*KW <= 32)
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
@@ -229,7 +244,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 }
                 voff[j] = (unsigned)((((img - img0) * p.H + iy) * p.W + ix) * (int)pix_bytes + unit_off);
             } else {
-                voff[j] = (unsigned)(trow * (int)row_bytes + unit_off);
+                voff[j] = (unsigned)(trow * (int)arow_bytes + unit_off);
+            }
+            if (DUAL) {
+                if (m >= p.M) {
+                    voff2[j] = kOutOfRange;
+                } else {
+                    const int img = m / (p.Ho * p.Wo);
+                    const int rem = m - img * (p.Ho * p.Wo);
+                    const int oy = rem / p.Wo;
+                    const int ox = rem - oy * p.Wo;
+                    voff2[j] = (unsigned)((((img - img0) * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * (p.Cin2 * 6) + unit_off);
+                }
             }
         } else {
             voff[j] = piece < PIECES ? (unsigned)((trow - BM) * (int)row_bytes + unit_off) : kOutOfRange;
@@ -244,6 +270,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     int d_dy = 0, d_dx = 0, d_cc = 0, d_tap = 0;
     const int cin_chunks = p.Cin >> 4;
     const int ntaps = p.K / p.Cin;   // KH * KW
+    [[maybe_unused]] const int k1_chunks = DUAL ? p.K1 >> 4 : 0;
     if (TAPS) {
         d_cc = kt_begin / ntaps;
         d_tap = kt_begin - d_cc * ntaps;
@@ -262,6 +289,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 const int jj_ = (j_) < A_PPW ? (j_) : 0;                                                                \
                 const bool ok_ = (a_taps[jj_] >> d_tap) & 1u;                                                           \
                 X6_DMA(rsrc_a, dst_, ok_ ? voff[j_] + (unsigned)tapoff_ : kOutOfRange, 0);                              \
+            } else if (DUAL && d_kt >= k1_chunks) {   /* workgroup-uniform: the steps past K1 read the second source */    \
+                const int jj_ = (j_) < A_PPW ? (j_) : 0;                                                                \
+                X6_DMA(rsrc_a2, dst_, voff2[jj_], lin_ - k1_chunks * kChunkBytes);                                      \
             } else {                                                                                                    \
                 X6_DMA(rsrc_a, dst_, voff[j_], lin_);                                                                   \
             }                                                                                                           \
@@ -601,7 +631,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 vb = act_gelu4(vb);
             }
             const int64_t o = (int64_t)m * p.N + n0;
-            if (p.out) {
+            if (p.out && m < p.out_rows) {
                 *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
                 *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
             }
@@ -619,7 +649,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             for (int e = tid; e < (EP_ROWS / 16) * BN; e += NT) {
                 const int g = e / BN, col = e - g * BN;
                 const int mg = m0 + pass * EP_ROWS + g * 16;
-                if (mg < p.M) {
+                if (mg < p.gap_rows) {
                     float t = 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) t += stg[(g * 16 + r) * LDC + col];
@@ -676,7 +706,7 @@ __global__ __launch_bounds__(256) void splitk_finish_x6(const X6Params p) {
         va = act_gelu4(va);
         vb = act_gelu4(vb);
     }
-    if (p.out) {
+    if (p.out && m < p.out_rows) {
         *reinterpret_cast<f32x4*>(p.out + o) = va;
         *reinterpret_cast<f32x4*>(p.out + o + 4) = vb;
     }
@@ -713,7 +743,7 @@ static int x6_report_stamps(relax_handle* h, const X6Params& p, int units, hipSt
 }
 #endif
 
-template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false>
 static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr int WG_PER_CU = NT == 256 ? 2 : 1;
@@ -724,7 +754,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     p.partial = nullptr;
     // Tail split-K: the last, partial round of tiles is cut along K (cost model: host_logic.cpp, shared with gemm.hip);
     // splitk_finish_x6 knows neither the fused group sums nor a split-plane residual, so those launches run unsplit
-    const bool can_split = h->gemm.split_k && !p.gap && !p.residual_sp3;
+    const bool can_split = h->gemm.split_k && !p.gap && !p.residual_sp3 && !p.no_split;
     const host::TailSplit ts = host::choose_tail_split(p.ntiles, 256 * WG_PER_CU, p.K / 16, 8, can_split);
     p.full_tiles = ts.full_tiles;
     p.nsplit = ts.nsplit;
@@ -736,7 +766,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     constexpr size_t lds = 2 * (size_t)(BM + BN) * kChunkBytes + 1024;
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[h->device] = true;
     }
@@ -745,7 +775,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * 8 * (size_t)units));
     p.stamps = static_cast<unsigned long long*>(h->scratch.p);
 #endif
-    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS, M16>), dim3(units), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL>), dim3(units), dim3(NT), lds, s, p);
 #ifdef RELAX_X6_STAMPS
     RELAX_TRY((x6_report_stamps<BM, BN>(h, p, units, s)));
 #endif
@@ -764,7 +794,12 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     p.gap = d.gap_groups;
     p.M = d.Nimg * d.Ho * d.Wo;
     p.N = d.Cout;
-    p.K = d.KH * d.KW * d.Cin;
+    p.K = d.KH * d.KW * d.Cin + (d.in2 ? d.Cin2 : 0);
+    p.a2 = static_cast<const char*>(d.in2);
+    p.K1 = d.KH * d.KW * d.Cin; p.H2 = d.H2; p.W2 = d.W2; p.Cin2 = d.Cin2; p.stride2 = d.stride2;
+    p.no_split = d.no_split;
+    p.out_rows = d.out_rows > 0 && d.out_rows < p.M ? d.out_rows : p.M;
+    p.gap_rows = d.gap_rows > 0 && d.gap_rows < p.M ? d.gap_rows : p.M;
     p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Ho = d.Ho; p.Wo = d.Wo;
     p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
     p.act = d.act;
@@ -778,21 +813,26 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, !d.gap_groups || ((d.Ho * d.Wo) % 16 == 0 && p.M % 16 == 0), "x6 conv: the fused spatial mean needs Ho*Wo %% 16 == 0");
     RELAX_REQUIRE(h, !taps || (d.pad >= 0 && d.KH * d.KW <= 32), "x6 conv: bad padding, or more than 32 taps (%dx%d)", d.KH, d.KW);
     RELAX_REQUIRE(h, taps || d.pad == 0, "x6 conv: 1x1 with padding is not supported");
+    RELAX_REQUIRE(h, !d.in2 || (!taps && d.stride == 1 && d.Cin2 % 16 == 0 && d.stride2 >= 1 && p.N % 256 == 0 &&
+                                (d.H2 - 1) / d.stride2 + 1 == d.Ho && (d.W2 - 1) / d.stride2 + 1 == d.Wo),
+                  "x6 conv: a second activation source needs a 1x1 stride-1 first source, Cout %% 256 == 0 and a matching output grid");
     // every operand is read / written in 16-byte units (LDS-DMA pieces, f32x4 bias / residual / output accesses, plane units)
     auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     RELAX_REQUIRE(h, aligned16(d.in) && aligned16(d.w) && aligned16(d.bias) && aligned16(d.residual) && aligned16(d.residual_sp3) &&
-                         aligned16(d.out) && aligned16(d.out_sp3) && aligned16(d.gap_groups),
+                         aligned16(d.out) && aligned16(d.out_sp3) && aligned16(d.gap_groups) && aligned16(d.in2),
                   "x6 conv/gemm: every operand pointer must be 16-byte aligned");
     const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)p.K;
     // algorithmic HBM bytes: activation in (6 B per value), weights, outputs (+ residual), each touched once
-    const double bytes = 6.0 * ((double)d.Nimg * d.H * d.W * d.Cin + (double)p.N * p.K) +
+    const double bytes = 6.0 * ((double)d.Nimg * d.H * d.W * d.Cin + (double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) +
                          (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.residual ? 4.0 : 0.0) + (d.residual_sp3 ? 6.0 : 0.0));
     int span;
     RELAX_TRY(prof_begin(h, s, 2, flops, &span, bytes));
     int rc;
     // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA); N = 128 / 64 layers: the same
     // loop on four waves, two workgroups per CU
-    if (p.N % 256 == 0)   // the 8-wave tile runs the 16x16x32 form of the loop
+    if (d.in2)
+        rc = launch_x6_variant<256, 256, 2, 4, false, true, true>(h, p, s);
+    else if (p.N % 256 == 0)   // the 8-wave tile runs the 16x16x32 form of the loop
         rc = taps ? launch_x6_variant<256, 256, 2, 4, true, true>(h, p, s) : launch_x6_variant<256, 256, 2, 4, false, true>(h, p, s);
     else if (p.N % 128 == 0)
         rc = taps ? launch_x6_variant<256, 128, 2, 2, true>(h, p, s) : launch_x6_variant<256, 128, 2, 2, false>(h, p, s);

@@ -71,8 +71,14 @@ struct ConvDescX6 {
     int Nimg, H, W, Cin;
     int Ho, Wo;
     int KH, KW, stride, pad;
-    const void* w;          // sp3 weights [Cout][KH*KW*Cin*6 B], k = (dy*KW+dx)*Cin + c
+    const void* w;          // sp3 weights [Cout][KH*KW*Cin*6 B], k = (dy*KW+dx)*Cin + c  (with in2: [Cout][(Cin + Cin2)*6 B])
     int Cout;
+    // optional second activation source of a 1x1 contraction (ResNet downsample branch folded into conv3: one accumulator
+    // sums W3 t2 + Wd x): sp3 NHWC [Nimg*H2*W2][Cin2*6 B], sampled at (oy, ox) * stride2; the weight rows are concatenated
+    const void* in2;
+    int H2, W2, Cin2, stride2;
+    int out_rows, gap_rows; // rows below these limits get the fp32 output / the group sums (0 = all rows)
+    bool no_split;          // never cut tail tiles along K (a launch whose bits must not depend on which outputs are requested)
     const float* bias;      // [Cout] or null
     const float* residual;  // fp32 [M, Cout] or null
     const void* residual_sp3;  // the residual as split planes instead (exact), or null
@@ -93,6 +99,10 @@ struct ConvW {          // one folded conv (+BN) of ResNet-50
 
 struct Bottleneck {
     ConvW c1, c2, c3, down;
+    // bf16x6 path, blocks with a downsample branch: conv3 and the downsample convolution as ONE contraction over the concatenated
+    // K = [conv2 output | block input] (weights [Cout][(width + Cin) * 6 B] as split planes, bias = the sum of the two folded shifts)
+    void* c3d_w_sp3 = nullptr;
+    float* c3d_bias = nullptr;
     bool has_down = false;
     int tap = -1;  // layer-stack tap index, -1 if not tapped
 };

@@ -105,7 +105,8 @@ static constexpr float kBnEps = 1e-5f;
 
 // conv (OIHW) [+ BN] -> device [Cout][Kpad] (+ bias).  cin_pad >= cin (conv1: 3 -> 4).
 static int make_conv(relax_handle* h, const HostSD& sd, const std::string& conv, const std::string& bn, int cout,
-                     int cin, int cin_pad, int k, int stride, int pad, ConvW* out, std::vector<void*>& allocs) {
+                     int cin, int cin_pad, int k, int stride, int pad, ConvW* out, std::vector<void*>& allocs,
+                     std::vector<float>* shift_out = nullptr) {
     const float* w = sd_get(h, sd, conv + ".weight", (int64_t)cout * cin * k * k);
     if (!w) return RELAX_ERR_INVALID;
     std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
@@ -125,6 +126,7 @@ static int make_conv(relax_handle* h, const HostSD& sd, const std::string& conv,
     RELAX_TRY(upload(h, packed.data(), packed.size(), &out->w, allocs));
     if (!bn.empty()) RELAX_TRY(upload(h, shift.data(), shift.size(), &out->bias, allocs));
     else out->bias = nullptr;
+    if (shift_out) *shift_out = shift;
     return RELAX_OK;
 }
 
@@ -219,12 +221,17 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
             rc = make_conv(h, sd, p + ".conv1", p + ".bn1", width, cin, cin, 1, 1, 0, &blk.c1, rn.allocs);
             if (rc == RELAX_OK)
                 rc = make_conv(h, sd, p + ".conv2", p + ".bn2", width, width, width, 3, stride, 1, &blk.c2, rn.allocs);
+            std::vector<float> shift3, shiftd;
             if (rc == RELAX_OK)
-                rc = make_conv(h, sd, p + ".conv3", p + ".bn3", width * 4, width, width, 1, 1, 0, &blk.c3, rn.allocs);
+                rc = make_conv(h, sd, p + ".conv3", p + ".bn3", width * 4, width, width, 1, 1, 0, &blk.c3, rn.allocs, &shift3);
             blk.has_down = (b == 0);
             if (rc == RELAX_OK && blk.has_down)
                 rc = make_conv(h, sd, p + ".downsample.0", p + ".downsample.1", width * 4, cin, cin, 1, stride, 0,
-                               &blk.down, rn.allocs);
+                               &blk.down, rn.allocs, &shiftd);
+            if (rc == RELAX_OK && blk.has_down) {   // bias of the fused conv3 + downsample contraction
+                for (size_t o = 0; o < shift3.size(); ++o) shift3[o] += shiftd[o];
+                rc = upload(h, shift3.data(), shift3.size(), &blk.c3d_bias, rn.allocs);
+            }
             if (rc != RELAX_OK) { free_resnet(h); return rc; }
             blk.tap = b < stage_taps[st] ? tap++ : -1;
             rn.blocks.push_back(blk);
@@ -256,6 +263,33 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
             if (rc != RELAX_OK) { free_resnet(h); return rc; }
         }
     }
+    // ... and, for the four blocks with a downsample branch, [conv3 | downsample] rows side by side
+    for (Bottleneck& blk : rn.blocks) {
+        if (!blk.has_down) continue;
+        const int K1 = blk.c3.Cin, K2 = blk.down.Cin, Co = blk.c3.Cout;
+        float* cat = nullptr;
+        void* q = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&cat), sizeof(float) * (size_t)Co * (K1 + K2)) != hipSuccess ||
+            hipMalloc(&q, (size_t)Co * (K1 + K2) * 6) != hipSuccess) {
+            if (cat) (void)hipFree(cat);
+            set_error(h, "resnet50: hipMalloc of the fused conv3 + downsample weights failed");
+            free_resnet(h);
+            return RELAX_ERR_NOMEM;
+        }
+        rn.allocs.push_back(q);
+        blk.c3d_w_sp3 = q;
+        hipError_t e = hipMemcpy2D(cat, sizeof(float) * (K1 + K2), blk.c3.w, sizeof(float) * K1, sizeof(float) * K1, Co, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy2D(cat + K1, sizeof(float) * (K1 + K2), blk.down.w, sizeof(float) * K2, sizeof(float) * K2, Co, hipMemcpyDeviceToDevice);
+        rc = e == hipSuccess ? launch_to_sp3(h, cat, K1 + K2, q, Co, K1 + K2, nullptr) : RELAX_ERR_HIP;
+        if (rc == RELAX_OK && hipDeviceSynchronize() != hipSuccess) rc = RELAX_ERR_HIP;
+        (void)hipFree(cat);
+        if (rc != RELAX_OK) {
+            set_error(h, "resnet50: building the fused conv3 + downsample weights failed");
+            free_resnet(h);
+            return rc;
+        }
+    }
     if (hipDeviceSynchronize() != hipSuccess) {
         set_error(h, "resnet50: weight conversion failed");
         free_resnet(h);
@@ -265,13 +299,10 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
     return RELAX_OK;
 }
 
-int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float* layer_stack, float* pool,
-                            float* const* taps_nchw, relax_stream stream) {
-    if (!h) return RELAX_ERR_INVALID;
-    RELAX_REQUIRE(h, h->rn.loaded, "relax_resnet50_features: call relax_load_resnet50 first");
-    RELAX_REQUIRE(h, frags && N > 0, "relax_resnet50_features: bad arguments");
-    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
+// One forward over N images.  Images [0, n_ls) get layer-stack rows (n_ls = 0: none), images [pool_from, N) get pool rows
+// (pool == nullptr: none); taps_nchw (all N images) as in relax_resnet50_features.
+static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls, int pool_from, float* layer_stack, float* pool,
+                          float* const* taps_nchw, hipStream_t s) {
     RELAX_TRY(ensure_buf(h, h->arena, resnet_arena_bytes(N)));
     float* base = static_cast<float*>(h->arena.p);
     const size_t n = (size_t)N;
@@ -284,28 +315,40 @@ int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float*
     float* gapws = T2 + kT2 * n;
     float* avg = gapws + kGapWs * n;
     const ResNet50W& rn = h->rn;
+    if (n_ls == 0) layer_stack = nullptr;
+    const int n_pool = pool ? N - pool_from : 0;
+    // the pool vector of an image that is also in the layer stack is the last 2048 columns of its layer-stack row
+    const bool pool_from_stack = pool && layer_stack && pool_from == 0 && n_ls == N;
 
-    auto emit_tap = [&](int tap, const float* act) -> int {
-        const int C = kTapChannels[tap], HW = kTapHW[tap] * kTapHW[tap];
+    auto tap_offset = [](int tap) {
         int off = 0;
         for (int t = 0; t < tap; ++t) off += kTapChannels[t];
-        if (layer_stack)
-            RELAX_TRY(launch_gap_ws(h, act, layer_stack + off, N, HW, C, RELAX_RN50_LAYER_STACK_DIM, gapws, s));
-        if (taps_nchw && taps_nchw[tap]) RELAX_TRY(launch_nhwc_to_nchw(h, act, taps_nchw[tap], N, HW, C, s));
+        return off;
+    };
+    auto pool_tail = [&](const float* last32, float* avg_ws, float* gap_scratch) -> int {   // last32: fp32 [N,49,2048] of the last block
+        if (!pool) return RELAX_OK;
+        const float* avg_src = layer_stack + (RELAX_RN50_LAYER_STACK_DIM - 2048);
+        int64_t avg_stride = RELAX_RN50_LAYER_STACK_DIM;
+        if (!pool_from_stack) {
+            RELAX_TRY(launch_gap_ws(h, last32 + (size_t)pool_from * 49 * 2048, avg_ws, n_pool, 49, 2048, 2048, gap_scratch, s));
+            avg_src = avg_ws;
+            avg_stride = 2048;
+        }
+        hipLaunchKernelGGL(rn_pool_stats, dim3(n_pool), dim3(256), 0, s, avg_src, avg_stride, pool);
+        RELAX_HIP_CHECK(h, hipGetLastError());
         return RELAX_OK;
     };
 
     if (h->gemm.precision == 2) {
         // bf16x6.  conv1 7x7/2 (raw) straight from the uint8 fragments (conv1_x6.hip: preprocess, im2col, split and contraction in one
         // kernel, the 16-pixel sums of the tap's spatial mean formed in its epilogue); from the max-pool on, every convolution input
-        // travels as split planes written by its producer, and block outputs are written twice (fp32: residual / taps; planes: next convs)
+        // travels as split planes written by its producer
         float* gap0 = T2 + kT2 * n;   // = the fp32 carving's gapws: free until the blocks carve the arena anew below
         RELAX_TRY(launch_conv1_x6(h, frags, rn.conv1.w_sp3, bufA, layer_stack ? gap0 : nullptr, N, s));
-        if (layer_stack) RELAX_TRY(launch_gap_groups_finish(h, gap0, layer_stack, N, 112 * 112, 64, RELAX_RN50_LAYER_STACK_DIM, s));
+        if (layer_stack) RELAX_TRY(launch_gap_groups_finish(h, gap0, layer_stack, n_ls, 112 * 112, 64, RELAX_RN50_LAYER_STACK_DIM, s));
         if (taps_nchw && taps_nchw[0]) RELAX_TRY(launch_nhwc_to_nchw(h, bufA, taps_nchw[0], N, 112 * 112, 64, s));
-        float* f32a = bufB;                                   // block in / out, fp32 (ping-pong with f32b)
+        float* f32a = bufB;                                   // block outputs as fp32, where something needs them (ping-pong with f32b)
         float* f32b = bufD;
-        float* D = bufA;                                      // downsample branch, fp32 (conv1's raw map is dead after the pool)
         char* spa = reinterpret_cast<char*>(T1);              // carve the rest of the arena anew
         char* spb = spa + sizeof(float) * (kBig * 3 / 2) * n;
         char* T1s = spb + sizeof(float) * (kBig * 3 / 2) * n;
@@ -315,8 +358,9 @@ int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float*
         gapws = gapws6;
         RELAX_TRY(launch_bn_relu_maxpool_sp3(h, bufA, rn.bn1_scale, rn.bn1_shift, spa, N, 112, 112, 64, s));
         // A block output exists as split planes always (next convolutions, next residual: hi + mid + lo is the fp32 value,
-        // exactly) and as fp32 only where something needs it: the tap export, or the spatial mean of the 14x14 / 7x7 taps
-        // (196 and 49 rows per image do not divide into the 16-row groups of the mean fused into the epilogue).
+        // exactly) and as fp32 only where something needs it, and only for the images that need it: the tap export, the spatial
+        // mean of the 14x14 / 7x7 taps of the layer-stack images (196 and 49 rows per image do not divide into the 16-row groups
+        // of the mean fused into the epilogue), the last block's map of the pool images.
         const float* cur32 = nullptr;
         char* cursp = spa;
         char* othersp = spb;
@@ -330,48 +374,53 @@ int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float*
             const bool want_export = tapped && taps_nchw && taps_nchw[blk.tap];
             const bool is_last = &blk == &rn.blocks.back();
             const bool fuse_mean = want_mean && HWo % 16 == 0;
-            const bool need32 = want_export || (want_mean && !fuse_mean) || (is_last && pool && !layer_stack);
+            const bool pool_needs32 = is_last && pool && !pool_from_stack;
+            const bool need32 = want_export || (want_mean && !fuse_mean) || pool_needs32;
+            // fp32 rows: every image for an export or the pool images behind the layer-stack ones, else the layer-stack images only
+            const int rows32 = (want_export || pool_needs32) ? N * HWo : n_ls * HWo;
             RELAX_TRY(run_conv_x6(h, blk.c1, cursp, N, H, H, nullptr, nullptr, T1s, 1, s));
             RELAX_TRY(run_conv_x6(h, blk.c2, T1s, N, H, H, nullptr, nullptr, T2s, 1, s));
-            const float* identity = nullptr;
-            const void* identity_sp3 = cursp;
+            ConvDescX6 d{};
+            d.in = T2s; d.Nimg = N; d.H = Ho; d.W = Ho; d.Cin = blk.c3.Cin; d.Ho = Ho; d.Wo = Ho;
+            d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+            d.Cout = Cout; d.act = 1;
+            d.out = need32 ? out32 : nullptr; d.out_rows = rows32;
+            d.out_sp3 = othersp;
+            d.gap_groups = fuse_mean ? gapws : nullptr; d.gap_rows = n_ls * HWo;
+            d.no_split = tapped && HWo % 16 == 0;   // a launch that fuses the mean when the layer stack is asked for runs unsplit either
+                                                    // way: the pool vector's bits do not depend on whether the layer stack is requested
             if (blk.has_down) {
-                RELAX_TRY(run_conv_x6(h, blk.down, cursp, N, H, H, nullptr, D, nullptr, 0, s));
-                identity = D;
-                identity_sp3 = nullptr;
+                // conv3 and the downsample convolution in ONE contraction over K = [conv2 output | block input sampled with the
+                // block's stride]: no fp32 copy of the branch is written and read back (layer1.0: 6.6 GB per 1024 images)
+                d.w = blk.c3d_w_sp3; d.bias = blk.c3d_bias;
+                d.in2 = cursp; d.H2 = H; d.W2 = H; d.Cin2 = blk.down.Cin; d.stride2 = blk.down.stride;
+            } else {
+                d.w = blk.c3.w_sp3; d.bias = blk.c3.bias;
+                d.residual_sp3 = cursp;
             }
-            RELAX_TRY(run_conv_x6(h, blk.c3, T2s, N, Ho, Ho, identity, need32 ? out32 : nullptr, othersp, 1, s, identity_sp3,
-                                  fuse_mean ? gapws : nullptr));
+            RELAX_TRY(launch_conv_x6(h, d, s));
             cur32 = need32 ? out32 : nullptr;
             if (need32) out32 = out32 == f32a ? f32b : f32a;
             char* t = cursp; cursp = othersp; othersp = t;
             H = Ho;
             if (tapped) {
-                int off = 0;
-                for (int t2 = 0; t2 < blk.tap; ++t2) off += kTapChannels[t2];
+                const int off = tap_offset(blk.tap);
                 if (fuse_mean)
-                    RELAX_TRY(launch_gap_groups_finish(h, gapws, layer_stack + off, N, HWo, Cout, RELAX_RN50_LAYER_STACK_DIM, s));
+                    RELAX_TRY(launch_gap_groups_finish(h, gapws, layer_stack + off, n_ls, HWo, Cout, RELAX_RN50_LAYER_STACK_DIM, s));
                 else if (want_mean)
-                    RELAX_TRY(launch_gap_ws(h, cur32, layer_stack + off, N, HWo, Cout, RELAX_RN50_LAYER_STACK_DIM, gapws, s));
+                    RELAX_TRY(launch_gap_ws(h, cur32, layer_stack + off, n_ls, HWo, Cout, RELAX_RN50_LAYER_STACK_DIM, gapws, s));
                 if (want_export) RELAX_TRY(launch_nhwc_to_nchw(h, cur32, taps_nchw[blk.tap], N, HWo, Cout, s));
             }
         }
-        if (pool) {
-            const float* avg_src;
-            int64_t avg_stride;
-            if (layer_stack) {
-                avg_src = layer_stack + (RELAX_RN50_LAYER_STACK_DIM - 2048);
-                avg_stride = RELAX_RN50_LAYER_STACK_DIM;
-            } else {
-                RELAX_TRY(launch_gap_ws(h, cur32, avg6, N, 49, 2048, 2048, gapws, s));
-                avg_src = avg6;
-                avg_stride = 2048;
-            }
-            hipLaunchKernelGGL(rn_pool_stats, dim3(N), dim3(256), 0, s, avg_src, avg_stride, pool);
-            RELAX_HIP_CHECK(h, hipGetLastError());
-        }
-        return RELAX_OK;
+        return pool_tail(cur32, avg6, gapws);
     }
+    auto emit_tap = [&](int tap, const float* act) -> int {
+        const int C = kTapChannels[tap], HW = kTapHW[tap] * kTapHW[tap];
+        if (layer_stack)
+            RELAX_TRY(launch_gap_ws(h, act, layer_stack + tap_offset(tap), n_ls, HW, C, RELAX_RN50_LAYER_STACK_DIM, gapws, s));
+        if (taps_nchw && taps_nchw[tap]) RELAX_TRY(launch_nhwc_to_nchw(h, act, taps_nchw[tap], N, HW, C, s));
+        return RELAX_OK;
+    };
     const int64_t npix = (int64_t)N * 224 * 224;
     hipLaunchKernelGGL(rn_preprocess, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, frags, X0, npix);
     RELAX_HIP_CHECK(h, hipGetLastError());
@@ -396,21 +445,28 @@ int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float*
         H = Ho;
         if (blk.tap >= 0) RELAX_TRY(emit_tap(blk.tap, cur));
     }
-    if (pool) {
-        const float* avg_src;
-        int64_t avg_stride;
-        if (layer_stack) {
-            avg_src = layer_stack + (RELAX_RN50_LAYER_STACK_DIM - 2048);
-            avg_stride = RELAX_RN50_LAYER_STACK_DIM;
-        } else {
-            RELAX_TRY(launch_gap_ws(h, cur, avg, N, 49, 2048, 2048, gapws, s));
-            avg_src = avg;
-            avg_stride = 2048;
-        }
-        hipLaunchKernelGGL(rn_pool_stats, dim3(N), dim3(256), 0, s, avg_src, avg_stride, pool);
-        RELAX_HIP_CHECK(h, hipGetLastError());
-    }
-    return RELAX_OK;
+    return pool_tail(cur, avg, gapws);
+}
+
+int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float* layer_stack, float* pool,
+                            float* const* taps_nchw, relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, h->rn.loaded, "relax_resnet50_features: call relax_load_resnet50 first");
+    RELAX_REQUIRE(h, frags && N > 0, "relax_resnet50_features: bad arguments");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    return resnet_forward(h, frags, N, layer_stack ? N : 0, 0, layer_stack, pool, taps_nchw, static_cast<hipStream_t>(stream));
+}
+
+int relax_resnet50_clip_features(relax_handle* h, const uint8_t* frags, int N, int n_layer_stack, float* layer_stack, float* pool,
+                                 relax_stream stream) {
+    if (!h) return RELAX_ERR_INVALID;
+    RELAX_REQUIRE(h, h->rn.loaded, "relax_resnet50_clip_features: call relax_load_resnet50 first");
+    RELAX_REQUIRE(h, frags && N > 0 && n_layer_stack >= 0 && n_layer_stack <= N, "relax_resnet50_clip_features: bad arguments");
+    RELAX_REQUIRE(h, (n_layer_stack == 0 || layer_stack) && (n_layer_stack == N || pool),
+                  "relax_resnet50_clip_features: NULL output for a non-empty group of images");
+    RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    return resnet_forward(h, frags, N, n_layer_stack, n_layer_stack, layer_stack, n_layer_stack < N ? pool : nullptr, nullptr,
+                          static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -295,6 +295,22 @@ class RelaxEngine:
         self._check(rc, "relax_resnet50_features")
         return (ls, pl, tap_out) if taps is not None else (ls, pl)
 
+    def resnet50_clip_features(self, frags, n_layer_stack):
+        """frags uint8 [N,224,224,3]: the first n_layer_stack images are original fragments (-> layer stack fp32
+        [n_layer_stack,13120]), the others residual fragments (-> pool fp32 [N - n_layer_stack, 2051]); ONE forward
+        (src/main_fragment_layerstack.py:330-331).  Same values as resnet50_features on the respective images."""
+        frags = self._frags(frags)
+        N = frags.shape[0]
+        n_ls = int(n_layer_stack)
+        if not 0 <= n_ls <= N:
+            raise ValueError(f"n_layer_stack={n_ls} outside [0, {N}]")
+        ls = torch.empty((n_ls, LAYER_STACK_DIM), dtype=torch.float32, device=self.device)
+        pl = torch.empty((N - n_ls, RN50_POOL_DIM), dtype=torch.float32, device=self.device)
+        rc = self.lib.relax_resnet50_clip_features(self.h, _ptr(frags), N, n_ls, _ptr(ls) if n_ls else None, _ptr(pl) if N > n_ls else None,
+                                                   _stream())
+        self._check(rc, "relax_resnet50_clip_features")
+        return ls, pl
+
     def vit_features(self, frags, tokens=False, pooled=True):
         """frags uint8 [N,224,224,3] BGR -> (tokens fp32 [N,196,dim] | None, pooled fp32 [N,3*dim] | None)"""
         if self.vit_dim is None:
@@ -326,8 +342,8 @@ class RelaxEngine:
         both = torch.cat([fr["ori_frag"], resid], dim=0)
         out = {"positions": fr["positions"], "counts": fr["counts"]}
         if resnet:
-            ls, pool = self.resnet50_features(both, layer_stack=True, pool=True)
-            out["resnet"] = torch.cat([ls[:T], pool[T:]], dim=1)
+            ls, pool = self.resnet50_clip_features(both, T)
+            out["resnet"] = torch.cat([ls, pool], dim=1)
         if vit:
             _, pooled = self.vit_features(both, tokens=False, pooled=True)
             out["vit"] = torch.cat([pooled[:T], pooled[T:]], dim=1)
@@ -361,8 +377,8 @@ class RelaxEngine:
         out = torch.empty((len(clips), F), dtype=torch.float32, device=self.device)
         blocks, col = [], 0
         if resnet:
-            ls, pool = self.resnet50_features(both, layer_stack=True, pool=True)
-            blocks += [(ls, 0, 0), (pool, n, LAYER_STACK_DIM)]
+            ls, pool = self.resnet50_clip_features(both, n)        # layer stack of the originals, pool of the residuals
+            blocks += [(ls, 0, 0), (pool, 0, LAYER_STACK_DIM)]
             col = LAYER_STACK_DIM + RN50_POOL_DIM
         if vit:
             _, pooled = self.vit_features(both, tokens=False, pooled=True)
@@ -410,31 +426,34 @@ class RelaxEngine:
         wf = [c[:, 0] for c in clips] if whole_frames is None else list(whole_frames)
         wcounts = [int(w.shape[0]) for w in wf]
         n, nw = sum(counts), sum(wcounts)
-        rn_in = torch.empty((2 * n + nw, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device)   # [ori | residual | bilinear]
+        # ResNet batch: the layer-stack images first [ori | bilinear whole frames], then the pool images [residual]
+        rn_in = torch.empty((2 * n + nw, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device)
         vit_in = torch.empty((2 * n + nw, TARGET, TARGET, 3), dtype=torch.uint8, device=self.device)  # [ori | residual | lanczos]
+        frag_bytes = TARGET * TARGET * 3
         at = aw = 0
         for i, (c, t) in enumerate(zip(clips, counts)):
-            res = rn_in[n + at:n + at + t]
-            self.fragment_pairs(c, out_ori=rn_in[at:at + t], out_diff=res)
+            res = vit_in[n + at:n + at + t]
+            self.fragment_pairs(c, out_ori=vit_in[at:at + t], out_diff=res)
             fimg = None if flow_images is None else flow_images[i]
             if flow and fimg is None:
                 _, fimg = self.optical_flow(c)
             if fimg is not None:
                 self.merge_fragments(res, self.fragment_image(fimg)["frag"], out=res)
             tw = wcounts[i]
-            self.resize_frames(wf[i], out_bilinear=rn_in[2 * n + aw:2 * n + aw + tw], out_lanczos=vit_in[2 * n + aw:2 * n + aw + tw])
+            self.resize_frames(wf[i], out_bilinear=rn_in[n + aw:n + aw + tw], out_lanczos=vit_in[2 * n + aw:2 * n + aw + tw])
             at += t
             aw += tw
-        self._check(self.lib.relax_copy_bytes(self.h, _ptr(rn_in), _ptr(vit_in), 2 * n * TARGET * TARGET * 3, _stream()),
-                    "relax_copy_bytes")   # the fragments are the same for both backbones
-        ls, pool = self.resnet50_features(rn_in, layer_stack=True, pool=True)
+        # the fragments are the same for both backbones
+        self._check(self.lib.relax_copy_bytes(self.h, _ptr(vit_in), _ptr(rn_in), n * frag_bytes, _stream()), "relax_copy_bytes")
+        self._check(self.lib.relax_copy_bytes(self.h, _ptr(vit_in[n:]), _ptr(rn_in[n + nw:]), n * frag_bytes, _stream()), "relax_copy_bytes")
+        ls, pool = self.resnet50_clip_features(rn_in, n + nw)
         _, vp = self.vit_features(vit_in, tokens=False, pooled=True)
         d = self.vit_dim
         out = torch.empty((len(clips), LAYER_STACK_DIM + 3 * d + LAYER_STACK_DIM + RN50_POOL_DIM + 6 * d), dtype=torch.float32,
                           device=self.device)
         c0 = LAYER_STACK_DIM + 3 * d
-        self._segment_means(out, [(ls, 2 * n, 0), (vp, 2 * n, LAYER_STACK_DIM)], wcounts)
-        return self._segment_means(out, [(ls, 0, c0), (pool, n, c0 + LAYER_STACK_DIM),
+        self._segment_means(out, [(ls, n, 0), (vp, 2 * n, LAYER_STACK_DIM)], wcounts)
+        return self._segment_means(out, [(ls, 0, c0), (pool, 0, c0 + LAYER_STACK_DIM),
                                          (vp, 0, c0 + LAYER_STACK_DIM + RN50_POOL_DIM),
                                          (vp, n, c0 + LAYER_STACK_DIM + RN50_POOL_DIM + 3 * d)], counts)
 

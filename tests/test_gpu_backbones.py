@@ -239,3 +239,25 @@ def test_bf16x3_at_the_headline_batch_uses_the_large_tiles_and_holds_the_bar():
     rel = np.linalg.norm(fast - exact) / np.linalg.norm(exact)
     assert rel < 5e-5, rel
     assert_close(fast, exact, "bf16x3 clip vectors vs fp32")
+
+
+def test_clip_features_entry_point_equals_the_two_group_calls(each_precision):
+    """relax_resnet50_clip_features: layer stack of the first group, pool of the second, one forward - the values the classic entry
+    point gives on the respective images (bit for bit without the tail split), also with an empty group."""
+    rn50_weights()
+    eng = engine()
+    frags = torch.from_numpy(_fragments(7, seed=4)).cuda()
+    eng.set_option("gemm_split_k", 0)
+    try:
+        ls_all, pool_all = eng.resnet50_features(frags, layer_stack=True, pool=True)
+        for n_ls in (0, 3, 7):
+            ls, pool = eng.resnet50_clip_features(frags, n_ls)
+            assert ls.shape == (n_ls, 13120) and pool.shape == (7 - n_ls, 2051)
+            assert torch.equal(ls, ls_all[:n_ls]), f"layer stack of a {n_ls} + {7 - n_ls} batch"
+            assert torch.equal(pool, pool_all[n_ls:]), f"pool of a {n_ls} + {7 - n_ls} batch"
+    finally:
+        eng.set_option("gemm_split_k", 1)
+    with pytest.raises(ValueError, match="n_layer_stack"):
+        eng.resnet50_clip_features(frags, 9)
+    rc = eng.lib.relax_resnet50_clip_features(eng.h, frags.data_ptr(), 7, 9, None, None, None)      # the C entry refuses it too
+    assert rc == -1 and b"bad arguments" in eng.lib.relax_last_error(eng.h)
