@@ -122,6 +122,51 @@ def hbm_traffic_per_launch(workload, clips_per_step, precision):
     return None
 
 
+def measure_hbm_traffic(workload, clips_per_step, precision, split_k):
+    """roofline.traffic measured in THIS run: two child passes of this script under rocprofv3 (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`:
+    separate passes, kernel-trace only, as the gfx950 guide prescribes; FETCH_SIZE doubled: it reports half of a 16-B-per-lane
+    streaming read), one warm-up + one step each; bytes per launch of the dominant kernel family (gemm_x6*, conv1_x6).  The children are
+    started as CHILD processes (never exec) with the program itself after `--`.  Returns (bytes per launch | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    if any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None, "this run is itself being profiled"
+    tot = {}
+    launches = 0
+    tmp = tempfile.mkdtemp(prefix="relax_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--traffic-child", "--workload", workload, "--clips-per-step", str(clips_per_step),
+                   "--precision", precision, "--gemm-split-k", str(split_k)]
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
+            if res.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode}): {res.stderr[-300:]}"
+            total, n = 0.0, 0
+            ids = set()
+            for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+                if r["Counter_Name"] != counter or not ("relax::gemm_x6" in r["Kernel_Name"] or "relax::conv1_x6" in r["Kernel_Name"]):
+                    continue
+                total += float(r["Counter_Value"])
+                ids.add(r["Dispatch_Id"])
+            tot[counter] = total * 1024.0          # KiB -> bytes
+            launches = len(ids)
+        if not launches:
+            return None, "no gemm_x6 dispatch in the PMC pass"
+        return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / launches, (
+            f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, one child pass each (1 warm-up + 1 step), "
+            f"(2 x FETCH_SIZE + WRITE_SIZE) over the {launches} gemm_x6 / conv1_x6 dispatches of the pass")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -189,6 +234,10 @@ def main():
                     help="0: no tail split-K - bits independent of the batch composition, i.e. of the number of ranks")
     ap.add_argument("--dump-matrix", default=None, help="dataset mode: rank 0 saves the gathered [n, F] matrix as .npy (tests)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short extra measurements of configs 2 / 4 / 5")
+    ap.add_argument("--no-measure-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only); a committed profile "
+                         "of the same workload, batch and precision is reported instead when there is one")
+    ap.add_argument("--traffic-child", action="store_true", help="(internal) one warm-up + one step of the workload, nothing else: the PMC target")
     ap.add_argument("--launch-check", action="store_true",
                     help="only rehearse the N-rank launch + collectives (no engine, no GPU needed): tests/test_bench_launch.py")
     args = ap.parse_args()
@@ -232,6 +281,17 @@ def main():
 
     if args.dataset_clips:
         dataset_mode(args, eng, rank, world, barrier, precision)
+        return
+    if args.traffic_child:      # the PMC target of measure_hbm_traffic: the same step function, one warm-up + one step, no JSON
+        n_res = args.resident_clips or 2
+        res_ = [torch.from_numpy(synth.synthetic_clip(T, H, W, clip_id=i, distinct=4)).cuda() for i in range(n_res)]
+        for i in range(2):
+            batch = [res_[(i * B + j) % n_res] for j in range(B)]
+            if args.workload.startswith("full"):
+                eng.full_clip_vectors(batch, flow=True)
+            else:
+                eng.clip_vectors(batch, resnet=True, vit=use_vit)
+        torch.cuda.synchronize()
         return
 
     def make_step(workload, clips_per_step, n_resident=2, seed_base=0, distinct=4):
@@ -349,6 +409,17 @@ def main():
     if world > 1:
         elapsed = rdist.all_reduce_max(elapsed, "cuda")
 
+    traffic, traffic_note = hbm_traffic_per_launch(args.workload, B, precision), (
+        "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (own passes, FETCH doubled per the gfx950 guide), from the "
+        "committed profile of this workload, batch and precision: profiles/r03_hbm_traffic.json (null when none matches the run)")
+    if world == 1 and not args.no_measure_traffic and x6:
+        torch.cuda.synchronize()
+        live, note = measure_hbm_traffic(args.workload, B, precision, args.gemm_split_k)
+        if live is not None:
+            traffic, traffic_note = live, note
+        else:
+            traffic_note += f"; the live measurement was not possible ({note})"
+
     if rank == 0:
         clips_total = args.steps * world * B
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -373,10 +444,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved * mult / (FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS),
                 "algorithmic_tflops": achieved,
-                "traffic": hbm_traffic_per_launch(args.workload, B, precision),
-                "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (own passes, FETCH doubled "
-                                "per the gfx950 guide), measured for this workload, batch and precision by tools/profile_round3.sh: "
-                                "profiles/r03_hbm_traffic.json (null when no committed profile matches the run)",
+                "traffic": traffic, "traffic_note": traffic_note,
                 "algorithmic_bytes_per_launch": gemm_alg_bytes / max(gemm_launches, 1),
                 "launches": gemm_launches, "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                 "algorithmic_gflop_per_launch": gemm_flops / max(gemm_launches, 1) / 1e9,

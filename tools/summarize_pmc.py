@@ -57,7 +57,8 @@ def hbm2(fetch_dir, write_dir, tag, workload="config3", clips=8, precision="bf16
             main_n += n[k]
     per = main_bytes / max(main_n, 1)
     lines.append(f"{main_prefix}*: {main_n} dispatches, corrected HBM bytes per dispatch = (2*FETCH + WRITE) = {per / 1e6:.1f} MB")
-    out = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{tag}.txt")
+    rnd = os.environ.get("RELAX_ROUND", "r02")
+    out = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic_{tag}.txt")
     open(out, "w").write("\n".join(lines) + "\n")
     if out_json:
         json.dump({"workload": workload, "clips_per_step": clips, "precision": precision, "hbm_bytes_per_launch": per,
@@ -65,7 +66,7 @@ def hbm2(fetch_dir, write_dir, tag, workload="config3", clips=8, precision="bf16
                    "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes on `bench.py --steps 2 "
                              "--warmup 1 --no-cpu-baseline --no-fast-mode --no-h2d`; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 "
                              "(gfx950 FETCH_SIZE reports half of 16-B/lane streaming reads)",
-                   "source": f"profiles/r02_hbm_traffic_{tag}.txt"}, open(os.path.join(ROOT, "profiles", out_json), "w"), indent=1)
+                   "source": f"profiles/{rnd}_hbm_traffic_{tag}.txt"}, open(os.path.join(ROOT, "profiles", out_json), "w"), indent=1)
     print("\n".join(lines))
 
 
