@@ -164,8 +164,8 @@ int relax_resnet50_features(relax_handle* h, const uint8_t* frags, int N, float*
                             float* const* taps_nchw, relax_stream stream);
 
 /* The clip path asks different things of the two groups of its batch: the layer stack of the ORIGINAL fragments and the pool
- * vector of the RESIDUAL fragments (src/main_fragment_layerstack.py:330-331: get_deep_feature(.., original_frag_path, ..,
- * 'layer_stack') and get_deep_feature(.., merged_frag_path, .., 'pool'); :341-345).  ONE forward over all N images:
+ * vector of the RESIDUAL fragments (src/main_fragment_layerstack.py:327-328: get_deep_feature(.., original_frag_path, ..,
+ * 'layer_stack') and get_deep_feature(.., merged_frag_path, .., 'pool'); :340-341).  ONE forward over all N images:
  *   images [0, n_layer_stack)  -> layer_stack fp32 [n_layer_stack, 13120]
  *   images [n_layer_stack, N)  -> pool        fp32 [N - n_layer_stack, 2051]
  * Same values as relax_resnet50_features on the respective images; the taps of the second group are neither reduced nor written

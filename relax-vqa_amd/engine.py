@@ -298,7 +298,7 @@ class RelaxEngine:
     def resnet50_clip_features(self, frags, n_layer_stack):
         """frags uint8 [N,224,224,3]: the first n_layer_stack images are original fragments (-> layer stack fp32
         [n_layer_stack,13120]), the others residual fragments (-> pool fp32 [N - n_layer_stack, 2051]); ONE forward
-        (src/main_fragment_layerstack.py:330-331).  Same values as resnet50_features on the respective images."""
+        (src/main_fragment_layerstack.py:327-328).  Same values as resnet50_features on the respective images."""
         frags = self._frags(frags)
         N = frags.shape[0]
         n_ls = int(n_layer_stack)
