@@ -141,7 +141,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int A_PIECES = BM * 6 / 64;
     constexpr int PPW = (PIECES + NW - 1) / NW;   // pieces per wave (a wave short of real pieces issues dummy ones)
     constexpr int A_PPW = A_PIECES / NW;
-    constexpr int DUMMY = 2 * STAGE;              // 1 KiB nobody reads
+    constexpr int NSTG = (M16 && !TAPS && !DUAL) ? 3 : 2;   // LDS stages (three: the 16x16x32 loop of the plain GEMMs, see X6_REGION16; the implicit-GEMM and two-source forms would spill)
+    constexpr int DUMMY = NSTG * STAGE;           // 1 KiB nobody reads
     static_assert(ROWS % 32 == 0 && TM >= 1 && TN >= 1 && YT % 2 == 0 && A_PIECES % NW == 0, "tile / wave layout mismatch");
     static_assert(!M16 || (TM == 4 && TN == 2 && PPW <= 7), "the 16x16x32 loop is written for 128 x 64 per wave");
     static_assert(!DUAL || !TAPS, "a second activation source goes with 1x1 contractions");
@@ -427,27 +428,35 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         /* registers and exposes the LDS latency every 64 cycles */                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
     }
-    // region: [wait, barrier, DMA of step k+2, B forms and A fragment 0 of step k+1, fragment 7 of step k, then fragments 0..6 of
-    // step k+1 each behind the read of the next one]
-#define X6_REGION16(xs_, has_next_, has_d_)                                                                             \
+    // region k: [wait, barrier, B forms and A fragment 0 of step k+1, fragment 7 of step k, then fragments 0..6 of step k+1 each
+    // behind the read of the next one]; xs_ = k & 1 (register set of B), st_ = k % NSTG (LDS stage of step k).
+    // Where the DMA goes (cycles per K step from the stamped build, ViT-B GEMMs, 3072 = the matrix pipes' own time):
+    //   two stages, all six pieces right behind the barrier (the 32x32x16 loop's place) ....... both waves of a SIMD stall in issue
+    //   two stages, one piece per MFMA group ............ 3.78 - 4.36 k (the last pieces have a third of a step to land)
+    //   two stages, three pieces in each of the first two groups ............ 3.71 - 3.90 k
+    //   THREE stages (DMA two steps ahead, counted vmcnt), three + three ..... 3.71 - 3.90 k: no change - latency is not the cost
+    //   three stages, one piece per MFMA group ........... 3.43 - 3.48 k = the loop with every DMA hitting L2 (3.43 k; no DMA: 3.32 k)
+    // PMC: with real traffic the TA address FIFO is full 3 x as long as VMEM instructions are active (SQ_VMEM_TA_ADDR_FIFO_FULL): a
+    // burst of pieces blocks the issuing wave - and its MFMAs, issue is in order - until the texture path has taken them, so the pieces
+    // are issued one at a time, a MFMA group apart, and the third stage gives the late ones a whole extra step to land.
+#define X6_REGION16(xs_, st_, has_next_, has_d_)                                                                        \
     {                                                                                                                   \
-        const char* sn_ = smem + ((xs_) ^ 1) * STAGE;                                                                   \
+        const char* sn_ = smem + (((st_) + 1) % NSTG) * STAGE;                                                          \
         if (has_next_) {                                                                                                \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+            /* own pieces of step k+1 have landed (three stages: those of step k+2, the newest PPW, stay in flight) */   \
+            if (NSTG == 3 && (has_d_)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");            \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
             __builtin_amdgcn_s_barrier();                                                                               \
             X6_READ_XB((xs_) ^ 1, sn_);                                                                                 \
             X6_READ_A16(0, 0, sn_);                                                                                     \
-            /* the DMA of step k+2 into the stage just freed, in the first two MFMA groups of the region: the issue */ \
-            /* cost of a piece hides under the group's MFMAs (all six right behind the barrier stall both waves of */  \
-            /* a SIMD: this MFMA shape leaves 8 of every 16 cycles for other instructions, the 32x32x16 one 24 of  */  \
-            /* 32), and every piece has most of a step to land                                                      */  \
-            if (has_d_) { _Pragma("unroll") for (int j = 0; j < (PPW + 1) / 2; ++j) X6_ISSUE_PIECE(xs_, j); }           \
+            if (NSTG == 2 && (has_d_)) { _Pragma("unroll") for (int j = 0; j < (PPW + 1) / 2; ++j) X6_ISSUE_PIECE(st_, j); } \
         }                                                                                                               \
         X6_MFMAS16(xs_, 1, 7);                                                                                          \
         if (has_next_) {                                                                                                \
             _Pragma("unroll") for (int e = 0; e < 7; ++e) {                                                             \
                 X6_READ_A16((e + 1) & 1, e + 1, sn_);                                                                   \
-                if (has_d_ && e == 0) { _Pragma("unroll") for (int j = (PPW + 1) / 2; j < PPW; ++j) X6_ISSUE_PIECE(xs_, j); } \
+                if (NSTG == 2 && (has_d_) && e == 0) { _Pragma("unroll") for (int j = (PPW + 1) / 2; j < PPW; ++j) X6_ISSUE_PIECE(st_, j); } \
+                if (NSTG == 3 && (has_d_) && e < PPW) X6_ISSUE_PIECE(st_, e);   /* the stage step k just left */             \
                 X6_MFMAS16((xs_) ^ 1, e & 1, e);                                                                        \
             }                                                                                                           \
             if (has_d_) X6_ISSUE_ADVANCE();                                                                             \
@@ -457,7 +466,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     const int nk = kt_end - kt_begin;
     X6_ISSUE(0);
     if (nk > 1) X6_ISSUE(1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    if (NSTG == 3 && nk > 2) X6_ISSUE(2);
+    // step 0 has landed; the younger steps stay in flight (vmcnt counts this wave's pieces in issue order)
+    if (NSTG == 3 && nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (M16) {
@@ -469,15 +481,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             X6_READ_A16((e + 1) & 1, e + 1, smem);
             X6_MFMAS16(0, e & 1, e);
         }
-        // region k: xs = k & 1 (register set of B = LDS stage); has_next = step k+1 exists; has_d = step k+2 exists
+        // has_next = step k+1 exists; has_d = step k + NSTG exists (its DMA is issued in region k); literal `true` in the steady state
         int k = 0;
-        for (; k + 3 < nk; k += 2) {
-            X6_REGION16(0, true, true);
-            X6_REGION16(1, true, true);
-        }
-        for (; k < nk; k += 2) {
-            X6_REGION16(0, k + 1 < nk, k + 2 < nk);
-            if (k + 1 < nk) X6_REGION16(1, k + 2 < nk, k + 3 < nk);
+        if constexpr (NSTG == 3) {   // six regions = one period of (register set, stage)
+            for (; k + 6 + 3 <= nk; k += 6) {
+                X6_REGION16(0, 0, true, true);
+                X6_REGION16(1, 1, true, true);
+                X6_REGION16(0, 2, true, true);
+                X6_REGION16(1, 0, true, true);
+                X6_REGION16(0, 1, true, true);
+                X6_REGION16(1, 2, true, true);
+            }
+            for (; k < nk; k += 6) {
+                X6_REGION16(0, 0, k + 1 < nk, k + 3 < nk);
+                if (k + 1 < nk) X6_REGION16(1, 1, k + 2 < nk, k + 4 < nk);
+                if (k + 2 < nk) X6_REGION16(0, 2, k + 3 < nk, k + 5 < nk);
+                if (k + 3 < nk) X6_REGION16(1, 0, k + 4 < nk, k + 6 < nk);
+                if (k + 4 < nk) X6_REGION16(0, 1, k + 5 < nk, k + 7 < nk);
+                if (k + 5 < nk) X6_REGION16(1, 2, k + 6 < nk, k + 8 < nk);
+            }
+        } else {
+            for (; k + 3 < nk; k += 2) {
+                X6_REGION16(0, 0, true, true);
+                X6_REGION16(1, 1, true, true);
+            }
+            for (; k < nk; k += 2) {
+                X6_REGION16(0, 0, k + 1 < nk, k + 2 < nk);
+                if (k + 1 < nk) X6_REGION16(1, 1, k + 2 < nk, k + 3 < nk);
+            }
         }
     } else {
     X6_READ_X(0, smem);
@@ -522,7 +553,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int EP_ROWS = 64;
     constexpr int C8 = BN / 8;
     static_assert(NT % C8 == 0 && (EP_ROWS * C8) % NT == 0, "epilogue chunk must divide over the workgroup");
-    static_assert(EP_ROWS * LDC * 4 <= 2 * STAGE, "epilogue chunk must fit the staging LDS");
+    static_assert(EP_ROWS * LDC * 4 <= 2 * STAGE, "epilogue chunk must fit the staging LDS");   // (the first two stages)
     constexpr int EP_STEP = NT / C8;
     constexpr int EP_ITERS = EP_ROWS / EP_STEP;
     const int half = lane >> 5;
@@ -763,7 +794,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
         RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
         p.partial = static_cast<float*>(h->splitk_ws.p);
     }
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * kChunkBytes + 1024;
+    constexpr size_t lds = ((M16 && !TAPS && !DUAL) ? 3 : 2) * (size_t)(BM + BN) * kChunkBytes + 1024;
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
         RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL>),
