@@ -67,6 +67,32 @@ def test_rccl_all_gather_single_rank():
         dist.destroy_process_group()
 
 
+def test_dataset_driver_under_rccl_single_rank():
+    """The dataset driver with an initialised nccl (= RCCL) process group: the device all_gather_into_tensor, the error-list
+    all_gather_object and the nccl barrier (device named) are the branches an 8-GPU run takes; world size 1 is all one box offers."""
+    import torch.distributed as dist
+    from relax_vqa_amd import dataset
+    from relax_vqa_amd import distributed as rd
+    from tests.gpu_common import rn50_weights, vit_weights
+    rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        clips = [synth.synthetic_clip(2, 240, 320, clip_id=70 + i) for i in range(3)]
+        src = lambda i: None if i == 1 else clips[i]      # noqa: E731
+        matrix, errors = dataset.extract_dataset_clips(src, 3, eng, clips_per_step=2)      # rank / world from the process group
+        rd.barrier()
+        torch.cuda.synchronize()
+        assert matrix.shape == (3, 19779) and [i for i, _ in errors] == [1]
+        assert bool(torch.isnan(matrix[1]).all()) and bool(torch.isfinite(matrix[[0, 2]]).all())
+    finally:
+        dist.destroy_process_group()
+
+
 def test_pinned_feeder_overlaps_and_preserves_data():
     from relax_vqa_amd.feeder import PinnedClipFeeder
     clips = [torch.from_numpy(synth.synthetic_clip(2, 64, 96, clip_id=50 + i)).pin_memory() for i in range(3)]
