@@ -126,7 +126,8 @@ def measure_hbm_traffic(workload, clips_per_step, precision, split_k):
     """roofline.traffic measured in THIS run: two child passes of this script under rocprofv3 (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`:
     separate passes, kernel-trace only, as the gfx950 guide prescribes; FETCH_SIZE doubled: it reports half of a 16-B-per-lane
     streaming read), one warm-up + one step each; bytes per launch of the dominant kernel family (gemm_x6*, conv1_x6).  The children are
-    started as CHILD processes (never exec) with the program itself after `--`.  Returns (bytes per launch | None, note)."""
+    started as CHILD processes (never exec) with the program itself after `--`, each bounded to 150 s.
+    Returns (bytes per launch | None, note)."""
     import csv
     import glob
     import shutil
@@ -136,21 +137,19 @@ def measure_hbm_traffic(workload, clips_per_step, precision, split_k):
         return None, "rocprofv3 not on PATH"
     if any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
         return None, "this run is itself being profiled"
-    tot = {}
-    launches = 0
     tmp = tempfile.mkdtemp(prefix="relax_pmc_", dir="/tmp")
+    tot, launches = {}, 0
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.abspath(__file__), "--traffic-child", "--workload", workload, "--clips-per-step", str(clips_per_step),
                    "--precision", precision, "--gemm-split-k", str(split_k)]
-            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=150)
             files = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
             if res.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode}): {res.stderr[-300:]}"
-            total, n = 0.0, 0
-            ids = set()
+            total, ids = 0.0, set()
             for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
                 if r["Counter_Name"] != counter or not ("relax::gemm_x6" in r["Kernel_Name"] or "relax::conv1_x6" in r["Kernel_Name"]):
                     continue
@@ -163,6 +162,8 @@ def measure_hbm_traffic(workload, clips_per_step, precision, split_k):
         return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / launches, (
             f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, one child pass each (1 warm-up + 1 step), "
             f"(2 x FETCH_SIZE + WRITE_SIZE) over the {launches} gemm_x6 / conv1_x6 dispatches of the pass")
+    except subprocess.TimeoutExpired:
+        return None, "a rocprofv3 pass did not finish in 150 s"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

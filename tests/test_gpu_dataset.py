@@ -51,6 +51,12 @@ def test_dataset_rows_equal_clip_vector_and_a_bad_clip_is_a_nan_row(tmp_path):
             want = torch.cat([f["resnet"], f["vit"]], dim=1).cpu().numpy()
             assert rows.shape == want.shape and np.array_equal(rows, want), f"per-frame file of clip {i}"
         assert not os.path.exists(os.path.join(out_dir, sampling.feature_file_name(2, "resnet50")))
+        # and against the oracle pipeline (de-duplicated schedule), the smallest clip: row = mean over frames of [resnet | vit]
+        from oracle import pipeline_ref
+        want = pipeline_ref.clip_features(good[1], synth.resnet50_state_dict(), synth.vit_state_dict("vit_base"), schedule="dedup")
+        want = np.concatenate([want["resnet"], want["vit"]], axis=1).mean(axis=0)
+        for a, b, nm in ((0, 13120, "layer stack"), (13120, 15171, "pool"), (15171, 19779, "vit")):
+            assert_close(matrix[1, a:b], want[a:b], f"dataset row 1 vs the oracle pipeline: {nm}")
         # resume from the files: nothing healthy goes through the engine again, same matrix to fp32 rounding of the host mean
         calls = []
         orig = eng.clip_vectors
