@@ -18,21 +18,26 @@
 // K loop: the loop has no VALU work, and tiles go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) without
 // touching registers.
 //
-// Structure: 256x256 tile on 8 waves (2 x 4, 128x64 per wave, 8 accumulators of 32x32), BK = 16, TWO LDS stages of
-// 512 rows x 96 B (96 KB + a 1 KB landing page for the padding pieces), one raw s_barrier per K step.  The K loop is
-// rotated into barrier-to-barrier "regions": region k issues the DMA of step k+1 into the stage step k-1 just left,
-// reads the fragments of step k+1 ahead of their MFMAs (X operand double-buffered in registers, Y in halves) and
-// runs the 48 MFMAs of step k; counted s_waitcnt vmcnt keeps loads in flight across barriers.  LDS rows are 96 B; the
-// two 16-byte halves of a plane are swapped in rows with bit 3 set, which makes the ds_read_b128 fragment reads
-// bank-conflict free (the permutation is applied on the SOURCE offset of the DMA, the LDS image stays linear).  Rows
-// beyond M and the padding taps of an implicit-GEMM convolution use an out-of-range buffer offset, which the buffer
-// unit answers with zeros.  Narrower outputs run the same loop on 4 waves (256x128, 256x64: two workgroups per CU);
-// the last, partial round of tiles is split along K (splitk_finish_x6 adds the slices in a fixed order).  The
-// epilogue goes through LDS in 64-row passes so that every store instruction writes whole 512-byte row segments, and
-// can add bias / an sp3 or fp32 residual, apply ReLU / GELU, write fp32 and / or sp3, and emit 16-row column sums for
-// the global-average-pool taps.  What was measured and NOT adopted (three stages, staggered starts, pinned
-// instruction order, non-temporal stores, 128x256 tiles on two workgroups per CU, K-slice phase starts) is recorded in
-// DESIGN.md section 3.2; none of that code is kept here.
+// Structure: BK = 16, LDS stages of (BM + BN) rows x 96 B filled by DMA, one raw s_barrier per K step; the K loop is rotated into
+// barrier-to-barrier "regions" that read the fragments of the next step ahead of their MFMAs; counted s_waitcnt vmcnt keeps
+// loads in flight across barriers.  Two forms of the loop:
+//   * 256x256 tile on 8 waves (2 x 4, 128x64 per wave, one workgroup per CU), template flag M16: the six products on
+//     v_mfma_f32_16x16x32_bf16, TWO per instruction (the 32-deep K of the instruction takes two planes of the chunk), B forms
+//     double-buffered in registers, A fragments streamed; THREE stages (144 KB) with the DMA pieces of step k+3 issued one per
+//     MFMA group (plain GEMMs; the implicit-GEMM and two-source instantiations: two stages).  See the comments at X6_MFMAS16 /
+//     X6_REGION16 for why (the chip's clock on this shape; the texture-address FIFO).
+//   * 256x128 / 256x64 tiles on 4 waves (two workgroups per CU) for N = 128 / 64: v_mfma_f32_32x32x16_bf16, one product per
+//     instruction, two stages, X operand double-buffered in registers, Y in halves; LDS rows hold the two 16-byte halves of a
+//     plane swapped in rows with bit 3 set, which makes these ds_read_b128 fragment reads bank-conflict free (the permutation
+//     is applied on the SOURCE offset of the DMA; the M16 form uses the linear image, conflict-free for ITS lane map).
+// Rows beyond M and the padding taps of an implicit-GEMM convolution use an out-of-range buffer offset, which the buffer unit
+// answers with zeros.  The last, partial round of tiles is split along K (splitk_finish_x6 adds the slices in a fixed order;
+// cost model: host_logic.cpp).  DUAL: a second activation source for the K steps past K1 (ResNet conv3 + downsample in one
+// contraction).  The epilogue goes through LDS in 64-row passes so that every store instruction writes whole 512-byte row
+// segments, and can add bias / an sp3 or fp32 residual, apply ReLU / GELU, write fp32 (optionally only the first out_rows rows)
+// and / or sp3, and emit 16-row column sums for the global-average-pool taps.  What was measured and NOT adopted (staggered
+// starts, pinned instruction order of the 32x32 loop, non-temporal stores, 128x256 tiles on two workgroups per CU, K-slice phase
+// starts, static wave priorities) is recorded in DESIGN.md sections 3.2 / 3.2.1; none of that code is kept here.
 #include "relax_internal.h"
 #include "host_logic.h"
 #include "sp3.h"
