@@ -192,6 +192,15 @@ def test_step_is_graph_capturable():
     clip = torch.from_numpy(synth.synthetic_clip(2, 240, 320, clip_id=77)).cuda()
     ref = eng.clip_vectors([clip])
     torch.cuda.synchronize()
+    poison = eng.get_option("debug_poison")     # the debugging aid fills workspaces synchronously: not a thing to capture
+    eng.set_option("debug_poison", 0)
+    try:
+        _capture_and_replay(eng, clip, ref)
+    finally:
+        eng.set_option("debug_poison", poison)
+
+
+def _capture_and_replay(eng, clip, ref):
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
