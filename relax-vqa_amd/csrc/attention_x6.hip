@@ -114,24 +114,29 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
 #define A6_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
     // Q^T fragments: lane (query li, half) needs d = 16 s + 8 half .. + 7 of its query; head_dim^-0.5 and log2(e) are folded
     // into Q (as in the fp32 kernel), so the softmax exponential is one v_exp_f32
-#define A6_LOAD_Q(item_)                                                                                             \
+#define A6_REQUEST_Q(item_)   /* the 64 fp32 of this lane's query half-rows into registers (requested early, split later) */ \
     {                                                                                                                \
         const int qrow_ = wave * 32 + li;                                                                            \
         const float* q_ = qkv + (int64_t)((item_) / heads) * A6_NTOK * ld + ((item_) % heads) * 64 +                 \
                           (int64_t)(qrow_ < A6_NTOK ? qrow_ : A6_NTOK - 1) * ld + 8 * half;                          \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                              \
-            const a6_f32x4 a_ = *reinterpret_cast<const a6_f32x4*>(q_ + 16 * s) * (0.125f * 1.44269504088896341f);   \
-            const a6_f32x4 b_ = *reinterpret_cast<const a6_f32x4*>(q_ + 16 * s + 4) * (0.125f * 1.44269504088896341f); \
-            sp3_u32x4 hi_, mid_, lo_;                                                                                \
-            split3_x8(a_, b_, hi_, mid_, lo_);                                                                       \
-            qp[s][0] = hi_;                                                                                          \
-            qp[s][1] = mid_;                                                                                         \
-            qp[s][2] = lo_;                                                                                          \
+            qraw[2 * s] = *reinterpret_cast<const a6_f32x4*>(q_ + 16 * s);                                           \
+            qraw[2 * s + 1] = *reinterpret_cast<const a6_f32x4*>(q_ + 16 * s + 4);                                   \
         }                                                                                                            \
     }
+#define A6_SPLIT_Q()                                                                                                 \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                  \
+        sp3_u32x4 hi_, mid_, lo_;                                                                                    \
+        split3_x8(qraw[2 * s] * (0.125f * 1.44269504088896341f), qraw[2 * s + 1] * (0.125f * 1.44269504088896341f), hi_, mid_, lo_); \
+        qp[s][0] = hi_;                                                                                              \
+        qp[s][1] = mid_;                                                                                             \
+        qp[s][2] = lo_;                                                                                              \
+    }
 
+    a6_f32x4 qraw[8];
     A6_DMA(item, 1);
-    A6_LOAD_Q(item);
+    A6_REQUEST_Q(item);
+    A6_SPLIT_Q();
     A6_WAIT_DMA();
     __syncthreads();
     A6_STORE_K();
@@ -186,7 +191,10 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
         A6_STORE_V();             // V^T takes K's place
         __syncthreads();
         const int next = item + gridDim.x;
-        if (next < total_items) A6_DMA(next, 1);   // K rows of the next item: in flight during the output phase
+        if (next < total_items) {
+            A6_DMA(next, 1);       // K rows of the next item: in flight during the output phase
+            A6_REQUEST_Q(next);    // and its queries: the registers of this item's Q fragments are free until the next scores
+        }
 
         // ---- output: O^T[d, query] = V^T P^T over 14 steps of 16 keys ---------------------------------------------------
         floatx16 oacc[2];
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
             }
         }
         if (next >= total_items) break;
-        A6_LOAD_Q(next);
+        A6_SPLIT_Q();
         A6_WAIT_DMA();
         __syncthreads();          // every wave is done with V^T, and the K rows have landed
         A6_STORE_K();             // next item's K
@@ -261,7 +269,8 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
 #undef A6_WAIT_DMA
 #undef A6_STORE_K
 #undef A6_STORE_V
-#undef A6_LOAD_Q
+#undef A6_REQUEST_Q
+#undef A6_SPLIT_Q
 #endif
 }
 
