@@ -145,25 +145,37 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
     while (true) {
         A6_DMA(item, 2);   // V rows: in flight during the score phase
         // ---- scores: S^T tile kt = K[kt] Q^T, 4 d-steps x 6 partial products (smallest first) -------------------------
+        // The K fragments of group g + 1 (one 16-deep d step of one key tile: three planes) are read while the six MFMAs of group g
+        // run: left to the compiler the loop came out as read - wait - MFMA with the LDS latency exposed at every group (a wave
+        // alone on its SIMD took 3 x the MFMAs' own time for this phase); __builtin_amdgcn_sched_barrier pins the pipeline.
         floatx16 sacc[A6_KT];
-#pragma unroll
-        for (int kt = 0; kt < A6_KT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
-            const char* kp = smem + (kt * 32 + li) * A6_KROW + half * 16;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const a6_bf16x8 kh = *reinterpret_cast<const a6_bf16x8*>(kp + s * kChunkBytes);
-                const a6_bf16x8 km = *reinterpret_cast<const a6_bf16x8*>(kp + s * kChunkBytes + 32);
-                const a6_bf16x8 kl = *reinterpret_cast<const a6_bf16x8*>(kp + s * kChunkBytes + 64);
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, as_frag(qp[s][0]), sacc[kt], 0, 0, 0);
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, as_frag(qp[s][1]), sacc[kt], 0, 0, 0);
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, as_frag(qp[s][2]), sacc[kt], 0, 0, 0);
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, as_frag(qp[s][0]), sacc[kt], 0, 0, 0);
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, as_frag(qp[s][1]), sacc[kt], 0, 0, 0);
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, as_frag(qp[s][0]), sacc[kt], 0, 0, 0);
-            }
+        a6_bf16x8 kf[2][3];
+#define A6_READ_K(buf_, g_)                                                                                          \
+        {                                                                                                            \
+            const char* kp_ = smem + (((g_) >> 2) * 32 + li) * A6_KROW + half * 16 + ((g_) & 3) * kChunkBytes;       \
+            kf[buf_][0] = *reinterpret_cast<const a6_bf16x8*>(kp_);                                                  \
+            kf[buf_][1] = *reinterpret_cast<const a6_bf16x8*>(kp_ + 32);                                             \
+            kf[buf_][2] = *reinterpret_cast<const a6_bf16x8*>(kp_ + 64);                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
         }
+        A6_READ_K(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4 * A6_KT; ++g) {
+            const int kt = g >> 2, s = g & 3, b = g & 1;
+            if (g + 1 < 4 * A6_KT) A6_READ_K((g + 1) & 1, g + 1);
+            if (s == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+            }
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][2], as_frag(qp[s][0]), sacc[kt], 0, 0, 0);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][1], as_frag(qp[s][1]), sacc[kt], 0, 0, 0);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][0], as_frag(qp[s][2]), sacc[kt], 0, 0, 0);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][1], as_frag(qp[s][0]), sacc[kt], 0, 0, 0);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][0], as_frag(qp[s][1]), sacc[kt], 0, 0, 0);
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][0], as_frag(qp[s][0]), sacc[kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef A6_READ_K
         // sacc[kt][r] = score(query li, key kt*32 + (r&3) + 8*(r>>2) + 4*half) * log2(e)
         float mx = -INFINITY;
 #pragma unroll
@@ -191,38 +203,55 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
         A6_STORE_V();             // V^T takes K's place
         __syncthreads();
         const int next = item + gridDim.x;
-        if (next < total_items) {
-            A6_DMA(next, 1);       // K rows of the next item: in flight during the output phase
-            A6_REQUEST_Q(next);    // and its queries: the registers of this item's Q fragments are free until the next scores
-        }
+        if (next < total_items) A6_DMA(next, 1);       // K rows of the next item: in flight during the output phase
 
         // ---- output: O^T[d, query] = V^T P^T over 14 steps of 16 keys ---------------------------------------------------
+        // Pipelined like the scores: the six V^T fragments of step c + 1 are read, and its probabilities split into planes, while
+        // the twelve MFMAs of step c run.  Registers 8*(c&1) .. +7 of score tile c>>1 are keys 16c + 8*(j>>2) + 4*half + (j&3):
+        // the B fragment of step c.
         floatx16 oacc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+        a6_bf16x8 vf[2][2][3];
+        sp3_u32x4 pp[2][3];
+#define A6_READ_V(buf_, c_)                                                                                          \
+        _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) {                                                           \
+            const char* vp_ = smem + (dt * 32 + li) * A6_VROW + (c_) * kChunkBytes + half * 16;                      \
+            vf[buf_][dt][0] = *reinterpret_cast<const a6_bf16x8*>(vp_);                                              \
+            vf[buf_][dt][1] = *reinterpret_cast<const a6_bf16x8*>(vp_ + 32);                                         \
+            vf[buf_][dt][2] = *reinterpret_cast<const a6_bf16x8*>(vp_ + 64);                                         \
+        }
+#define A6_SPLIT_P(buf_, c_)                                                                                         \
+        split3_x8((sp3_f32x4){sacc[(c_) >> 1][8 * ((c_) & 1) + 0], sacc[(c_) >> 1][8 * ((c_) & 1) + 1],              \
+                              sacc[(c_) >> 1][8 * ((c_) & 1) + 2], sacc[(c_) >> 1][8 * ((c_) & 1) + 3]},             \
+                  (sp3_f32x4){sacc[(c_) >> 1][8 * ((c_) & 1) + 4], sacc[(c_) >> 1][8 * ((c_) & 1) + 5],              \
+                              sacc[(c_) >> 1][8 * ((c_) & 1) + 6], sacc[(c_) >> 1][8 * ((c_) & 1) + 7]},             \
+                  pp[buf_][0], pp[buf_][1], pp[buf_][2])
+        A6_READ_V(0, 0);
+        A6_SPLIT_P(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 2 * A6_KT; ++c) {
-            // registers 8*(c&1) .. +7 of score tile c>>1 are keys 16c + 8*(j>>2) + 4*half + (j&3): the B fragment of step c
-            sp3_u32x4 ph, pm, pl;
-            split3_x8((sp3_f32x4){sacc[c >> 1][8 * (c & 1) + 0], sacc[c >> 1][8 * (c & 1) + 1], sacc[c >> 1][8 * (c & 1) + 2],
-                                  sacc[c >> 1][8 * (c & 1) + 3]},
-                      (sp3_f32x4){sacc[c >> 1][8 * (c & 1) + 4], sacc[c >> 1][8 * (c & 1) + 5], sacc[c >> 1][8 * (c & 1) + 6],
-                                  sacc[c >> 1][8 * (c & 1) + 7]},
-                      ph, pm, pl);
+            const int b = c & 1;
+            if (c + 1 < 2 * A6_KT) {
+                A6_READ_V(b ^ 1, c + 1);
+                __builtin_amdgcn_sched_barrier(0);       // the reads go out first ...
+                A6_SPLIT_P(b ^ 1, c + 1);                // ... the split's VALU interleaves with the MFMAs below
+            }
+            if (c == A6_KT && next < total_items) A6_REQUEST_Q(next);   // the next item's queries (half of the score registers are free by now)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const char* vp = smem + (dt * 32 + li) * A6_VROW + c * kChunkBytes + half * 16;
-                const a6_bf16x8 vh = *reinterpret_cast<const a6_bf16x8*>(vp);
-                const a6_bf16x8 vm = *reinterpret_cast<const a6_bf16x8*>(vp + 32);
-                const a6_bf16x8 vl = *reinterpret_cast<const a6_bf16x8*>(vp + 64);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, as_frag(ph), oacc[dt], 0, 0, 0);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, as_frag(pm), oacc[dt], 0, 0, 0);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, as_frag(pl), oacc[dt], 0, 0, 0);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, as_frag(ph), oacc[dt], 0, 0, 0);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, as_frag(pm), oacc[dt], 0, 0, 0);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, as_frag(ph), oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[b][dt][2], as_frag(pp[b][0]), oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[b][dt][1], as_frag(pp[b][1]), oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[b][dt][0], as_frag(pp[b][2]), oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[b][dt][1], as_frag(pp[b][0]), oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[b][dt][0], as_frag(pp[b][1]), oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[b][dt][0], as_frag(pp[b][0]), oacc[dt], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+#undef A6_READ_V
+#undef A6_SPLIT_P
         // oacc[dt][r] = O(query li, d = dt*32 + (r&3) + 8*(r>>2) + 4*half): runs of 4 consecutive d.  The lane^32 partner
         // holds the runs in between: after swapping two runs per tile each lane owns two units of 8 consecutive d
         //   half 0: d = dt*32 + 0..7 and 16..23        half 1: d = dt*32 + 8..15 and 24..31
