@@ -89,13 +89,14 @@ struct X6Params {
     const float* bias;
     const float* residual;   // fp32 [M][N] or null
     const char* residual_sp3;   // the residual as split planes [M][N*6 B] (exact: hi + mid + lo), or null
-    float* gap;              // fused spatial mean, stage 1: sums of the outputs over aligned 16-row groups [M/16][N], or null
+    float* gap;              // fused spatial mean, stage 1: sums of the outputs over aligned groups of 16 (or 4: gap_shift) rows [M/16][N], or null
     float* out;              // fp32 [M][N] or null
     char* out_sp3;           // sp3 [M][N*6 B] or null
     float* partial;          // split-K partial tiles
     int M, N, K;
     int K1, H2, W2, Cin2, stride2;   // DUAL only
     int out_rows, gap_rows;          // rows below these limits get the fp32 output / the group sums (default M)
+    int gap_shift;                   // log2 of the rows per group of the fused spatial mean: 4, or 2 for the 14x14 maps (196 rows per image)
     int no_split;
     int H, W, Cin, Ho, Wo, KW, stride, pad;
     int act;
@@ -678,18 +679,31 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             }
         }
         if (p.gap && slice < 0) {
-            // fused spatial mean, stage 1: sums over the aligned 16-row groups of this chunk, rows added in order.  Images start
-            // at multiples of 16 rows (the launcher checks Ho*Wo % 16 == 0), so a group never spans two images and the
-            // grouping does not depend on where in the batch an image sits: bits are batch-invariant.
+            // fused spatial mean, stage 1: sums over the aligned 16-row (14x14 maps: 4-row) groups of this chunk, rows added in order.
+            // Images start at multiples of the group (the launcher checks Ho*Wo % group == 0), so a group never spans two images and
+            // the grouping does not depend on where in the batch an image sits: bits are batch-invariant.
             __syncthreads();
-            for (int e = tid; e < (EP_ROWS / 16) * BN; e += NT) {
-                const int g = e / BN, col = e - g * BN;
-                const int mg = m0 + pass * EP_ROWS + g * 16;
-                if (mg < p.gap_rows) {
-                    float t = 0.f;
+            if (p.gap_shift == 4) {
+                for (int e = tid; e < (EP_ROWS / 16) * BN; e += NT) {
+                    const int g = e / BN, col = e - g * BN;
+                    const int mg = m0 + pass * EP_ROWS + g * 16;
+                    if (mg < p.gap_rows) {
+                        float t = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) t += stg[(g * 16 + r) * LDC + col];
-                    p.gap[(int64_t)(mg >> 4) * p.N + n0 + col] = t;
+                        for (int r = 0; r < 16; ++r) t += stg[(g * 16 + r) * LDC + col];
+                        p.gap[(int64_t)(mg >> 4) * p.N + n0 + col] = t;
+                    }
+                }
+            } else {
+                for (int e = tid; e < (EP_ROWS / 4) * BN; e += NT) {
+                    const int g = e / BN, col = e - g * BN;
+                    const int mg = m0 + pass * EP_ROWS + g * 4;
+                    if (mg < p.gap_rows) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) t += stg[(g * 4 + r) * LDC + col];
+                        p.gap[(int64_t)(mg >> 2) * p.N + n0 + col] = t;
+                    }
                 }
             }
         }
@@ -836,6 +850,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     p.no_split = d.no_split;
     p.out_rows = d.out_rows > 0 && d.out_rows < p.M ? d.out_rows : p.M;
     p.gap_rows = d.gap_rows > 0 && d.gap_rows < p.M ? d.gap_rows : p.M;
+    p.gap_shift = (d.Ho * d.Wo) % 16 == 0 ? 4 : 2;
     p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Ho = d.Ho; p.Wo = d.Wo;
     p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
     p.act = d.act;
@@ -846,7 +861,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, (int64_t)p.K * 6 * 256 < kMaxRecords, "x6 conv/gemm: K=%d too large", p.K);
     RELAX_REQUIRE(h, d.out || d.out_sp3 || d.gap_groups, "x6 conv/gemm: no output requested");
     RELAX_REQUIRE(h, !(d.residual && d.residual_sp3), "x6 conv/gemm: two residuals");
-    RELAX_REQUIRE(h, !d.gap_groups || ((d.Ho * d.Wo) % 16 == 0 && p.M % 16 == 0), "x6 conv: the fused spatial mean needs Ho*Wo %% 16 == 0");
+    RELAX_REQUIRE(h, !d.gap_groups || (d.Ho * d.Wo) % 4 == 0, "x6 conv: the fused spatial mean needs Ho*Wo %% 4 == 0");
     RELAX_REQUIRE(h, !taps || (d.pad >= 0 && d.KH * d.KW <= 32), "x6 conv: bad padding, or more than 32 taps (%dx%d)", d.KH, d.KW);
     RELAX_REQUIRE(h, taps || d.pad == 0, "x6 conv: 1x1 with padding is not supported");
     RELAX_REQUIRE(h, !d.in2 || (!taps && d.stride == 1 && d.Cin2 % 16 == 0 && d.stride2 >= 1 && p.N % 256 == 0 &&

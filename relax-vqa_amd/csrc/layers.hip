@@ -406,7 +406,9 @@ __global__ __launch_bounds__(256) void gap_finish(const float* __restrict__ part
     out[(int64_t)n * out_stride + c] = t / (float)HW;
 }
 
-// stage 2 of the spatial mean fused into the bf16x6 epilogue: out[n, c] = (sum of the HW/16 group sums of image n, in order) / HW
+// stage 2 of the spatial mean fused into the bf16x6 epilogue: out[n, c] = (sum of the G group sums of image n, in order) / HW.
+// The loads of 16 groups are in flight together, the additions keep the order (one load per addition left the kernel waiting on
+// memory latency G times: 100 us for 100 MB of group sums).
 __global__ __launch_bounds__(256) void gap_groups_finish(const float* __restrict__ groups, float* __restrict__ out, int Nimg,
                                                          int G, int HW, int C, int64_t out_stride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -414,15 +416,25 @@ __global__ __launch_bounds__(256) void gap_groups_finish(const float* __restrict
     const int n = (int)(i / C), c = (int)(i % C);
     const float* g = groups + (int64_t)n * G * C + c;
     float t = 0.f;
-    for (int k = 0; k < G; ++k) t += g[(int64_t)k * C];
+    int k = 0;
+    for (; k + 16 <= G; k += 16) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = g[(int64_t)(k + j) * C];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += v[j];
+    }
+    for (; k < G; ++k) t += g[(int64_t)k * C];
     out[(int64_t)n * out_stride + c] = t / (float)HW;
 }
 
+// group = rows per group sum: 16, or 4 where HW is a multiple of 4 only (the 14x14 maps)
 int launch_gap_groups_finish(relax_handle* h, const float* groups, float* out, int Nimg, int HW, int C, int64_t out_stride,
                              hipStream_t s) {
-    RELAX_REQUIRE(h, HW % 16 == 0 && Nimg > 0 && C > 0, "gap_groups_finish: bad shape HW=%d C=%d", HW, C);
+    RELAX_REQUIRE(h, HW % 4 == 0 && Nimg > 0 && C > 0, "gap_groups_finish: bad shape HW=%d C=%d", HW, C);
+    const int group = HW % 16 == 0 ? 16 : 4;
     hipLaunchKernelGGL(gap_groups_finish, dim3((unsigned)(((int64_t)Nimg * C + 255) / 256)), dim3(256), 0, s, groups, out, Nimg,
-                       HW / 16, HW, C, out_stride);
+                       HW / group, HW, C, out_stride);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }

@@ -82,7 +82,7 @@ struct ConvDescX6 {
     const float* bias;      // [Cout] or null
     const float* residual;  // fp32 [M, Cout] or null
     const void* residual_sp3;  // the residual as split planes instead (exact), or null
-    float* gap_groups;      // fused spatial mean, stage 1: sums over aligned 16-row groups [M/16][Cout], or null
+    float* gap_groups;      // fused spatial mean, stage 1: sums over aligned 16-row groups [M/16][Cout] (Ho*Wo % 16 != 0: 4-row groups [M/4][Cout]), or null
     float* out;             // fp32 [M, Cout] or null
     void* out_sp3;          // sp3 [M][Cout*6 B] or null (at least one output)
     int act;                // 0 none, 1 relu, 2 gelu(erf)

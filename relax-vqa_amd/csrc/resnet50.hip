@@ -359,8 +359,8 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
         RELAX_TRY(launch_bn_relu_maxpool_sp3(h, bufA, rn.bn1_scale, rn.bn1_shift, spa, N, 112, 112, 64, s));
         // A block output exists as split planes always (next convolutions, next residual: hi + mid + lo is the fp32 value,
         // exactly) and as fp32 only where something needs it, and only for the images that need it: the tap export, the spatial
-        // mean of the 14x14 / 7x7 taps of the layer-stack images (196 and 49 rows per image do not divide into the 16-row groups
-        // of the mean fused into the epilogue), the last block's map of the pool images.
+        // mean of the 7x7 taps of the layer-stack images (49 rows per image do not divide into the 16- or 4-row groups of the
+        // mean fused into the epilogue), the last block's map of the pool images.
         const float* cur32 = nullptr;
         char* cursp = spa;
         char* othersp = spb;
@@ -373,7 +373,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             const bool want_mean = tapped && layer_stack;
             const bool want_export = tapped && taps_nchw && taps_nchw[blk.tap];
             const bool is_last = &blk == &rn.blocks.back();
-            const bool fuse_mean = want_mean && HWo % 16 == 0;
+            const bool fuse_mean = want_mean && HWo % 4 == 0;
             const bool pool_needs32 = is_last && pool && !pool_from_stack;
             const bool need32 = want_export || (want_mean && !fuse_mean) || pool_needs32;
             // fp32 rows: every image for an export or the pool images behind the layer-stack ones, else the layer-stack images only
@@ -387,7 +387,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             d.out = need32 ? out32 : nullptr; d.out_rows = rows32;
             d.out_sp3 = othersp;
             d.gap_groups = fuse_mean ? gapws : nullptr; d.gap_rows = n_ls * HWo;
-            d.no_split = tapped && HWo % 16 == 0;   // a launch that fuses the mean when the layer stack is asked for runs unsplit either
+            d.no_split = tapped && HWo % 4 == 0;   // a launch that fuses the mean when the layer stack is asked for runs unsplit either
                                                     // way: the pool vector's bits do not depend on whether the layer stack is requested
             if (blk.has_down) {
                 // conv3 and the downsample convolution in ONE contraction over K = [conv2 output | block input sampled with the
