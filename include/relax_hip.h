@@ -193,9 +193,10 @@ int relax_mlp_head(relax_handle* h, const float* features, int n, float* scores,
 /* ---- operator level (what the backbones are built from; parity-tested one by one) ------------ */
 /* out[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + residual[M,N]);  act: 0 none, 1 relu, 2 gelu(erf).
  * fp32 in, fp32 MFMA accumulate.  K % 32 == 0 (bf16x6: K % 16 == 0), N % 64 == 0.  bias/residual may be NULL; every pointer
- * 16-byte aligned.  These operator-level entry points are test / bench paths: under "gemm_precision" 2 (default) BOTH
+ * 16-byte aligned.  These operator-level entry points are test / bench paths: under "gemm_precision" 2 (default) the
  * operands are converted to split planes on every call (two extra kernels, (M+N)*K*6 bytes; the model drivers keep weights
- * and activations in that format instead), into a workspace the handle owns - like every entry point they must not run
+ * and activations in that format instead; where N % 256 != 0 only W is converted: the 64 / 128-column form of the kernel
+ * splits the fp32 rows of A in its K loop, as ResNet-50's layer1 / layer2 do), into a workspace the handle owns - like every entry point they must not run
  * concurrently on two streams of one handle.  Finite operands up to 3.38e38 (csrc/sp3.h); beyond: "gemm_precision" 0. */
 int relax_op_gemm(relax_handle* h, const float* A, const float* W, const float* bias, const float* residual,
                   float* out, int M, int N, int K, int act, relax_stream stream);

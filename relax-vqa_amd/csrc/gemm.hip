@@ -694,13 +694,20 @@ int relax_op_gemm(relax_handle* h, const float* A, const float* W, const float* 
         // operator-level entry under "bf16x6": both operands are converted to split planes here (the model drivers
         // keep weights and activations in that format instead)
         RELAX_REQUIRE(h, K % 16 == 0, "relax_op_gemm (bf16x6): K=%d must be a multiple of 16", K);
-        const size_t a_bytes = (size_t)M * K * 6, w_bytes = (size_t)N * K * 6;
+        // (64 / 128-column problems: the kernel takes the fp32 rows of A as they are and splits them in its K loop)
+        const bool a_f32 = N % 256 != 0;
+        const size_t a_bytes = a_f32 ? 0 : (size_t)M * K * 6, w_bytes = (size_t)N * K * 6;
         RELAX_TRY(ensure_buf(h, h->sp3_ws, a_bytes + w_bytes + 256));
         char* As = static_cast<char*>(h->sp3_ws.p);
         char* Ws = As + ((a_bytes + 255) & ~(size_t)255);
-        RELAX_TRY(launch_to_sp3(h, A, K, As, M, K, s));
+        if (!a_f32) RELAX_TRY(launch_to_sp3(h, A, K, As, M, K, s));
         RELAX_TRY(launch_to_sp3(h, W, K, Ws, N, K, s));
-        return launch_gemm_x6(h, As, Ws, bias, residual, out, nullptr, M, N, K, act, s);
+        ConvDescX6 d{};
+        d.in = a_f32 ? static_cast<const void*>(A) : As; d.in_f32 = a_f32;
+        d.Nimg = 1; d.H = 1; d.W = M; d.Cin = K; d.Ho = 1; d.Wo = M;
+        d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+        d.w = Ws; d.Cout = N; d.bias = bias; d.residual = residual; d.out = out; d.act = act;
+        return launch_conv_x6(h, d, s);
     }
     return launch_gemm(h, A, W, bias, residual, out, M, N, K, act, s);
 }
@@ -728,14 +735,16 @@ int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const
     if (h->gemm.precision == 2 && Cin % 16 == 0 && d.Kpad == KH * KW * Cin && KH * KW <= 32 && Cout % 64 == 0 &&
         (KH * KW > 1 || pad == 0)) {
         // operator-level entry under "bf16x6": input and weights are converted to split planes here
-        const size_t a_bytes = (size_t)Nimg * H * W * Cin * 6, w_bytes = (size_t)Cout * d.Kpad * 6;
+        // (1x1 stride-1 convolutions onto 64 / 128 channels: the kernel splits the fp32 pixels in its K loop)
+        const bool a_f32 = KH * KW == 1 && stride == 1 && Cout % 256 != 0;
+        const size_t a_bytes = a_f32 ? 0 : (size_t)Nimg * H * W * Cin * 6, w_bytes = (size_t)Cout * d.Kpad * 6;
         RELAX_TRY(ensure_buf(h, h->sp3_ws, a_bytes + w_bytes + 256));
         char* As = static_cast<char*>(h->sp3_ws.p);
         char* Ws = As + ((a_bytes + 255) & ~(size_t)255);
-        RELAX_TRY(launch_to_sp3(h, in, Cin, As, (int64_t)Nimg * H * W, Cin, s));
+        if (!a_f32) RELAX_TRY(launch_to_sp3(h, in, Cin, As, (int64_t)Nimg * H * W, Cin, s));
         RELAX_TRY(launch_to_sp3(h, w, d.Kpad, Ws, Cout, d.Kpad, s));
         ConvDescX6 x{};
-        x.in = As; x.Nimg = Nimg; x.H = H; x.W = W; x.Cin = Cin; x.Ho = d.Ho; x.Wo = d.Wo;
+        x.in = a_f32 ? static_cast<const void*>(in) : As; x.in_f32 = a_f32; x.Nimg = Nimg; x.H = H; x.W = W; x.Cin = Cin; x.Ho = d.Ho; x.Wo = d.Wo;
         x.KH = KH; x.KW = KW; x.stride = stride; x.pad = pad;
         x.w = Ws; x.Cout = Cout; x.bias = bias; x.residual = residual; x.out = out; x.out_sp3 = nullptr; x.act = act;
         return launch_conv_x6(h, x, s);

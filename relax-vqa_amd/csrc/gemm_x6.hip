@@ -130,7 +130,7 @@ constexpr int64_t kMaxRecords = 0x7ffffff0;
 // (the loop body is rotated: one "region" = barrier .. next barrier = M1(k) + M0(k+1) is one basic block, which the compiler's
 // scheduler interleaves better than any order pinned by hand)
 // X = the operand with fewer fragments per wave (double-buffered in registers), Y = the other one (two halves).
-template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (it has no __amdgpu_buffer_rsrc_t and emits no stub for a body that names it)
     constexpr int NW = WM * WN;
@@ -142,9 +142,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int YT = SPLIT_B ? TN : TM;
     constexpr int YH = YT / 2;
     constexpr int ROWS = BM + BN;
-    constexpr int STAGE = ROWS * kChunkBytes;
-        constexpr int PIECES = ROWS * 6 / 64;         // 1 KiB DMA pieces per stage
-    constexpr int A_PIECES = BM * 6 / 64;
+    constexpr int A_ROW = AF32 ? 64 : kChunkBytes;   // LDS bytes of one activation row of a stage (AF32: 16 fp32 values, split in registers)
+    constexpr int A_BYTES = BM * A_ROW;
+    constexpr int STAGE = A_BYTES + BN * kChunkBytes;
+    constexpr int PIECES = STAGE / 1024;             // 1 KiB DMA pieces per stage
+    constexpr int A_PIECES = A_BYTES / 1024;
     constexpr int PPW = (PIECES + NW - 1) / NW;   // pieces per wave (a wave short of real pieces issues dummy ones)
     constexpr int A_PPW = A_PIECES / NW;
     constexpr int NSTG = (M16 && !TAPS && !DUAL) ? 3 : 2;   // LDS stages (three: the 16x16x32 loop of the plain GEMMs, see X6_REGION16; the implicit-GEMM and two-source forms would spill)
@@ -152,6 +154,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     static_assert(ROWS % 32 == 0 && TM >= 1 && TN >= 1 && YT % 2 == 0 && A_PIECES % NW == 0, "tile / wave layout mismatch");
     static_assert(!M16 || (TM == 4 && TN == 2 && PPW <= 7), "the 16x16x32 loop is written for 128 x 64 per wave");
     static_assert(!DUAL || !TAPS, "a second activation source goes with 1x1 contractions");
+    static_assert(!AF32 || (!M16 && !TAPS && !DUAL), "fp32 activation rows: the plain-GEMM form of the four-wave tiles only");
+    static_assert(STAGE % 1024 == 0 && A_BYTES % 1024 == 0, "stage regions are whole DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     // holds logical half h = h' ^ bit3(row).  Pieces j < A_PPW belong to the activation rows, the rest to the weight rows.
     const bool pixels = TAPS || p.stride != 1;     // rows are output pixels of an NHWC image (else: plain matrix rows)
     const int64_t row_bytes = (int64_t)p.K * 6;                       // weight rows
-    const int64_t arow_bytes = (int64_t)(DUAL ? p.K1 : p.K) * 6;      // plain activation rows (DUAL: the first source's K1 values)
+    const int64_t arow_bytes = (int64_t)(DUAL ? p.K1 : p.K) * (AF32 ? 4 : 6);   // plain activation rows (DUAL: the first source's K1 values)
     const int64_t pix_bytes = (int64_t)p.Cin * 6;
     const int img0 = (pixels || DUAL) ? m0 / (p.Ho * p.Wo) : 0;
     __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w, rsrc_a2;
@@ -227,10 +231,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int piece = wave + NW * j;
-        const int u = piece * 64 + lane;
-        const int trow = u / 6;
-        const int c = u - trow * 6;
-        const int unit_off = (c >> 1) * 32 + (((c & 1) ^ (M16 ? 0 : ((trow >> 3) & 1))) << 4);   // (M16: linear image, see below)
+        int trow, unit_off;
+        if (AF32 && j < A_PPW) {
+            // fp32 activation rows: 4 units of 16 bytes per row; unit q of row r sits in slot q ^ ((r >> 2) & 3), which makes the
+            // two ds_read_b128 of a fragment (lanes = 32 consecutive rows at one q) bank-conflict free
+            const int u = piece * 64 + lane;
+            trow = u >> 2;
+            unit_off = (((u & 3) ^ ((trow >> 2) & 3)) << 4);
+        } else {
+            const int u = (piece - (AF32 ? A_PIECES : 0)) * 64 + lane;
+            trow = u / 6;
+            const int c = u - trow * 6;
+            unit_off = (c >> 1) * 32 + (((c & 1) ^ (M16 ? 0 : ((trow >> 3) & 1))) << 4);   // (M16: linear image, see below)
+            if (AF32) trow += BM;
+        }
         if (j < A_PPW) {
             const int m = m0 + trow;
             a_taps[j] = 0u;
@@ -288,6 +302,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
 #define X6_ISSUE_PIECE(st_, j_)                                                                                         \
     {                                                                                                                   \
         const int lin_ = (TAPS ? d_tap * cin_chunks + d_cc : d_kt) * kChunkBytes;                                       \
+        const int lin_a_ = AF32 ? d_kt * 64 : lin_;                                                                     \
         const int tapoff_ = TAPS ? (d_dy * p.W + d_dx) * (int)pix_bytes + d_cc * kChunkBytes : 0;                        \
         const int piece_ = wave + NW * (j_);                                                                            \
         const int dst_ = piece_ < PIECES ? (st_) * STAGE + piece_ * 1024 : DUMMY;                                       \
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 const int jj_ = (j_) < A_PPW ? (j_) : 0;                                                                \
                 X6_DMA(rsrc_a2, dst_, voff2[jj_], lin_ - k1_chunks * kChunkBytes);                                      \
             } else {                                                                                                    \
-                X6_DMA(rsrc_a, dst_, voff[j_], lin_);                                                                   \
+                X6_DMA(rsrc_a, dst_, voff[j_], lin_a_);                                                                 \
             }                                                                                                           \
         } else {                                                                                                        \
             X6_DMA(rsrc_w, dst_, voff[j_], lin_);                                                                       \
@@ -346,17 +361,42 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     const int r32 = lane & 31;
     const int frag = r32 * kChunkBytes + ((((lane >> 5) ^ (r32 >> 3)) & 1) << 4);
     const int a_off = (wm * TM * 32) * kChunkBytes + frag;
-    const int b_off = (BM + wn * TN * 32) * kChunkBytes + frag;
+    const int b_off = A_BYTES + (wn * TN * 32) * kChunkBytes + frag;
+    // AF32: lane (r, h) reads the fp32 values k = 8h .. 8h+7 of row r as two 16-byte units and splits them into the three planes
+    [[maybe_unused]] const int a32_0 = (wm * TM * 32 + r32) * 64 + ((((lane >> 5) * 2) ^ ((r32 >> 2) & 3)) << 4);
+    [[maybe_unused]] const int a32_1 = (wm * TM * 32 + r32) * 64 + ((((lane >> 5) * 2 + 1) ^ ((r32 >> 2) & 3)) << 4);
     const int x_off = SPLIT_B ? a_off : b_off;
     const int y_off = SPLIT_B ? b_off : a_off;
 
     bf16x8 xf[2][XT][3], yf0[YH][3], yf1[YH][3];   // [.][fragment][plane hi, mid, lo]
+#define X6_READ_A32(dst_, idx_, sp_)                                                                                    \
+    {                                                                                                                   \
+        const f32x4 v0_ = *reinterpret_cast<const f32x4*>((sp_) + a32_0 + (idx_) * 32 * 64);                            \
+        const f32x4 v1_ = *reinterpret_cast<const f32x4*>((sp_) + a32_1 + (idx_) * 32 * 64);                            \
+        u32x4 h_, m_, l_;                                                                                               \
+        split3_x8(v0_, v1_, h_, m_, l_);                                                                                \
+        dst_[0] = __builtin_bit_cast(bf16x8, h_);                                                                       \
+        dst_[1] = __builtin_bit_cast(bf16x8, m_);                                                                       \
+        dst_[2] = __builtin_bit_cast(bf16x8, l_);                                                                       \
+    }
 #define X6_READ_X(set_, sp_)                                                                                            \
-    _Pragma("unroll") for (int x = 0; x < XT; ++x) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                     \
-        xf[set_][x][pl] = *reinterpret_cast<const bf16x8*>((sp_) + x_off + x * 32 * kChunkBytes + pl * 32);
+    _Pragma("unroll") for (int x = 0; x < XT; ++x) {                                                                    \
+        if constexpr (AF32 && SPLIT_B) {                                                                                \
+            X6_READ_A32(xf[set_][x], x, sp_);                                                                           \
+        } else {                                                                                                        \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                            \
+                xf[set_][x][pl] = *reinterpret_cast<const bf16x8*>((sp_) + x_off + x * 32 * kChunkBytes + pl * 32);     \
+        }                                                                                                               \
+    }
 #define X6_READ_Y(yf_, half_, sp_)                                                                                      \
-    _Pragma("unroll") for (int y = 0; y < YH; ++y) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                     \
-        yf_[y][pl] = *reinterpret_cast<const bf16x8*>((sp_) + y_off + ((half_) * YH + y) * 32 * kChunkBytes + pl * 32);
+    _Pragma("unroll") for (int y = 0; y < YH; ++y) {                                                                    \
+        if constexpr (AF32 && !SPLIT_B) {                                                                               \
+            X6_READ_A32(yf_[y], (half_) * YH + y, sp_);                                                                 \
+        } else {                                                                                                        \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                            \
+                yf_[y][pl] = *reinterpret_cast<const bf16x8*>((sp_) + y_off + ((half_) * YH + y) * 32 * kChunkBytes + pl * 32); \
+        }                                                                                                               \
+    }
     // the six partial products, smallest first: (A plane, B plane) = (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi);
     // product type outermost: XT*YH independent accumulators between two MFMAs on the same one
 #define X6_MFMAS(set_, yf_, half_)                                                                                      \
@@ -541,6 +581,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
 #undef X6_REGION
 #undef X6_MFMAS
 #undef X6_READ_X
+#undef X6_READ_A32
 #undef X6_READ_Y
 #undef X6_ISSUE
 #undef X6_ISSUE_PIECE
@@ -793,7 +834,7 @@ static int x6_report_stamps(relax_handle* h, const X6Params& p, int units, hipSt
 }
 #endif
 
-template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false>
 static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr int WG_PER_CU = NT == 256 ? 2 : 1;
@@ -813,10 +854,10 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
         RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
         p.partial = static_cast<float*>(h->splitk_ws.p);
     }
-    constexpr size_t lds = ((M16 && !TAPS && !DUAL) ? 3 : 2) * (size_t)(BM + BN) * kChunkBytes + 1024;
+    constexpr size_t lds = ((M16 && !TAPS && !DUAL) ? 3 : 2) * (size_t)(BM * (AF32 ? 64 : kChunkBytes) + BN * kChunkBytes) + 1024;
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[h->device] = true;
     }
@@ -825,7 +866,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * 8 * (size_t)units));
     p.stamps = static_cast<unsigned long long*>(h->scratch.p);
 #endif
-    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL>), dim3(units), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32>), dim3(units), dim3(NT), lds, s, p);
 #ifdef RELAX_X6_STAMPS
     RELAX_TRY((x6_report_stamps<BM, BN>(h, p, units, s)));
 #endif
@@ -867,6 +908,8 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, !d.in2 || (!taps && d.stride == 1 && d.Cin2 % 16 == 0 && d.stride2 >= 1 && p.N % 256 == 0 &&
                                 (d.H2 - 1) / d.stride2 + 1 == d.Ho && (d.W2 - 1) / d.stride2 + 1 == d.Wo),
                   "x6 conv: a second activation source needs a 1x1 stride-1 first source, Cout %% 256 == 0 and a matching output grid");
+    RELAX_REQUIRE(h, !d.in_f32 || (!taps && !d.in2 && d.stride == 1 && p.N % 256 != 0),
+                  "x6 conv/gemm: fp32 activation rows go with a 1x1 stride-1 contraction of 64 or 128 (not a multiple of 256) output columns");
     // every operand is read / written in 16-byte units (LDS-DMA pieces, f32x4 bias / residual / output accesses, plane units)
     auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     RELAX_REQUIRE(h, aligned16(d.in) && aligned16(d.w) && aligned16(d.bias) && aligned16(d.residual) && aligned16(d.residual_sp3) &&
@@ -874,14 +917,17 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
                   "x6 conv/gemm: every operand pointer must be 16-byte aligned");
     const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)p.K;
     // algorithmic HBM bytes: activation in (6 B per value), weights, outputs (+ residual), each touched once
-    const double bytes = 6.0 * ((double)d.Nimg * d.H * d.W * d.Cin + (double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) +
+    const double bytes = (d.in_f32 ? 4.0 : 6.0) * ((double)d.Nimg * d.H * d.W * d.Cin) + 6.0 * ((double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) +
                          (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.residual ? 4.0 : 0.0) + (d.residual_sp3 ? 6.0 : 0.0));
     int span;
     RELAX_TRY(prof_begin(h, s, 2, flops, &span, bytes));
     int rc;
     // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA); N = 128 / 64 layers: the same
     // loop on four waves, two workgroups per CU
-    if (d.in2)
+    if (d.in_f32)   // fp32 activation rows, split in the K loop (ResNet-50: the block outputs of layer1 / layer2 travel as fp32)
+        rc = p.N % 128 == 0 ? launch_x6_variant<256, 128, 2, 2, false, false, false, true>(h, p, s)
+                            : launch_x6_variant<256, 64, 4, 1, false, false, false, true>(h, p, s);
+    else if (d.in2)
         rc = launch_x6_variant<256, 256, 2, 4, false, true, true>(h, p, s);
     else if (p.N % 256 == 0)   // the 8-wave tile runs the 16x16x32 form of the loop
         rc = taps ? launch_x6_variant<256, 256, 2, 4, true, true>(h, p, s) : launch_x6_variant<256, 256, 2, 4, false, true>(h, p, s);

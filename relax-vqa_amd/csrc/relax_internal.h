@@ -77,6 +77,7 @@ struct ConvDescX6 {
     // sums W3 t2 + Wd x): sp3 NHWC [Nimg*H2*W2][Cin2*6 B], sampled at (oy, ox) * stride2; the weight rows are concatenated
     const void* in2;
     int H2, W2, Cin2, stride2;
+    int in_f32;             // 1: `in` is plain fp32 [M][Cin] rows (split into planes inside the K loop): 1x1 stride-1, Cout = 64 / 128 only
     int out_rows, gap_rows; // rows below these limits get the fp32 output / the group sums (0 = all rows)
     bool no_split;          // never cut tail tiles along K (a launch whose bits must not depend on which outputs are requested)
     const float* bias;      // [Cout] or null

@@ -357,35 +357,51 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
         float* avg6 = gapws6 + kGapWs * n;
         gapws = gapws6;
         RELAX_TRY(launch_bn_relu_maxpool_sp3(h, bufA, rn.bn1_scale, rn.bn1_shift, spa, N, 112, 112, 64, s));
-        // A block output exists as split planes always (next convolutions, next residual: hi + mid + lo is the fp32 value,
-        // exactly) and as fp32 only where something needs it, and only for the images that need it: the tap export, the spatial
-        // mean of the 7x7 taps of the layer-stack images (49 rows per image do not divide into the 16- or 4-row groups of the
-        // mean fused into the epilogue), the last block's map of the pool images.
+        // A block output exists as split planes (next convolutions, next residual: hi + mid + lo is the fp32 value, exactly) and as
+        // fp32 only where something needs it, and only for the images that need it: the tap export, the spatial mean of the 7x7
+        // taps of the layer-stack images (49 rows per image do not divide into the 16- or 4-row groups of the mean fused into
+        // the epilogue), the last block's map of the pool images.
+        // The block outputs inside layer1 and layer2 (56x56x256 and 28x28x512: the widest tensors, their consumers HBM-bound) travel
+        // as plain fp32 instead, 4 bytes per value where the planes take 6: the next block's conv1 (64 / 128 output columns, one
+        // column tile, so every value is split exactly once, as the producer's epilogue would have) splits them inside its K loop
+        // and its conv3 adds them as an fp32 residual - the same values bit for bit.  A layer's last block writes planes: the next
+        // layer's first conv3 reads them as its second activation source.
         const float* cur32 = nullptr;
         char* cursp = spa;
         char* othersp = spb;
         float* out32 = f32a;
+        bool cur_is_f32 = false;   // the current block input exists as fp32 rows only
         int H = 56;
-        for (const Bottleneck& blk : rn.blocks) {
+        for (size_t b = 0; b < rn.blocks.size(); ++b) {
+            const Bottleneck& blk = rn.blocks[b];
             const int Ho = H / blk.c2.stride;
             const int HWo = Ho * Ho, Cout = blk.c3.Cout;
             const bool tapped = blk.tap >= 0;
             const bool want_mean = tapped && layer_stack;
             const bool want_export = tapped && taps_nchw && taps_nchw[blk.tap];
-            const bool is_last = &blk == &rn.blocks.back();
+            const bool is_last = b + 1 == rn.blocks.size();
             const bool fuse_mean = want_mean && HWo % 4 == 0;
             const bool pool_needs32 = is_last && pool && !pool_from_stack;
-            const bool need32 = want_export || (want_mean && !fuse_mean) || pool_needs32;
-            // fp32 rows: every image for an export or the pool images behind the layer-stack ones, else the layer-stack images only
-            const int rows32 = (want_export || pool_needs32) ? N * HWo : n_ls * HWo;
-            RELAX_TRY(run_conv_x6(h, blk.c1, cursp, N, H, H, nullptr, nullptr, T1s, 1, s));
+            const bool out_is_f32 = Cout <= 512 && !is_last && !rn.blocks[b + 1].has_down;
+            const bool need32 = out_is_f32 || want_export || (want_mean && !fuse_mean) || pool_needs32;
+            // fp32 rows: every image for the next block, an export or the pool images behind the layer-stack ones, else the
+            // layer-stack images only
+            const int rows32 = (out_is_f32 || want_export || pool_needs32) ? N * HWo : n_ls * HWo;
+            {
+                ConvDescX6 d{};
+                d.in = cur_is_f32 ? static_cast<const void*>(cur32) : cursp; d.in_f32 = cur_is_f32;
+                d.Nimg = N; d.H = H; d.W = H; d.Cin = blk.c1.Cin; d.Ho = H; d.Wo = H;
+                d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
+                d.w = blk.c1.w_sp3; d.Cout = blk.c1.Cout; d.bias = blk.c1.bias; d.out_sp3 = T1s; d.act = 1;
+                RELAX_TRY(launch_conv_x6(h, d, s));
+            }
             RELAX_TRY(run_conv_x6(h, blk.c2, T1s, N, H, H, nullptr, nullptr, T2s, 1, s));
             ConvDescX6 d{};
             d.in = T2s; d.Nimg = N; d.H = Ho; d.W = Ho; d.Cin = blk.c3.Cin; d.Ho = Ho; d.Wo = Ho;
             d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
             d.Cout = Cout; d.act = 1;
             d.out = need32 ? out32 : nullptr; d.out_rows = rows32;
-            d.out_sp3 = othersp;
+            d.out_sp3 = out_is_f32 ? nullptr : othersp;
             d.gap_groups = fuse_mean ? gapws : nullptr; d.gap_rows = n_ls * HWo;
             d.no_split = tapped && HWo % 4 == 0;   // a launch that fuses the mean when the layer stack is asked for runs unsplit either
                                                     // way: the pool vector's bits do not depend on whether the layer stack is requested
@@ -396,12 +412,13 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 d.in2 = cursp; d.H2 = H; d.W2 = H; d.Cin2 = blk.down.Cin; d.stride2 = blk.down.stride;
             } else {
                 d.w = blk.c3.w_sp3; d.bias = blk.c3.bias;
-                d.residual_sp3 = cursp;
+                if (cur_is_f32) d.residual = cur32; else d.residual_sp3 = cursp;
             }
             RELAX_TRY(launch_conv_x6(h, d, s));
             cur32 = need32 ? out32 : nullptr;
             if (need32) out32 = out32 == f32a ? f32b : f32a;
-            char* t = cursp; cursp = othersp; othersp = t;
+            if (!out_is_f32) { char* t = cursp; cursp = othersp; othersp = t; }
+            cur_is_f32 = out_is_f32;
             H = Ho;
             if (tapped) {
                 const int off = tap_offset(blk.tap);
