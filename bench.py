@@ -378,7 +378,7 @@ def main():
         eng.profile_enable(False)
         eng.set_precision(precision)
         fast = {"precision": "exact fp32 products on v_mfma_f32_32x32x2_f32 (an fp32 FMA chain)" if other == "fp32" else
-                             "bf16x6: three bf16 planes per fp32 operand, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate",
+                             "bf16x6: three bf16 planes per fp32 operand, six partial products on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, two products per instruction; 32x32x16 on the narrow tiles), fp32 accumulate",
                 "value": args.steps * B / e1, "unit": "clips/s", "ms_per_step": e1 / args.steps * 1e3,
                 "contraction_algorithmic_tflops": f_flops / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0,
                 "frac_of_fp32_mfma_peak": (f_flops / (f_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS) if (f_ms > 0 and other == "fp32") else None}
@@ -439,7 +439,7 @@ def main():
                 "bound": "mfma",
                 "kernel": {"fp32": "conv_gemm_f32 (fp32 implicit-GEMM conv / GEMM, v_mfma_f32_32x32x2_f32)",
                            "bf16x3": "conv_gemm_f32<..., bf16x3> (3 x v_mfma_f32_32x32x16_bf16 per fp32 product; achieved = EXECUTED flops = 3 x algorithmic)",
-                           "bf16x6": "gemm_x6 + conv1_x6 (6 x v_mfma_f32_32x32x16_bf16 per fp32 product; achieved = EXECUTED bf16 flops = 6 x algorithmic, "
+                           "bf16x6": "gemm_x6 + conv1_x6 (six bf16 partial products per fp32 product on v_mfma_f32_16x16x32_bf16 / 32x32x16; achieved = EXECUTED bf16 flops = 6 x algorithmic, "
                                      "peak = dense bf16 MFMA)"}[precision],
                 "achieved": achieved * mult, "peak": FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
