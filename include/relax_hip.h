@@ -67,7 +67,8 @@ int relax_reserve(relax_handle* h, int max_images);
 
 /* Integer options.  "gemm_precision": 0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 2 = "bf16x6" (fp32-grade):
  * every fp32 operand is held as three bf16 numbers hi + mid + lo (exact) and a*b = the six partial products of weight
- * >= 2^-16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - as close to the exact sum as the fp32 FMA chain
+ * >= 2^-16 on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, two products per instruction; 32x32x16 on the 64 / 128-column
+ * tiles) with fp32 accumulation - as close to the exact sum as the fp32 FMA chain
  * (csrc/gemm_x6.hip, tests/test_gpu_x6.py); used by the ViT / ResNet drivers and by relax_op_gemm; 1 = "bf16x3":
  * every fp32 operand is split on the fly into bf16 hi + lo and a*b = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
  * with fp32 accumulation (about 2^-16 relative error per product; measured features within ~1e-5 of the fp32 path).
@@ -76,7 +77,10 @@ int relax_reserve(relax_handle* h, int max_images);
  * batch size - set 0 when features must be bit-identical across batch compositions (e.g. comparing sharded runs).
  * "gemm_variant", "gemm_variant_n64" (exact-fp32 kernel only), "gemm_group_m": tuning knobs (tile variants are listed in
  * csrc/gemm.hip; none of them changes results beyond fp32 rounding).  "flow_max_pairs": cap on the pairs one optical-flow launch takes
- * (0 = by workspace size).  "debug_poison" (test mode, default 0): every workspace request fills the buffer with 0xFF bytes
+ * (0 = by workspace size).  "x6_fp32_rows" (default 1): bf16x6 contractions onto 64 / 128 output columns read fp32 activation rows and
+ * split them in the K loop, and the ResNet-50 block outputs inside layer1 / layer2 travel as fp32 (4 bytes per value instead of 6);
+ * 0 = split planes everywhere: the same bits, more bytes (kept as the A/B switch of tests/test_gpu_x6.py).
+ * "debug_poison" (test mode, default 0): every workspace request fills the buffer with 0xFF bytes
  * first (synchronously), so a read of workspace that was not written in the same call shows up in the results. */
 int relax_set_option(relax_handle* h, const char* key, int value);
 /* Reads an option back (bench.py reports the arithmetic the ENGINE is in, not the one its command line asked for). */

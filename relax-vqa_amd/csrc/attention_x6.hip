@@ -25,9 +25,10 @@ typedef __bf16 a6_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned a6_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned a6_u32x2 __attribute__((ext_vector_type(2)));
 
-[[maybe_unused]] constexpr int A6_NTOK = 197;
+constexpr int A6_NTOK = 197;
 constexpr int A6_KT = 7;                  // key tiles of 32 (224 padded keys) = query tiles = waves
 constexpr int A6_KPAD = A6_KT * 32;
+[[maybe_unused]] constexpr int A6_VC = (A6_NTOK + 15) / 16;   // 16-key steps of the output phase that hold a real key: 13 (keys 208 .. 223 are padding, their probabilities exact zeros)
 constexpr int A6_THREADS = A6_KT * 64;
 constexpr int A6_KROW = 4 * kChunkBytes + 16;      // K image: [key][4 chunks of 16 d][3 planes][16] + pad (25 units: conflict-free)
 constexpr int A6_VROW = 14 * kChunkBytes + 16;     // V^T image: [d][14 chunks of 16 keys][3 planes][16] + pad (85 units)
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
         const int next = item + gridDim.x;
         if (next < total_items) A6_DMA(next, 1);       // K rows of the next item: in flight during the output phase
 
-        // ---- output: O^T[d, query] = V^T P^T over 14 steps of 16 keys ---------------------------------------------------
+        // ---- output: O^T[d, query] = V^T P^T over 13 steps of 16 keys (the 14th holds padding keys only: zeros times zeros) ---------------------------------------------------
         // Pipelined like the scores: the six V^T fragments of step c + 1 are read, and its probabilities split into planes, while
         // the twelve MFMAs of step c run.  Registers 8*(c&1) .. +7 of score tile c>>1 are keys 16c + 8*(j>>2) + 4*half + (j&3):
         // the B fragment of step c.
@@ -231,9 +232,9 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
         A6_SPLIT_P(0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < 2 * A6_KT; ++c) {
+        for (int c = 0; c < A6_VC; ++c) {
             const int b = c & 1;
-            if (c + 1 < 2 * A6_KT) {
+            if (c + 1 < A6_VC) {
                 A6_READ_V(b ^ 1, c + 1);
                 __builtin_amdgcn_sched_barrier(0);       // the reads go out first ...
                 A6_SPLIT_P(b ^ 1, c + 1);                // ... the split's VALU interleaves with the MFMAs below

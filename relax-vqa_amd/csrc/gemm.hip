@@ -695,7 +695,7 @@ int relax_op_gemm(relax_handle* h, const float* A, const float* W, const float* 
         // keep weights and activations in that format instead)
         RELAX_REQUIRE(h, K % 16 == 0, "relax_op_gemm (bf16x6): K=%d must be a multiple of 16", K);
         // (64 / 128-column problems: the kernel takes the fp32 rows of A as they are and splits them in its K loop)
-        const bool a_f32 = N % 256 != 0;
+        const bool a_f32 = h->gemm.fp32_rows && N % 256 != 0;
         const size_t a_bytes = a_f32 ? 0 : (size_t)M * K * 6, w_bytes = (size_t)N * K * 6;
         RELAX_TRY(ensure_buf(h, h->sp3_ws, a_bytes + w_bytes + 256));
         char* As = static_cast<char*>(h->sp3_ws.p);
@@ -736,7 +736,7 @@ int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const
         (KH * KW > 1 || pad == 0)) {
         // operator-level entry under "bf16x6": input and weights are converted to split planes here
         // (1x1 stride-1 convolutions onto 64 / 128 channels: the kernel splits the fp32 pixels in its K loop)
-        const bool a_f32 = KH * KW == 1 && stride == 1 && Cout % 256 != 0;
+        const bool a_f32 = h->gemm.fp32_rows && KH * KW == 1 && stride == 1 && Cout % 256 != 0;
         const size_t a_bytes = a_f32 ? 0 : (size_t)Nimg * H * W * Cin * 6, w_bytes = (size_t)Cout * d.Kpad * 6;
         RELAX_TRY(ensure_buf(h, h->sp3_ws, a_bytes + w_bytes + 256));
         char* As = static_cast<char*>(h->sp3_ws.p);

@@ -382,7 +382,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             const bool is_last = b + 1 == rn.blocks.size();
             const bool fuse_mean = want_mean && HWo % 4 == 0;
             const bool pool_needs32 = is_last && pool && !pool_from_stack;
-            const bool out_is_f32 = Cout <= 512 && !is_last && !rn.blocks[b + 1].has_down;
+            const bool out_is_f32 = h->gemm.fp32_rows && Cout <= 512 && !is_last && !rn.blocks[b + 1].has_down;
             const bool need32 = out_is_f32 || want_export || (want_mean && !fuse_mean) || pool_needs32;
             // fp32 rows: every image for the next block, an export or the pool images behind the layer-stack ones, else the
             // layer-stack images only

@@ -124,6 +124,52 @@ def test_gelu_is_the_erf_gelu_to_fp32_rounding(each_precision):
     assert torch.all(z == 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 64, 16), (1000, 128, 256), (5000, 192, 1024), (777, 320, 4608), (256 * 9 + 5, 64, 576),
+                                   (70000, 128, 512)])
+def test_fp32_activation_rows_give_the_bits_of_split_planes(x6, M, N, K):
+    """Contractions onto 64 / 128-column tiles (N % 256 != 0) read the fp32 rows of A and split them inside the K loop
+    ("x6_fp32_rows", default on); with the option off A is converted to split planes first.  Same values, same products, same
+    order: the outputs are equal bit for bit, with bias + residual + GELU and with the tail split on and off (70000 rows: more than
+    one round of tiles, so whole-K tiles and K slices both occur; K = 16: a single step; 4608: the longest K of the models)."""
+    A, W = _rand(M, K, seed=21).cuda(), _rand(N, K, seed=22, scale=K ** -0.5).cuda()
+    b, r = _rand(N, seed=23).cuda(), _rand(M, N, seed=24).cuda()
+    assert x6.get_option("x6_fp32_rows") == 1
+    for split in (1, 0):
+        x6.set_option("gemm_split_k", split)
+        try:
+            got = x6.op_gemm(A, W, bias=b, residual=r, act=2)
+            x6.set_option("x6_fp32_rows", 0)
+            want = x6.op_gemm(A, W, bias=b, residual=r, act=2)
+        finally:
+            x6.set_option("x6_fp32_rows", 1)
+            x6.set_option("gemm_split_k", 1)
+        assert torch.equal(got, want), f"split_k={split}"
+    ref = torch.nn.functional.gelu(A.double() @ W.double().T + b.double() + r.double()).float().cpu().numpy()
+    assert_close(got, ref, "fp32-row contraction")
+
+
+def test_resnet50_fp32_block_outputs_give_the_bits_of_split_planes(x6):
+    """ResNet-50 with the layer1 / layer2 block outputs as fp32 rows (default) against split planes everywhere: layer stack, pool
+    vector, the clip path and every exported tap are equal bit for bit, with the tail split on and off."""
+    rn50_weights()
+    f = torch.from_numpy(_fragments(6)).cuda()
+    res = {}
+    for rows in (1, 0):
+        x6.set_option("x6_fp32_rows", rows)
+        try:
+            for split in (1, 0):
+                x6.set_option("gemm_split_k", split)
+                ls, pool, taps = x6.resnet50_features(f, taps=range(15))
+                cls, cpool = x6.resnet50_clip_features(f, 3)
+                res[rows, split] = [ls, pool, cls, cpool] + [taps[i] for i in range(15)]
+        finally:
+            x6.set_option("x6_fp32_rows", 1)
+            x6.set_option("gemm_split_k", 1)
+    for split in (1, 0):
+        for i, (a, b) in enumerate(zip(res[1, split], res[0, split])):
+            assert torch.equal(a, b), f"output {i}, split_k={split}"
+
+
 def test_split_k_is_deterministic_and_optional(x6):
     """300 tiles of 256x256: 44 tail tiles are cut along K.  Same bits run to run; with gemm_split_k = 0 the bits do not
     depend on how many rows travel together."""
