@@ -119,6 +119,11 @@ __global__ __launch_bounds__(256) void gauss3_v4(const float* __restrict__ src, 
 // Coarse pyramid levels (scale 1/4, 1/8): cv::resize only samples the blurred frame at 2 columns x 2 rows per output
 // pixel, so the blur is evaluated at those samples only - same taps, same order, same interpolation arithmetic as
 // gauss_pass + resize_linear_f32 (bit-identical), a fraction of the work.
+// a * (1 - t) + b * t with every operation rounded on its own (no fused multiply-add: what cv::resize and the oracle compute); every
+// bilinear step of the pyramid goes through this one function, so the stand-alone resize, the sampled blur + resize and the copy inside
+// update_matrices_k<true> agree bit for bit
+__device__ inline float lerp_rn(float a, float b, float t) { return __fadd_rn(__fmul_rn(a, __fsub_rn(1.f, t)), __fmul_rn(b, t)); }
+
 __device__ inline void linear_tap(int d, double scale, int n_in, int* s0, int* s1, float* f) {
     float fx = (float)((d + 0.5) * scale - 0.5);
     int sx = (int)floorf(fx);
@@ -188,9 +193,7 @@ __global__ __launch_bounds__(256) void gauss_v_sampled_resize(const float* __res
         a10 += k * p1[0];
         a11 += k * p1[1];
     }
-    const float r0 = a00 * (1.f - fx) + a01 * fx;
-    const float r1 = a10 * (1.f - fx) + a11 * fx;
-    dst[(b * h + dy) * w + dx] = r0 * (1.f - fy) + r1 * fy;
+    dst[(b * h + dy) * w + dx] = lerp_rn(lerp_rn(a00, a01, fx), lerp_rn(a10, a11, fx), fy);
 }
 
 // cv::resize INTER_LINEAR on float [B][H][W][C] -> [B][h][w][C], result scaled by mul (flow upsampling: 1/pyr_scale)
@@ -216,9 +219,9 @@ __global__ __launch_bounds__(256) void resize_linear_f32(const float* __restrict
     const int sx1 = sx + 1 < W ? sx + 1 : W - 1;
     const int sy1 = sy + 1 < H ? sy + 1 : H - 1;
     const float* im = src + b * ((int64_t)H * W * C);
-    const float r0 = im[((int64_t)sy * W + sx) * C + c] * (1.f - fx) + im[((int64_t)sy * W + sx1) * C + c] * fx;
-    const float r1 = im[((int64_t)sy1 * W + sx) * C + c] * (1.f - fx) + im[((int64_t)sy1 * W + sx1) * C + c] * fx;
-    dst[((b * h + dy) * w) * C + e] = (r0 * (1.f - fy) + r1 * fy) * mul;
+    const float r0 = lerp_rn(im[((int64_t)sy * W + sx) * C + c], im[((int64_t)sy * W + sx1) * C + c], fx);
+    const float r1 = lerp_rn(im[((int64_t)sy1 * W + sx) * C + c], im[((int64_t)sy1 * W + sx1) * C + c], fx);
+    dst[((b * h + dy) * w) * C + e] = __fmul_rn(lerp_rn(r0, r1, fy), mul);
 }
 
 // FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][h][w][5].  A block owns a band of 246 output columns (256
@@ -350,8 +353,18 @@ __device__ inline void matrix_entries(const float* __restrict__ R0, const float*
 // algorithmic 2.4).  The block index is therefore remapped: XCD x (= linear block id mod 8) owns the band of rows
 // [x * rpb, (x + 1) * rpb) and walks it row-major: fetched / written 2.4, 7.85 -> 6.0 GB per launch at 2160p; the time moved
 // less (1115 -> 1084 us: 5.5 TB/s of useful bytes either way).  Eight rows per block in a loop instead: 1.7 % slower.
+// UP: the flow of this level is the coarser level's flow resized by cv::resize INTER_LINEAR and doubled (the pyramid step).  The
+// first matrix update of a level is its only reader (box_solve_fused writes the level's own flow), so the resized plane is never
+// stored: the update computes the two values where it needs them - the operations of resize_linear_f32<2>, bit for bit (one kernel
+// and 16 bytes per pixel fewer per level).
+struct FlowUp {
+    const float* src;     // coarser flow [P][H][W][2]
+    int H, W;
+    double scale_y, scale_x;
+};
+template <bool UP>
 __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict__ R, const float* __restrict__ flow,
-                                                         float* __restrict__ M, int h, int w, int rpb) {
+                                                         float* __restrict__ M, int h, int w, int rpb, const FlowUp up) {
     const int L = blockIdx.x + gridDim.x * blockIdx.y;    // grid (w / 256, 8 * rpb, pairs), rpb = rows per band = ceil(h / 8)
     const int band = L & 7, k = L >> 3;
     const int y = band * rpb + k / (int)gridDim.x;
@@ -361,8 +374,32 @@ __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict
     const int64_t hw = (int64_t)w * h;
     const int64_t i = pair * hw + (int64_t)y * w + x;
     float e[5];
-    matrix_entries(R + (pair * 2) * hw * 5 + ((int64_t)y * w + x) * 5, R + (pair * 2 + 1) * hw * 5, x, y, flow[i * 2], flow[i * 2 + 1],
-                   h, w, e);
+    float fx0, fy0;
+    if constexpr (UP) {
+        float fx = (float)((x + 0.5) * up.scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= up.W - 1) { fx = 0.f; sx = up.W - 1; }
+        float fy = (float)((y + 0.5) * up.scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        if (sy < 0) { fy = 0.f; sy = 0; }
+        if (sy >= up.H - 1) { fy = 0.f; sy = up.H - 1; }
+        const int sx1 = sx + 1 < up.W ? sx + 1 : up.W - 1;
+        const int sy1 = sy + 1 < up.H ? sy + 1 : up.H - 1;
+        const float* im = up.src + pair * ((int64_t)up.H * up.W * 2);
+        const float2 a00 = *reinterpret_cast<const float2*>(im + ((int64_t)sy * up.W + sx) * 2);
+        const float2 a01 = *reinterpret_cast<const float2*>(im + ((int64_t)sy * up.W + sx1) * 2);
+        const float2 a10 = *reinterpret_cast<const float2*>(im + ((int64_t)sy1 * up.W + sx) * 2);
+        const float2 a11 = *reinterpret_cast<const float2*>(im + ((int64_t)sy1 * up.W + sx1) * 2);
+        fx0 = __fmul_rn(lerp_rn(lerp_rn(a00.x, a01.x, fx), lerp_rn(a10.x, a11.x, fx), fy), 2.0f);
+        fy0 = __fmul_rn(lerp_rn(lerp_rn(a00.y, a01.y, fx), lerp_rn(a10.y, a11.y, fx), fy), 2.0f);
+    } else {
+        fx0 = flow[i * 2];
+        fy0 = flow[i * 2 + 1];
+    }
+    matrix_entries(R + (pair * 2) * hw * 5 + ((int64_t)y * w + x) * 5, R + (pair * 2 + 1) * hw * 5, x, y, fx0, fy0, h, w, e);
     float* o = M + pair * 5 * hw + ((int64_t)y * w + x);
 #pragma unroll
     for (int c = 0; c < 5; ++c) o[c * hw] = e[c];
@@ -386,8 +423,12 @@ constexpr int FUSE_ROWS = 3;                          // divides the ring period
 constexpr int FUSE_OUT = 240;                         // output columns per block
 constexpr int FUSE_STRIPS = FUSE_OUT / 4;             // 60 strips per row, 180 strip threads per group
 static_assert(WINSIZE % FUSE_ROWS == 0 && FUSE_OUT + WINSIZE - 1 <= 256 && FUSE_ROWS * FUSE_STRIPS <= 256, "fused box geometry");
+// MINMAX (the last iteration of the finest level, when the flow image is asked for): the per-pair minimum and maximum of the flow
+// magnitude, which flow_to_rgb's normalisation needs, are taken from the values as they are written (mag_minmax's expression,
+// same bits; its pass over the flow plane disappears).
+template <bool MINMAX>
 __global__ __launch_bounds__(256) void box_solve_fused(const float* __restrict__ M, float* __restrict__ flow, int h, int w,
-                                                       int seg) {
+                                                       int seg, unsigned* __restrict__ mm) {
     __shared__ __attribute__((aligned(16))) double lds[FUSE_ROWS][5][256];
     constexpr int m = WINSIZE / 2;
     const int tid = threadIdx.x;
@@ -404,6 +445,7 @@ __global__ __launch_bounds__(256) void box_solve_fused(const float* __restrict__
     const int x0 = c0 + 4 * sq;
     const bool strip = tid < FUSE_ROWS * FUSE_STRIPS && x0 < w;
 
+    [[maybe_unused]] unsigned mag_lo = 0xffffffffu, mag_hi = 0u;
     float ring[5][WINSIZE];   // the 15 rows of the window; slot of row r = (r - y0 + 7) % 15
     double s[5];
     float nxt[FUSE_ROWS][5];  // rows entering the window at the rows of the next group
@@ -478,13 +520,31 @@ __global__ __launch_bounds__(256) void box_solve_fused(const float* __restrict__
                             const double g11 = acc[0][e] * sc, g12 = acc[1][e] * sc, g22 = acc[2][e] * sc, h1 = acc[3][e] * sc,
                                          h2 = acc[4][e] * sc;
                             const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
-                            dst[2 * e] = (float)((g11 * h2 - g12 * h1) * idet);
-                            dst[2 * e + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+                            const float fxo = (float)((g11 * h2 - g12 * h1) * idet), fyo = (float)((g22 * h1 - g12 * h2) * idet);
+                            dst[2 * e] = fxo;
+                            dst[2 * e + 1] = fyo;
+                            if constexpr (MINMAX) {
+                                const unsigned u = __float_as_uint(sqrtf(fxo * fxo + fyo * fyo));
+                                mag_lo = u < mag_lo ? u : mag_lo;
+                                mag_hi = u > mag_hi ? u : mag_hi;
+                            }
                         }
                     }
                 }
                 __syncthreads();   // the next group overwrites the three rows
             }
+        }
+    }
+    if constexpr (MINMAX) {   // wave minimum / maximum, one atomic pair per wave
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned a = __shfl_xor(mag_lo, o), b = __shfl_xor(mag_hi, o);
+            mag_lo = a < mag_lo ? a : mag_lo;
+            mag_hi = b > mag_hi ? b : mag_hi;
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&mm[pair], mag_lo);                 // mins [0,P), maxs [P,2P)
+            atomicMax(&mm[gridDim.z + pair], mag_hi);
         }
     }
 }
@@ -675,10 +735,18 @@ static inline bool vec4_ok(int w, int64_t plane_elems, const void* a, const void
     return w % 4 == 0 && plane_elems % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
 }
 
-static int visualise(relax_handle* h, const float* flow, int P, int HW, uint8_t* bgr, unsigned* mm, hipStream_t s) {
+static int minmax_reset(relax_handle* h, int P, unsigned* mm, hipStream_t s) {
     RELAX_HIP_CHECK(h, hipMemsetAsync(mm, 0xff, sizeof(unsigned) * P, s));       // running minima
     RELAX_HIP_CHECK(h, hipMemsetAsync(mm + P, 0, sizeof(unsigned) * P, s));       // running maxima
-    hipLaunchKernelGGL(mag_minmax, dim3(HW / 4096 > 64 ? (HW / 4096 < 1024 ? HW / 4096 : 1024) : 64, P), dim3(256), 0, s, flow, HW, mm);
+    return RELAX_OK;
+}
+
+// have_minmax: mm already holds the magnitude range of every pair (box_solve_fused<true> wrote the flow)
+static int visualise(relax_handle* h, const float* flow, int P, int HW, uint8_t* bgr, unsigned* mm, hipStream_t s, bool have_minmax = false) {
+    if (!have_minmax) {
+        RELAX_TRY(minmax_reset(h, P, mm, s));
+        hipLaunchKernelGGL(mag_minmax, dim3(HW / 4096 > 64 ? (HW / 4096 < 1024 ? HW / 4096 : 1024) : 64, P), dim3(256), 0, s, flow, HW, mm);
+    }
     if (HW % 4 == 0 && (reinterpret_cast<uintptr_t>(flow) & 15) == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0)
         hipLaunchKernelGGL(flow_visualise_v4, dim3(nblocks(HW / 4), 1, P), dim3(256), 0, s, flow, mm, P, HW, bgr);
     else
@@ -732,12 +800,8 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
         RELAX_REQUIRE(h, k < 2 || 129.0 / scale + smooth + 4 <= GH_SEG, "optical flow: pyramid scale %g too coarse for the row stage", scale);
         const int w = (int)lrint(W * scale), hh = (int)lrint(H * scale);
         const int64_t hw = (int64_t)w * hh;
-        if (!prev_flow) {
-            RELAX_HIP_CHECK(h, hipMemsetAsync(cur, 0, sizeof(float) * P * 2 * hw, s));
-        } else {
-            hipLaunchKernelGGL(resize_linear_f32<2>, dim3(nblocks(w * 2), hh, P), dim3(256), 0, s, prev_flow, cur, ph, pw, hh, w,
-                               (double)ph / hh, (double)pw / w, 2.0f);
-        }
+        if (!prev_flow) RELAX_HIP_CHECK(h, hipMemsetAsync(cur, 0, sizeof(float) * P * 2 * hw, s));
+        // (finer levels: the first matrix update resizes the coarser flow where it reads it - no resized plane)
         GaussKernel gk;
         make_gauss(smooth, sigma, &gk);
         const float* Isrc;
@@ -774,7 +838,12 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
         const double um_bytes = 68.0 * (double)hw * P;
         int um_span;
         RELAX_TRY(prof_begin(h, s, 3, um_bytes, &um_span));
-        hipLaunchKernelGGL(update_matrices_k, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8);
+        if (prev_flow) {
+            const FlowUp up{prev_flow, ph, pw, (double)ph / hh, (double)pw / w};
+            hipLaunchKernelGGL(update_matrices_k<true>, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8, up);
+        } else {
+            hipLaunchKernelGGL(update_matrices_k<false>, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8, FlowUp{});
+        }
         RELAX_TRY(prof_end(h, s, um_span));
         {
             int seg = 135;   // a multiple of the 15-row ring period
@@ -782,10 +851,15 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
             while (seg > 30 && (int64_t)bands * ((hh + seg - 1) / seg) * P < 1024) seg -= 15;   // enough blocks to fill the chip
             const dim3 gf(bands, (hh + seg - 1) / seg, P);
             for (int it = 0; it < ITERS; ++it) {
-                hipLaunchKernelGGL(box_solve_fused, gf, dim3(256), 0, s, M, cur, hh, w, seg);
+                if (k == 0 && it == ITERS - 1 && bgr_out) {   // the final flow: its magnitude range is taken on the way out
+                    RELAX_TRY(minmax_reset(h, P, mm, s));
+                    hipLaunchKernelGGL(box_solve_fused<true>, gf, dim3(256), 0, s, M, cur, hh, w, seg, mm);
+                } else {
+                    hipLaunchKernelGGL(box_solve_fused<false>, gf, dim3(256), 0, s, M, cur, hh, w, seg, nullptr);
+                }
                 if (it < ITERS - 1) {
                     RELAX_TRY(prof_begin(h, s, 3, um_bytes, &um_span));
-                    hipLaunchKernelGGL(update_matrices_k, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8);
+                    hipLaunchKernelGGL(update_matrices_k<false>, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8, FlowUp{});
                     RELAX_TRY(prof_end(h, s, um_span));
                 }
             }
@@ -798,7 +872,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
     RELAX_HIP_CHECK(h, hipGetLastError());
     if (flow_out)
         RELAX_HIP_CHECK(h, hipMemcpyAsync(flow_out, prev_flow, sizeof(float) * P * 2 * HW, hipMemcpyDeviceToDevice, s));
-    if (bgr_out) RELAX_TRY(visualise(h, prev_flow, P, (int)HW, bgr_out, mm, s));
+    if (bgr_out) RELAX_TRY(visualise(h, prev_flow, P, (int)HW, bgr_out, mm, s, true));
     return RELAX_OK;
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Do two builds of the library give the same bits?  (GPU box only.)
-  python tools/ab_bits.py tools/abl/librelax_prev.so relax-vqa_amd/csrc/librelax_hip.so [N] [resnet|vit|both]
+  python tools/ab_bits.py tools/abl/librelax_prev.so relax-vqa_amd/csrc/librelax_hip.so [N] [resnet|vit|both|flow]
 Each build runs in its own process (RELAX_HIP_LIB) on the same seeded fragments, for gemm_split_k 0 and 1, with and without the
 tap export; prints per output whether the tensors are equal and the largest relative difference."""
 import os
@@ -34,6 +34,15 @@ def child(out, n, what):
         _, _, taps = eng.resnet50_features(frags[:4], taps=range(15))
         for i in range(15):
             res[f"rn tap{i}"] = taps[i].cpu()
+    if what == "flow":
+        from relax_vqa_amd import synth as sy
+        for (hh, ww, t) in ((270, 480, 3), (1080, 1920, 2), (200, 264, 5)):
+            fr = torch.stack([torch.stack([torch.from_numpy(a) for a in sy.synthetic_pair(hh, ww, 900 + i)]) for i in range(t)]).cuda()
+            fl, im = eng.optical_flow(fr, want_flow=True, want_image=True)
+            res[f"flow {hh}x{ww}"], res[f"flow image {hh}x{ww}"] = fl.cpu(), im.cpu().float()
+            im_only = eng.optical_flow(fr, want_flow=False, want_image=True)[1]
+            res[f"flow image only {hh}x{ww}"] = im_only.cpu().float()
+            res[f"flow_to_rgb {hh}x{ww}"] = eng.flow_to_rgb(fl).cpu().float()
     if what in ("vit", "both"):
         eng.load_vit(synth.vit_state_dict("vit_base"), "vit_base")
         for split in (0, 1):
