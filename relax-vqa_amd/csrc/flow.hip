@@ -116,14 +116,14 @@ __global__ __launch_bounds__(256) void gauss3_v4(const float* __restrict__ src, 
     *reinterpret_cast<f32x4*>(dst + (int64_t)blockIdx.z * ((int64_t)W * H) + (int64_t)y * W + x0) = o;
 }
 
-// Coarse pyramid levels (scale 1/4, 1/8): cv::resize only samples the blurred frame at 2 columns x 2 rows per output
-// pixel, so the blur is evaluated at those samples only - same taps, same order, same interpolation arithmetic as
-// gauss_pass + resize_linear_f32 (bit-identical), a fraction of the work.
 // a * (1 - t) + b * t with every operation rounded on its own (no fused multiply-add: what cv::resize and the oracle compute); every
 // bilinear step of the pyramid goes through this one function, so the stand-alone resize, the sampled blur + resize and the copy inside
 // update_matrices_k<true> agree bit for bit
 __device__ inline float lerp_rn(float a, float b, float t) { return __fadd_rn(__fmul_rn(a, __fsub_rn(1.f, t)), __fmul_rn(b, t)); }
 
+// Coarse pyramid levels (scale 1/4, 1/8): cv::resize only samples the blurred frame at 2 columns x 2 rows per output
+// pixel, so the blur is evaluated at those samples only - same taps, same order, same interpolation arithmetic as
+// gauss_pass + resize_linear_f32 (bit-identical), a fraction of the work.
 __device__ inline void linear_tap(int d, double scale, int n_in, int* s0, int* s1, float* f) {
     float fx = (float)((d + 0.5) * scale - 0.5);
     int sx = (int)floorf(fx);
