@@ -16,7 +16,7 @@
 // (lane (r, h) of a 32x32x16 MFMA holds k = 8h .. 8h+7 of row r).  The split happens ONCE where a value is produced
 // (weights at load time, activations in the producing kernel's epilogue / LayerNorm / patchify / max-pool), never in the
 // K loop: the loop has no VALU work, and tiles go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) without
-// touching registers.
+// touching registers.  (One exception, the AF32 form below.)
 //
 // Structure: BK = 16, LDS stages of (BM + BN) rows x 96 B filled by DMA, one raw s_barrier per K step; the K loop is rotated into
 // barrier-to-barrier "regions" that read the fragments of the next step ahead of their MFMAs; counted s_waitcnt vmcnt keeps
@@ -30,6 +30,11 @@
 //     instruction, two stages, X operand double-buffered in registers, Y in halves; LDS rows hold the two 16-byte halves of a
 //     plane swapped in rows with bit 3 set, which makes these ds_read_b128 fragment reads bank-conflict free (the permutation
 //     is applied on the SOURCE offset of the DMA; the M16 form uses the linear image, conflict-free for ITS lane map).
+//     AF32 (plain GEMMs on these tiles): the activation rows arrive as fp32 (64 B per row and K step, unit q of row r in slot
+//     q ^ ((r >> 2) & 3) of the row: conflict-free ds_read_b128) and the lane splits its 8 values into the three planes right after
+//     the fragment read.  N = 64 / 128 means ONE column tile, so every activation is split exactly once either way; these launches
+//     wait on memory, and their operands (ResNet-50's widest tensors) cost 4 bytes per value instead of 6.  Same values, same
+//     products, same order as split planes: bit-identical results (tests/test_gpu_x6.py).
 // Rows beyond M and the padding taps of an implicit-GEMM convolution use an out-of-range buffer offset, which the buffer unit
 // answers with zeros.  The last, partial round of tiles is split along K (splitk_finish_x6 adds the slices in a fixed order;
 // cost model: host_logic.cpp).  DUAL: a second activation source for the K steps past K1 (ResNet conv3 + downsample in one
