@@ -89,6 +89,20 @@ def test_reference_png_pair(golden_dir):
     assert (merged == ref_merged).mean() > 0.995
 
 
+@pytest.mark.parametrize("h,w,t", [(200, 264, 3), (97, 131, 2), (540, 960, 2)])
+def test_flow_image_of_the_fused_range_equals_flow_to_rgb_of_the_flow(h, w, t):
+    """relax_optical_flow takes the per-pair magnitude range for the visualisation while its last solve writes the flow
+    (box_solve_fused<true>); relax_flow_to_rgb on the returned flow takes it with a pass of its own (mag_minmax).  Same
+    expression on the same values: the two images are equal byte for byte, for every pair of a batch."""
+    frames = np.stack([np.stack(_smooth_pair(h, w, 20 + i)) for i in range(t)])
+    eng = engine()
+    flow, img = eng.optical_flow(torch.from_numpy(frames).cuda(), want_flow=True, want_image=True)
+    again = eng.flow_to_rgb(flow)
+    assert torch.equal(img, again)
+    only = eng.optical_flow(torch.from_numpy(frames).cuda(), want_flow=False, want_image=True)[1]
+    assert torch.equal(img, only)
+
+
 def test_batch_of_pairs_and_chunking():
     pairs = [_smooth_pair(120, 168, s) for s in range(3)]
     frames = np.stack([np.stack(p) for p in pairs])
