@@ -103,6 +103,14 @@ def test_pinned_feeder_overlaps_and_preserves_data():
     for k, batch in enumerate(seen):
         for j, b in enumerate(batch):
             assert torch.equal(b.cpu(), clips[(k * 2 + j) % 3]), (k, j)
+    # a second run on the same feeder, its first batch started ahead of time (bench.py's steady-state timing): same batches
+    again = []
+    feeder.prime()
+    feeder.run(3, lambda batch: again.append([b.clone() for b in batch]))
+    torch.cuda.synchronize()
+    for k, batch in enumerate(again):
+        for j, b in enumerate(batch):
+            assert torch.equal(b.cpu(), clips[(k * 2 + j) % 3]), (k, j)
 
 
 def test_bench_two_ranks_sharing_the_gpu():
