@@ -226,9 +226,8 @@ def main():
                          "planes, six partial products, fp32 accumulate - error against fp64 of the size of the fp32 path's "
                          "(tests/test_gpu_x6.py); fp32: exact fp32 MFMA; bf16x3: lower precision, never the headline")
     ap.add_argument("--clips-per-step", type=int, default=0,
-                    help="clips each rank pushes through the engine per step (one batched pass: B*2*T fragments); default 32 for the "
-                         "headline workload (config 3: the partial last round of tiles of every launch weighs half as much as at 16, "
-                         "+1 %), 16 for the others")
+                    help="clips each rank pushes through the engine per step (one batched pass: B*2*T fragments); default: 2048 "
+                         "fragments per pass for configs 2 / 3 / 4 (64 / 32 / 64 clips), 16 clips for the dataset pass and the full pipelines")
     ap.add_argument("--dataset-clips", type=int, default=0,
                     help="dataset mode (BASELINE config 4 as written): this many clips sharded over the ranks, one all-gather of the "
                          "[n, F] matrix at the end; strong scaling; --steps is ignored (the pass is ceil(n / ranks / clips-per-step) batches)")
@@ -245,7 +244,9 @@ def main():
                     help="only rehearse the N-rank launch + collectives (no engine, no GPU needed): tests/test_bench_launch.py")
     args = ap.parse_args()
     if args.clips_per_step <= 0:
-        args.clips_per_step = 32 if (args.workload == "config3" and not args.dataset_clips) else 16
+        # 2048 fragments per backbone pass for the backbone-only workloads (the partial last round of tiles of a launch weighs
+        # less: config 3 +1 %, config 2 +9 %, config 4 +4 % over 16 clips per step); the dataset pass and the full pipelines keep 16
+        args.clips_per_step = 16 if (args.dataset_clips or args.workload.startswith("full")) else 2048 // (2 * WORKLOADS[args.workload][2])
 
     # ---- launcher: nothing above or in this block touches a GPU -------------------------------------------------
     if args.gpus < 1:
@@ -394,7 +395,7 @@ def main():
     if world == 1 and not args.no_other_workloads and args.workload == "config3" and x6:
         del clips, step
         others = {}
-        for name, b_o in (("config2", 16), ("config4", 16), ("full2160p", 2)):
+        for name, b_o in (("config2", 64), ("config4", 64), ("full2160p", 2)):
             torch.cuda.empty_cache()
             step_o, dim_o, clips_o = make_step(name, b_o, 2, seed_base=50, distinct=2 if name == "full2160p" else 4)
             e_o, out_o, prof_o = timed(step_o, 3, 1)
