@@ -227,7 +227,7 @@ def main():
                          "(tests/test_gpu_x6.py); fp32: exact fp32 MFMA; bf16x3: lower precision, never the headline")
     ap.add_argument("--clips-per-step", type=int, default=0,
                     help="clips each rank pushes through the engine per step (one batched pass: B*2*T fragments); default: 2048 "
-                         "fragments per pass for configs 2 / 3 / 4 (64 / 32 / 64 clips), 16 clips for the dataset pass and the full pipelines")
+                         "fragments per pass for configs 2 / 3 / 4 (64 / 32 / 64 clips, dataset pass included), 16 clips for the full pipelines")
     ap.add_argument("--dataset-clips", type=int, default=0,
                     help="dataset mode (BASELINE config 4 as written): this many clips sharded over the ranks, one all-gather of the "
                          "[n, F] matrix at the end; strong scaling; --steps is ignored (the pass is ceil(n / ranks / clips-per-step) batches)")
@@ -244,9 +244,9 @@ def main():
                     help="only rehearse the N-rank launch + collectives (no engine, no GPU needed): tests/test_bench_launch.py")
     args = ap.parse_args()
     if args.clips_per_step <= 0:
-        # 2048 fragments per backbone pass for the backbone-only workloads (the partial last round of tiles of a launch weighs
-        # less: config 3 +1 %, config 2 +9 %, config 4 +4 % over 16 clips per step); the dataset pass and the full pipelines keep 16
-        args.clips_per_step = 16 if (args.dataset_clips or args.workload.startswith("full")) else 2048 // (2 * WORKLOADS[args.workload][2])
+        # 2048 fragments per backbone pass for the backbone-only workloads, the dataset pass included (the partial last round of tiles
+        # of a launch weighs less: config 3 +1 %, config 2 +9 %, config 4 +4 % over 16 clips per step); the full pipelines keep 16
+        args.clips_per_step = 16 if args.workload.startswith("full") else 2048 // (2 * WORKLOADS[args.workload][2])
 
     # ---- launcher: nothing above or in this block touches a GPU -------------------------------------------------
     if args.gpus < 1:
