@@ -56,3 +56,23 @@ def assert_close(got, want, what, rtol=RTOL, atol_frac=ATOL_FRAC):
     assert worst <= 1.0, (f"{what}: max err/bound {worst:.3g}; max abs err {err.max():.3e}, "
                           f"mean |want| {scale:.3e}, norm-rel {np.linalg.norm(got - want) / np.linalg.norm(want):.3e}")
     return float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
+
+
+def run_ranks(make_cmd, cwd, env, timeout=600, attempts=2):
+    """Runs a multi-rank launch line (make_cmd(port) -> argv) as a child process.  The rendezvous port is probed free a moment
+    before the launcher binds it, so another process can take it in between: a launch that dies on the rendezvous itself (address
+    in use / connection refused, nothing of bench.py has run yet) is repeated once on a fresh port; every other failure is
+    returned as it is."""
+    import socket
+    import subprocess
+    res = None
+    for _ in range(attempts):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        res = subprocess.run(make_cmd(port), cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
+        rendezvous = any(k in res.stderr for k in ("EADDRINUSE", "Address already in use", "address already in use",
+                                                   "RendezvousConnectionError", "Connection refused", "DistNetworkError"))
+        if res.returncode == 0 or not rendezvous:
+            break
+    return res

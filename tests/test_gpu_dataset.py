@@ -3,7 +3,6 @@ the NaN-row failure contract, per-frame files - and the strong-scaling bench mod
 Reference: the per-video loop src/main_fragment_layerstack.py:269-361 and src/data_processing/extract_npy2mat.py:117-130."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -93,19 +92,16 @@ def test_dataset_full_vectors_and_the_quality_head_on_a_matrix_with_a_failed_cli
 
 
 def _bench_dataset(n_ranks, dump, extra_env=None):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    from tests.gpu_common import run_ranks
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     args = [os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--workload", "config4", "--dataset-clips", "7",
             "--clips-per-step", "2", "--warmup", "1", "--gemm-split-k", "0", "--resident-clips", "3", "--dump-matrix", dump]
     if n_ranks > 1:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
-               "127.0.0.1", "--master-port", str(port)] + args
+        res = run_ranks(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+                                      "--master-addr", "127.0.0.1", "--master-port", str(port)] + args, ROOT, env, timeout=900)
     else:
-        cmd = [sys.executable] + args
-    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        res = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout
