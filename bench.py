@@ -395,7 +395,7 @@ def main():
     if world == 1 and not args.no_other_workloads and args.workload == "config3" and x6:
         del clips, step
         others = {}
-        for name, b_o in (("config2", 64), ("config4", 64), ("full2160p", 2)):
+        for name, b_o in (("config2", 64), ("config4", 64), ("full2160p", 8)):
             torch.cuda.empty_cache()
             step_o, dim_o, clips_o = make_step(name, b_o, 2, seed_base=50, distinct=2 if name == "full2160p" else 4)
             e_o, out_o, prof_o = timed(step_o, 3, 1)
