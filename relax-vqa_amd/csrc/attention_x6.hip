@@ -143,6 +143,21 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
     A6_STORE_K();
     __syncthreads();
 
+#ifdef RELAX_A6_STAMPS   // diagnostic build (tools/build_ablations.sh a6stamps): ticks per phase of an item, waves 0 and 6 of workgroup 3
+    unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();
+    int items_done = 0;
+#define A6_STAMP(i_)                                                                                                 \
+    {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime();                                                  \
+        ph[i_] += n_ - t_;                                                                                           \
+        t_ = n_;                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+#else
+#define A6_STAMP(i_)
+#endif
     while (true) {
         A6_DMA(item, 2);   // V rows: in flight during the score phase
         // ---- scores: S^T tile kt = K[kt] Q^T, 4 d-steps x 6 partial products (smallest first) -------------------------
@@ -177,6 +192,7 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef A6_READ_K
+        A6_STAMP(0);   // scores
         // sacc[kt][r] = score(query li, key kt*32 + (r&3) + 8*(r>>2) + 4*half) * log2(e)
         float mx = -INFINITY;
 #pragma unroll
@@ -199,10 +215,13 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
             }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
+        A6_STAMP(1);   // softmax
         A6_WAIT_DMA();
         __syncthreads();          // every wave is done with K, and the V rows have landed
+        A6_STAMP(2);   // wait for V + barrier
         A6_STORE_V();             // V^T takes K's place
         __syncthreads();
+        A6_STAMP(3);   // V rows -> transposed plane image + barrier
         const int next = item + gridDim.x;
         if (next < total_items) A6_DMA(next, 1);       // K rows of the next item: in flight during the output phase
 
@@ -253,6 +272,7 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
         }
 #undef A6_READ_V
 #undef A6_SPLIT_P
+        A6_STAMP(4);   // P V
         // oacc[dt][r] = O(query li, d = dt*32 + (r&3) + 8*(r>>2) + 4*half): runs of 4 consecutive d.  The lane^32 partner
         // holds the runs in between: after swapping two runs per tile each lane owns two units of 8 consecutive d
         //   half 0: d = dt*32 + 0..7 and 16..23        half 1: d = dt*32 + 8..15 and 24..31
@@ -287,14 +307,27 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
                 }
             }
         }
+        A6_STAMP(5);   // epilogue
+#ifdef RELAX_A6_STAMPS
+        ++items_done;
+#endif
         if (next >= total_items) break;
         A6_SPLIT_Q();
+        A6_STAMP(6);   // split of the next Q
         A6_WAIT_DMA();
         __syncthreads();          // every wave is done with V^T, and the K rows have landed
+        A6_STAMP(7);   // wait for K + barrier
         A6_STORE_K();             // next item's K
         __syncthreads();
+        A6_STAMP(8);   // K rows -> plane image + barrier
         item = next;
     }
+#ifdef RELAX_A6_STAMPS
+    if (OUT_F32 && blockIdx.x == 3 && (tid == 0 || tid == 6 * 64)) {   // (the fp32-output form only: the averages go out in the first floats of `out`)
+        for (int i = 0; i < 9; ++i) out[(tid ? 16 : 0) + i] = (float)(ph[i] / items_done);
+    }
+#endif
+#undef A6_STAMP
 #undef A6_DMA
 #undef A6_WAIT_DMA
 #undef A6_STORE_K
