@@ -189,6 +189,12 @@ def self_launch(n_ranks, argv):
     return proc.returncode
 
 
+def _rccl_ranks(world, backend):
+    """Ranks whose collective ran over RCCL: `world` under the nccl backend (and for the single rank of an N = 1 run, which has no
+    collective), 0 under gloo (the rehearsal backend of several ranks sharing one GPU) - `ranks` / `backend` say what ran."""
+    return world if (world == 1 or backend == "nccl") else 0
+
+
 def launch_check(rank, world):
     """--launch-check: the multi-rank control flow of this file without an engine (CPU test of the launcher): rendezvous,
     barrier, the feature all-gather on stand-in per-clip vectors, the max-over-ranks timing reduction, one JSON line."""
@@ -204,8 +210,9 @@ def launch_check(rank, world):
     want = torch.arange(world, dtype=torch.float32).repeat_interleave(2)[:, None].expand(-1, 5)
     assert torch.equal(out.cpu(), want), "all-gather returned rows out of clip order"
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": world,
-                          "backend": dist.get_backend() if world > 1 else None, "pids_distinct": True}))
+        backend = dist.get_backend() if world > 1 else None
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": world, "rccl_ranks": _rccl_ranks(world, backend),
+                          "backend": backend, "pids_distinct": True}))
     if world > 1:
         rdist.barrier()
         dist.destroy_process_group()
@@ -235,6 +242,12 @@ def main():
     ap.add_argument("--gemm-split-k", type=int, default=1, choices=[0, 1],
                     help="0: no tail split-K - bits independent of the batch composition, i.e. of the number of ranks")
     ap.add_argument("--dump-matrix", default=None, help="dataset mode: rank 0 saves the gathered [n, F] matrix as .npy (tests)")
+    ap.add_argument("--host-clips", action="store_true",
+                    help="dataset mode: after the device-resident pass, the same pass with every clip living in (pageable) host memory - "
+                         "loader threads stage it in pinned buffers, a side stream copies batch k+1 under the compute of batch k "
+                         "(relax-vqa_amd/dataset.py); reported beside `value` as `host_fed` with `h2d_hidden_frac`")
+    ap.add_argument("--prefetch", type=int, default=2, help="dataset mode: batches the loader threads run ahead of the engine (0: inline, no threads)")
+    ap.add_argument("--loader-workers", type=int, default=8, help="dataset mode: loader threads per rank")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short extra measurements of configs 2 / 4 / 5")
     ap.add_argument("--no-measure-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only); a committed profile "
@@ -356,15 +369,14 @@ def main():
         feeder = PinnedClipFeeder([host_clips[j % n_resident] for j in range(B)], B, eng.device)
         run = lambda batch: eng.clip_vectors(batch, resnet=True, vit=use_vit)   # noqa: E731
         feeder.run(2, run)
-        feeder.prime()          # the first batch of the timed steps is on its way (and waited for by the barrier): steady state
-        feeder.copy_stream.synchronize()
         barrier()
         t2 = time.perf_counter()
-        feeder.run(args.steps, run)
+        feeder.run(args.steps, run)     # `steps` copies and `steps` compute passes inside the clock: the first copy has nothing to hide under
         barrier()
         e2 = time.perf_counter() - t2
         h2d = {"value": args.steps * B / e2, "unit": "clips/s", "ms_per_step": e2 / args.steps * 1e3,
-               "note": "every clip copied pinned host -> device on a side stream, double-buffered under the compute (steady state: the copy of the first timed batch is issued before the clock starts)"}
+               "note": "every clip copied pinned host -> device on a side stream, double-buffered under the compute; all `steps` copies are "
+                       "inside the timed region (the first one is exposed, the others hide under the previous step)"}
         del feeder, host_clips
 
     # the other fp32-grade arithmetic, measured beside the headline on the same workload and step function
@@ -413,6 +425,9 @@ def main():
                                               "kernel_time_share_of_step": fl_ms * 1e-3 / e_o}
             others[name] = rec
             del step_o, clips_o, out_o
+        torch.cuda.empty_cache()
+        others["config4_dataset"] = dataset_pass(eng, "config4", 256, 64, 0, 1, args.gemm_split_k, host_clips=True, prefetch=args.prefetch,
+                                                 workers=args.loader_workers, n_resident=4, warmup=1)
 
     if world > 1:
         elapsed = rdist.all_reduce_max(elapsed, "cuda")
@@ -435,7 +450,9 @@ def main():
         result = {
             "metric": "clips/sec (32 sampled frames, 1080p) feature extraction" if args.workload == "config3"
                       else f"clips/sec feature extraction ({args.workload})",
-            "value": clips_total / elapsed, "unit": "clips/s", "n_gpus": world, "rccl_ranks": world, "steps": args.steps,
+            "value": clips_total / elapsed, "unit": "clips/s", "n_gpus": world, "ranks": world,
+            "backend": dist.get_backend() if world > 1 else None,
+            "rccl_ranks": _rccl_ranks(world, dist.get_backend() if world > 1 else None), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_TEXT[precision],
@@ -502,48 +519,90 @@ def workload_text(name):
             + (" + whole-frame features + Farneback flow fragments (35203-d)" if name.startswith("full") else "") + ", random-init weights")
 
 
-def dataset_mode(args, eng, rank, world, barrier, precision):
-    """BASELINE config 4 as written: --dataset-clips clips sharded over the ranks (relax-vqa_amd/dataset.py), ONE all-gather of the
-    [n, F] matrix; strong scaling: value = n clips / the time of the whole pass (max over ranks), warm-up batches untimed."""
+def dataset_pass(eng, workload, n, B, rank, world, split_k, host_clips=False, prefetch=2, workers=8, n_resident=4, warmup=1, dump=None):
+    """BASELINE config 4 as written: n clips sharded over the ranks (relax-vqa_amd/dataset.py), ONE all-gather of the [n, F] matrix;
+    strong scaling: value = n clips / the time of the whole pass (max over ranks), warm-up batches untimed.  `value` is the pass over
+    device-resident clips (the metric's definition); host_clips adds the same pass fed from pageable host memory.
+    -> the record (a dict; complete on every rank, printed by rank 0)."""
     from relax_vqa_amd import dataset
-    H, W, T, use_vit = WORKLOADS[args.workload]
-    full = args.workload.startswith("full")
-    n = args.dataset_clips
-    B = args.clips_per_step
-    n_resident = args.resident_clips or 4
+    H, W, T, use_vit = WORKLOADS[workload]
+    full = workload.startswith("full")
     # every rank holds the same few distinct clips; clip i of the list is resident[i % n_resident] (the list is synthetic: what is
     # measured is the pass over n clips, and a rank count must not change which pixels clip i has)
-    resident = [torch.from_numpy(synth.synthetic_clip(T, H, W, clip_id=700 + i, distinct=4)).cuda() for i in range(n_resident)]
-    source = lambda i: resident[i % n_resident]   # noqa: E731
-    kw = dict(clips_per_step=B, resnet=True, vit=use_vit, full=full, rank=rank, world=world)
-    for _ in range(args.warmup):
-        dataset.extract_dataset_clips(source, min(B * world, n), eng, **kw)
-    barrier()
-    timings = {}
-    t0 = time.perf_counter()
-    matrix, errors = dataset.extract_dataset_clips(source, n, eng, timings=timings, **kw)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gather_s = timings["all_gather_s"]
-    if world > 1:
-        elapsed = rdist.all_reduce_max(elapsed, "cuda")
-        gather_s = rdist.all_reduce_max(gather_s, "cuda")
+    host = [synth.synthetic_clip(T, H, W, clip_id=700 + i, distinct=4) for i in range(n_resident)]
+    resident = [torch.from_numpy(c).cuda() for c in host]
     F = dataset.feature_dim(eng, True, use_vit, full)
-    assert matrix.shape == (n, F) and not errors and bool(torch.isfinite(matrix).all()), (matrix.shape, errors[:3])
+    # batch_invariant: the pass itself switches the tail split-K off unless the command line asks for the split (rank-count-invariant bits)
+    kw = dict(clips_per_step=B, resnet=True, vit=use_vit, full=full, rank=rank, world=world, prefetch=prefetch, workers=workers,
+              batch_invariant=(split_k == 0))
+
+    def barrier():
+        if world > 1:
+            rdist.barrier()
+        torch.cuda.synchronize()
+
+    def one_pass(source, warm_clips):
+        for _ in range(warmup):
+            dataset.extract_dataset_clips(source, min(warm_clips, n), eng, **kw)
+        barrier()
+        timings = {}
+        t0 = time.perf_counter()
+        matrix, errors = dataset.extract_dataset_clips(source, n, eng, timings=timings, **kw)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        gather_s = timings["all_gather_s"]
+        if world > 1:
+            elapsed = rdist.all_reduce_max(elapsed, "cuda")
+            gather_s = rdist.all_reduce_max(gather_s, "cuda")
+        assert matrix.shape == (n, F) and not errors and bool(torch.isfinite(matrix).all()), (matrix.shape, errors[:3])
+        return matrix, elapsed, gather_s, timings
+
+    matrix, elapsed, gather_s, timings = one_pass(lambda i: resident[i % n_resident], B * world)
+    if dump and rank == 0:
+        np.save(dump, matrix.cpu().numpy())
+    per_rank = -(-n // world)
+    backend = dist.get_backend() if world > 1 else None
+    rec = {
+        "metric": f"clips/sec feature extraction, dataset pass ({workload}, {n} clips sharded over the ranks)",
+        "value": n / elapsed, "unit": "clips/s", "n_gpus": world, "ranks": world, "backend": backend,
+        "rccl_ranks": _rccl_ranks(world, backend), "steps": -(-per_rank // B),
+        "warmup": warmup, "ms_per_step": elapsed / (-(-per_rank // B)) * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": DTYPE_TEXT[eng.precision()], "data": "synthetic",
+        "config": {"workload": workload_text(workload) + f"; {n} clips, contiguous shards of <= {per_rank}",
+                   "dataset_clips": n, "clips_per_step_per_gpu": B, "pairs_per_clip": T, "feature_dim": F, "distinct_clips": n_resident,
+                   "parallelism": f"clip-sharded dp{world}, one RCCL all-gather of the [{n}, {F}] matrix"},
+        "all_gather_ms": gather_s * 1e3, "extract_s": timings["extract_s"], "errors": 0,
+        "gemm_split_k": split_k, "prefetch_batches": prefetch, "loader_workers": workers}
+    if host_clips:
+        # the same pass with every clip in pageable host memory (numpy arrays, as a decoder would hand them over)
+        m_h, e_h, g_h, t_h = one_pass(lambda i: host[i % n_resident], (prefetch + 2) * B * world)
+        assert torch.equal(m_h, matrix), "the host-fed pass changed the matrix"
+        # what the copies would cost alone: one batch of this rank's clips, pinned -> device, timed on an idle GPU
+        pin = [torch.from_numpy(host[j % n_resident]).pin_memory() for j in range(min(B, 8))]
+        dst = [torch.empty_like(p, device="cuda") for p in pin]
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for p, d in zip(pin, dst):
+            d.copy_(p, non_blocking=True)
+        torch.cuda.synchronize()
+        bw = sum(p.numel() for p in pin) / (time.perf_counter() - tc)
+        t_copy = t_h["h2d_bytes"] / bw
+        rec["host_fed"] = {"value": n / e_h, "unit": "clips/s", "frac_of_device_resident": elapsed / e_h,
+                           "h2d_hidden_frac": max(0.0, min(1.0, 1.0 - max(0.0, e_h - elapsed) / t_copy)) if t_copy > 0 else None,
+                           "h2d_GB": t_h["h2d_bytes"] / 1e9, "h2d_alone_s": t_copy, "pinned_h2d_GBps": bw / 1e9,
+                           "loader_wait_s": t_h["loader_wait_s"], "extract_s": t_h["extract_s"], "matrix_equal_to_device_resident": True,
+                           "note": "clips in pageable host memory -> loader threads copy them into pinned staging -> side-stream H2D of batch "
+                                   "k+1 under the compute of batch k (relax-vqa_amd/dataset.py::ClipStager); never `value`"}
+        del pin, dst
+    return rec
+
+
+def dataset_mode(args, eng, rank, world, barrier, precision):
+    rec = dataset_pass(eng, args.workload, args.dataset_clips, args.clips_per_step, rank, world, args.gemm_split_k,
+                       host_clips=args.host_clips, prefetch=args.prefetch, workers=args.loader_workers,
+                       n_resident=args.resident_clips or 4, warmup=args.warmup, dump=args.dump_matrix)
     if rank == 0:
-        if args.dump_matrix:
-            np.save(args.dump_matrix, matrix.cpu().numpy())
-        per_rank = -(-n // world)
-        print(json.dumps({
-            "metric": f"clips/sec feature extraction, dataset pass ({args.workload}, {n} clips sharded over the ranks)",
-            "value": n / elapsed, "unit": "clips/s", "n_gpus": world, "rccl_ranks": world, "steps": -(-per_rank // B),
-            "warmup": args.warmup, "ms_per_step": elapsed / (-(-per_rank // B)) * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": DTYPE_TEXT[precision], "data": "synthetic",
-            "config": {"workload": workload_text(args.workload) + f"; {n} clips, contiguous shards of <= {per_rank}",
-                       "dataset_clips": n, "clips_per_step_per_gpu": B, "pairs_per_clip": T, "feature_dim": F, "distinct_clips": n_resident,
-                       "parallelism": f"clip-sharded dp{world}, one RCCL all-gather of the [{n}, {F}] matrix"},
-            "all_gather_ms": gather_s * 1e3, "extract_s": timings["extract_s"], "errors": len(errors),
-            "gemm_split_k": args.gemm_split_k}))
+        print(json.dumps(rec))
     if world > 1:
         rdist.barrier()
         dist.destroy_process_group()

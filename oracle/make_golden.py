@@ -151,6 +151,19 @@ def golden_fragment_png(report):
                    "_residual_merged_frag"]:
         shutil.copyfile(os.path.join(base, "original_5636101558", f"5636101558_3{suffix}.png"),
                         os.path.join(dst, f"5636101558_3{suffix}.png"))
+    # and the sets at the headline (1080p) and config-5 (2160p) resolutions, so that the HIP path meets real video content -
+    # flat regions, scores close to rank 196, OpenCV's own flow image - at the sizes the bench runs (tests/test_gpu_reference_png_sets.py).
+    # 1080p: the full set but `_residual.png` (4 MB; it is |next - orig|, recomputed and checked above); 2160p: all five files the
+    # reference ships (the frames themselves are not in its tree).
+    for d, stem, suffixes in (
+            ("original_TelevisionClip_1080P-68c6", "TelevisionClip_1080P-68c6_1",
+             ["", "_next", "_residual_imp", "_ori_frag", "_residual_of", "_residual_of_imp", "_residual_merged_frag"]),
+            ("original_Sports_2160P-0455", "Sports_2160P-0455_1",
+             ["_ori_frag", "_residual_imp", "_residual_of", "_residual_of_imp", "_residual_merged_frag"])):
+        dst = os.path.join(GOLD, "png_" + stem)
+        os.makedirs(dst, exist_ok=True)
+        for suffix in suffixes:
+            shutil.copyfile(os.path.join(base, d, f"{stem}{suffix}.png"), os.path.join(dst, f"{stem}{suffix}.png"))
 
 
 def golden_pooling(mfl, mrf, mfp, report):

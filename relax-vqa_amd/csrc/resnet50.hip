@@ -327,9 +327,12 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
     };
     auto pool_tail = [&](const float* last32, float* avg_ws, float* gap_scratch) -> int {   // last32: fp32 [N,49,2048] of the last block
         if (!pool) return RELAX_OK;
-        const float* avg_src = layer_stack + (RELAX_RN50_LAYER_STACK_DIM - 2048);
-        int64_t avg_stride = RELAX_RN50_LAYER_STACK_DIM;
-        if (!pool_from_stack) {
+        const float* avg_src;
+        int64_t avg_stride;
+        if (pool_from_stack) {      // (layer_stack is non-null here; no pointer arithmetic on it otherwise)
+            avg_src = layer_stack + (RELAX_RN50_LAYER_STACK_DIM - 2048);
+            avg_stride = RELAX_RN50_LAYER_STACK_DIM;
+        } else {
             RELAX_TRY(launch_gap_ws(h, last32 + (size_t)pool_from * 49 * 2048, avg_ws, n_pool, 49, 2048, 2048, gap_scratch, s));
             avg_src = avg_ws;
             avg_stride = 2048;

@@ -8,6 +8,9 @@ frames of every file into one [n_videos, F] matrix, saved as a .mat keyed by the
 
   rank r owns the contiguous block `shard_clips(n_clips, r, world)` of clip indices          (distributed.py)
   batches of `clips_per_step` clips go through RelaxEngine.clip_vectors / full_clip_vectors   (one pass of each backbone)
+  the pass is HOST-FED and OVERLAPPED: `workers` loader threads call clips(i) for the next `prefetch` batches (decode / read /
+    resume-from-file happen there) and land host clips in pinned staging buffers; a side HIP stream copies batch k+1 into the
+    other of two device slots while the engine works on batch k; events order the two streams both ways      (ClipStager)
   optional: the per-frame [T,F] rows of every clip are written under the reference's file name (resume: skip_existing)
   the [n_local, F] means are all-gathered into the [n_clips, F] matrix every rank returns     (RCCL over xGMI; gloo on CPU)
   optional: rank 0 writes the .mat the reference's regression scripts read
@@ -15,9 +18,12 @@ frames of every file into one [n_videos, F] matrix, saved as a .mat keyed by the
 Failure contract: a clip that cannot be loaded or extracted does not take its batch - or the run - down.  Its
 row in the matrix is NaN and (clip index, message) goes into the returned error list (gathered over the ranks, sorted);
 the reference's imputer zeroes NaN / inf before the regressor (src/model_regression.py:123-126), relax_mlp_head imputes
-them with the training means.
+them with the training means.  A loader thread that raises yields exactly that entry for its clip; nothing waits on it forever.
 """
 import os
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -50,20 +56,123 @@ def _check_clip(clip):
         raise ValueError(f"frames of {shape[3]}x{shape[2]} hold no 16x16 patch")
 
 
+class ClipStager:
+    """Pinned host staging + two device slots + a side stream for one (process, device).  Kept on the engine object between
+    passes so that the pinned and device buffers are allocated once (hipHostMalloc of GBs is slow).
+
+    Loader threads call `to_pinned(host_tensor)`; the driver thread calls `upload(list of clips)` for batch k+1 right after it
+    has enqueued the compute of batch k, then `done_with(token)` once that batch has been consumed.  Clips already on the device
+    pass through untouched; on a CPU 'device' (tests with a stand-in engine) everything passes through."""
+
+    def __init__(self, device):
+        self.device = device
+        self.on_gpu = device.type == "cuda"
+        self._lock = threading.Lock()
+        self._pinned_free = {}                       # nbytes -> [pinned flat uint8 tensors]
+        self.bytes_copied = 0
+        if self.on_gpu:
+            self.copy_stream = torch.cuda.Stream(device=device)
+            self._slots = [None, None]               # flat uint8 device buffers, grown on demand
+            self._free = [torch.cuda.Event(), torch.cuda.Event()]     # compute has finished with the slot
+            for e in self._free:
+                e.record(torch.cuda.current_stream(device))
+            self._turn = 0
+
+    # ---- loader-thread side ------------------------------------------------------------------------------
+    def to_pinned(self, t):
+        """host uint8 tensor -> (pinned tensor of the same shape, buffer to hand back) - a copy unless `t` is pinned already."""
+        if not self.on_gpu or t.is_pinned():
+            return t, None
+        n = t.numel()
+        with self._lock:
+            free = self._pinned_free.get(n)
+            buf = free.pop() if free else None
+        if buf is None:
+            buf = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        buf.copy_(t.reshape(-1))                     # releases the GIL: the loader threads copy in parallel
+        return buf.view(t.shape), buf
+
+    def give_back(self, bufs):
+        with self._lock:
+            for b in bufs:
+                if b is not None:
+                    self._pinned_free.setdefault(b.numel(), []).append(b)
+
+    # ---- driver-thread side --------------------------------------------------------------------------------
+    def upload(self, clips):
+        """clips: device tensors and / or (pinned) host tensors -> (device tensors, token).  Host clips are copied on the side
+        stream into this turn's device slot; the current stream is made to wait for the copies in `wait(token)`."""
+        if not self.on_gpu or all(c.is_cuda for c in clips):
+            return list(clips), None
+        slot = self._turn
+        self._turn ^= 1
+        cur = torch.cuda.current_stream(self.device)
+        sizes = [0 if c.is_cuda else -(-c.numel() // 256) * 256 for c in clips]
+        need = sum(sizes)
+        with torch.cuda.stream(self.copy_stream):
+            if self._slots[slot] is None or self._slots[slot].numel() < need:
+                self._slots[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)   # block of the copy stream's pool ...
+                self._slots[slot].record_stream(cur)                                           # ... that the compute stream reads
+            self.copy_stream.wait_event(self._free[slot])        # the batch that used this slot two turns ago is through
+            out, at = [], 0
+            for c, sz in zip(clips, sizes):
+                if c.is_cuda:
+                    out.append(c)
+                    continue
+                d = self._slots[slot][at:at + c.numel()].view(c.shape)
+                d.copy_(c, non_blocking=True)
+                out.append(d)
+                at += sz
+                self.bytes_copied += c.numel()
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        return out, (slot, ready)
+
+    def wait(self, token):
+        if token is not None:
+            torch.cuda.current_stream(self.device).wait_event(token[1])
+
+    def done_with(self, token):
+        """Called after the batch's compute has been enqueued on the current stream."""
+        if token is not None:
+            self._free[token[0]].record(torch.cuda.current_stream(self.device))
+
+    def copies_landed(self, token):
+        if token is not None:
+            token[1].synchronize()
+
+
+def _stager(engine):
+    st = getattr(engine, "_clip_stager", None)
+    if st is None or st.device != engine.device:
+        st = ClipStager(engine.device)
+        try:
+            engine._clip_stager = st
+        except AttributeError:
+            pass
+    return st
+
+
 def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=True, vit=True, full=False, flow=True,
                           out_dir=None, network_name="resnet50", skip_existing=False, mat_path=None, data_name=None,
-                          rank=None, world=None, group=None, timings=None):
+                          rank=None, world=None, group=None, timings=None, prefetch=2, workers=4, batch_invariant=True):
     """clips: callable i -> uint8 [T,2,H,W,3] (device tensor, host tensor or ndarray; T and the resolution may differ from
-    clip to clip), or a sequence indexed the same way.  Only this rank's shard is ever requested.
+    clip to clip), or a sequence indexed the same way.  Only this rank's shard is ever requested; the callable runs in loader
+    threads (`workers` of them, up to `prefetch` batches ahead of the engine), so it may block on I/O or decode.
     -> (matrix fp32 [n_clips, F] on the engine's device, identical on every rank; errors [(clip index, message), ...]).
 
+    prefetch = 0: no loader threads, no side stream - clips(i) is called in the driver thread as the batch is assembled (the
+             round-3 behaviour; same rows bit for bit).
+    batch_invariant (default): the pass runs with the engine's tail split-K off, so a clip's row does not depend on which clips
+             share its batch - i.e. not on the number of ranks (engine.clip_vectors); the option is restored afterwards.
     out_dir: write each clip's per-frame rows [T, F] as `video_{i+1}_{network_name}_feature_map_original.npy`
-             (sampling.feature_file_name); with skip_existing a clip whose file exists is not recomputed: its row is the mean
-             of the stored rows (the resume the reference lacks).  Not available with full=True (whole-frame and fragment
-             features have different frame counts there).
+             (sampling.feature_file_name; written to a temporary name and renamed, so a killed run never leaves a truncated file
+             under the final name); with skip_existing a clip whose file exists is not recomputed: its row is the mean of the
+             stored rows (the resume the reference lacks) - a file that cannot be read or has the wrong shape is recomputed and
+             overwritten.  Not available with full=True (whole-frame and fragment features have different frame counts there).
     mat_path / data_name: rank 0 saves the matrix as {data_name: float64 [n_clips, F]} (extract_npy2mat.py:79-84).
-    timings: optional dict, receives 'extract_s' and 'all_gather_s' (device-synchronised wall times of the two phases)."""
-    import time
+    timings: optional dict, receives 'extract_s', 'all_gather_s' (device-synchronised wall times of the two phases),
+             'loader_wait_s' (time the driver thread spent waiting for loader threads) and 'h2d_bytes'."""
     if rank is None or world is None:
         import torch.distributed as dist
         on = dist.is_available() and dist.is_initialized()
@@ -71,12 +180,27 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         world = dist.get_world_size(group) if on else 1
     if out_dir is not None and full:
         raise ValueError("per-frame files are written for the fragment features only (full=False)")
+    B = int(clips_per_step)
+    if B < 1:
+        raise ValueError(f"clips_per_step must be >= 1, got {clips_per_step!r}")
     get = clips if callable(clips) else clips.__getitem__
     mine = rdist.shard_clips(n_clips, rank, world)
     F = feature_dim(engine, resnet, vit, full)
     dev = engine.device
+    on_gpu = dev.type == "cuda"
     local = torch.full((len(mine), F), float("nan"), dtype=torch.float32, device=dev)
     errors = []
+    stager = _stager(engine) if prefetch > 0 else None
+    # (loader threads start on device 0 like every new thread: name this rank's device before they pin memory or touch tensors)
+    pool = ThreadPoolExecutor(max_workers=max(int(workers), 1), thread_name_prefix="relax-loader",
+                              initializer=(lambda: torch.cuda.set_device(dev)) if on_gpu else None) if prefetch > 0 else None
+    h2d_bytes0 = stager.bytes_copied if stager is not None else 0
+    writes = []
+
+    restore_split = None
+    if batch_invariant and hasattr(engine, "get_option") and hasattr(engine, "set_option"):
+        restore_split = engine.get_option("gemm_split_k")
+        engine.set_option("gemm_split_k", 0)
 
     def run(batch):
         if full:
@@ -86,56 +210,128 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         return engine.clip_vectors(batch, resnet=resnet, vit=vit), None
 
     def store(slots, idxs, vecs, frames):
-        local[torch.as_tensor(slots, device=dev)] = vecs
+        if slots == list(range(slots[0], slots[0] + len(slots))):
+            local[slots[0]:slots[0] + len(slots)] = vecs          # device-to-device on the current stream: no host sync
+        else:
+            local[torch.as_tensor(slots, device=dev)] = vecs
         if frames is not None:
             for i, rows in zip(idxs, frames):
-                sampling.save_clip_features(out_dir, i, network_name, rows.cpu().numpy())
+                arr = rows.cpu().numpy()
+                if pool is not None:
+                    writes.append(pool.submit(sampling.save_clip_features, out_dir, i, network_name, arr))
+                else:
+                    sampling.save_clip_features(out_dir, i, network_name, arr)
 
-    torch.cuda.synchronize(dev) if dev.type == "cuda" else None
-    t0 = time.perf_counter()
-    for lo in range(0, len(mine), max(int(clips_per_step), 1)):
-        slots, idxs, batch = [], [], []
-        for slot, i in enumerate(mine[lo:lo + clips_per_step], start=lo):
-            try:
-                if out_dir is not None and skip_existing:
-                    path = os.path.join(out_dir, sampling.feature_file_name(i, network_name))
-                    if os.path.exists(path):
+    def load(i):
+        """One clip, in a loader thread (or inline when prefetch = 0) -> ("row", mean vector) | ("clip", tensor, pinned buffer) |
+        ("err", message).  Never raises."""
+        try:
+            if out_dir is not None and skip_existing:
+                path = os.path.join(out_dir, sampling.feature_file_name(i, network_name))
+                if os.path.exists(path):
+                    try:
                         rows = np.load(path)
-                        if rows.ndim != 2 or rows.shape[1] != F:
-                            raise ValueError(f"{path}: stored rows are {rows.shape}, expected [T,{F}]")
-                        local[slot] = torch.from_numpy(rows.mean(axis=0).astype(np.float32)).to(dev)
-                        continue
-                clip = get(i)
-                _check_clip(clip)
+                        if rows.ndim == 2 and rows.shape[1] == F and rows.shape[0] > 0:
+                            return ("row", rows.mean(axis=0).astype(np.float32))
+                    except Exception:                   # noqa: BLE001 - truncated / foreign file: recompute and overwrite it
+                        pass
+            clip = get(i)
+            _check_clip(clip)
+            t = clip if isinstance(clip, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(clip))
+            if t.is_cuda or stager is None:
+                return ("clip", t, None)
+            t, buf = stager.to_pinned(t.contiguous())
+            return ("clip", t, buf)
+        except Exception as e:                          # noqa: BLE001 - the contract: the clip fails, the run goes on
+            return ("err", f"{type(e).__name__}: {e}")
+
+    batches = [mine[lo:lo + B] for lo in range(0, len(mine), B)]
+    futures = {}
+    loader_wait = 0.0
+
+    def submit(b):
+        if pool is not None and 0 <= b < len(batches) and b not in futures:
+            futures[b] = [pool.submit(load, i) for i in batches[b]]
+
+    def stage(b):
+        """Collect batch b from the loaders and start its host-to-device copies -> (slots, idxs, device clips, token, pinned)."""
+        nonlocal loader_wait
+        t_w = time.perf_counter()
+        results = [f.result() for f in futures.pop(b)] if pool is not None else [load(i) for i in batches[b]]
+        loader_wait += time.perf_counter() - t_w
+        slots, idxs, host, pinned = [], [], [], []
+        for slot, (i, r) in enumerate(zip(batches[b], results), start=b * B):
+            if r[0] == "err":
+                errors.append((i, r[1]))
+            elif r[0] == "row":
+                local[slot] = torch.from_numpy(r[1]).to(dev)
+            else:
                 slots.append(slot)
                 idxs.append(i)
-                batch.append(clip if isinstance(clip, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(clip)))
-            except Exception as e:                      # noqa: BLE001 - the contract: the clip fails, the run goes on
-                errors.append((i, f"{type(e).__name__}: {e}"))
-        if not batch:
-            continue
-        try:
-            vecs, frames = run(batch)
-            store(slots, idxs, vecs, frames)
-        except Exception as e0:                         # noqa: BLE001 - find the clip(s) that broke the batch, keep the others
-            if len(batch) == 1:
-                errors.append((idxs[0], f"{type(e0).__name__}: {e0}"))
-                continue
-            for slot, i, clip in zip(slots, idxs, batch):
+                host.append(r[1])
+                pinned.append(r[2])
+        if not host:
+            return slots, idxs, [], None, pinned
+        if stager is not None:
+            devs, token = stager.upload(host)
+        else:
+            devs, token = host, None
+        return slots, idxs, devs, token, pinned
+
+    try:
+        torch.cuda.synchronize(dev) if on_gpu else None
+        t0 = time.perf_counter()
+        for b in range(min(prefetch + 1, len(batches))):
+            submit(b)
+        staged = stage(0) if batches else None
+        for b in range(len(batches)):
+            slots, idxs, batch, token, pinned = staged
+            failed = None
+            if batch:
+                if stager is not None:
+                    stager.wait(token)
                 try:
-                    vecs, frames = run([clip])
-                    store([slot], [i], vecs, frames)
-                except Exception as e:                  # noqa: BLE001
-                    errors.append((i, f"{type(e).__name__}: {e}"))
-    torch.cuda.synchronize(dev) if dev.type == "cuda" else None
-    t1 = time.perf_counter()
+                    vecs, frames = run(batch)
+                except Exception as e0:                     # noqa: BLE001 - find the clip(s) that broke the batch, keep the others
+                    failed = e0
+            # batch b's compute is enqueued: get batch b+1 from the loaders and start its copies under it, refill the loader queue
+            if b + 1 < len(batches):
+                submit(b + 1 + prefetch)
+                staged = stage(b + 1)
+            if batch:
+                if failed is None:
+                    store(slots, idxs, vecs, frames)
+                elif len(batch) == 1:
+                    errors.append((idxs[0], f"{type(failed).__name__}: {failed}"))
+                else:
+                    for slot, i, clip in zip(slots, idxs, batch):
+                        try:
+                            vecs, frames = run([clip])
+                            store([slot], [i], vecs, frames)
+                        except Exception as e:              # noqa: BLE001
+                            errors.append((i, f"{type(e).__name__}: {e}"))
+                if stager is not None:
+                    stager.done_with(token)
+                    stager.copies_landed(token)
+                    stager.give_back(pinned)
+        for w in writes:
+            w.result()
+        torch.cuda.synchronize(dev) if on_gpu else None
+        t1 = time.perf_counter()
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
+        if restore_split is not None:
+            engine.set_option("gemm_split_k", restore_split)
     matrix = rdist.gather_clip_vectors(local, n_clips, rank, world, group)
     all_errors = sorted(e for part in rdist.gather_objects(errors, world, group) for e in part)
-    torch.cuda.synchronize(dev) if dev.type == "cuda" else None
+    torch.cuda.synchronize(dev) if on_gpu else None
     t2 = time.perf_counter()
     if timings is not None:
         timings["extract_s"] = t1 - t0
         timings["all_gather_s"] = t2 - t1
+        timings["loader_wait_s"] = loader_wait
+        timings["h2d_bytes"] = stager.bytes_copied - h2d_bytes0 if stager is not None else 0
     if mat_path is not None and rank == 0:
         sampling.save_mat(mat_path, data_name or "features", matrix.cpu().numpy().astype(np.float64))
     return matrix, all_errors

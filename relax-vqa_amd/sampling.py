@@ -10,6 +10,7 @@ decodes the video (or already holds the frames) and these helpers reproduce whic
 """
 import math
 import os
+import threading
 
 import numpy as np
 
@@ -48,7 +49,16 @@ def save_clip_features(directory, video_index, network_name, per_frame_features,
     path = os.path.join(directory, feature_file_name(video_index, network_name))
     if skip_existing and os.path.exists(path):
         return path
-    np.save(path, np.asarray(per_frame_features))
+    # write under a temporary name, then rename: a run killed mid-write (or a second rank / run reading the directory) never sees
+    # a truncated array under the final name (os.replace is atomic within a directory)
+    tmp = f"{path}.{os.getpid()}.{threading.get_ident()}.tmp"
+    try:
+        with open(tmp, "wb") as f:
+            np.save(f, np.asarray(per_frame_features))
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return path
 
 

@@ -60,19 +60,31 @@ def assert_close(got, want, what, rtol=RTOL, atol_frac=ATOL_FRAC):
 
 def run_ranks(make_cmd, cwd, env, timeout=600, attempts=2):
     """Runs a multi-rank launch line (make_cmd(port) -> argv) as a child process.  The rendezvous port is probed free a moment
-    before the launcher binds it, so another process can take it in between: a launch that dies on the rendezvous itself (address
-    in use / connection refused, nothing of bench.py has run yet) is repeated once on a fresh port; every other failure is
-    returned as it is."""
+    before the launcher binds it, so another process can take it in between.  A launch is repeated (once, on a fresh port) ONLY
+    when it provably died before the program started: the launcher itself could not bind its port (address in use) AND nothing
+    of the program ran - no stdout, no Python traceback of the program in stderr.  Peer ranks print 'Connection refused' /
+    'DistNetworkError' too when another rank crashes mid-run and the store goes away, so those strings alone never trigger a
+    repeat.  The first attempt is never discarded silently: a repeat raises a warning with its stderr tail and the returned
+    result carries it as `first_attempt`."""
     import socket
     import subprocess
-    res = None
-    for _ in range(attempts):
+    import warnings
+    res, first = None, None
+    for k in range(attempts):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         res = subprocess.run(make_cmd(port), cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
-        rendezvous = any(k in res.stderr for k in ("EADDRINUSE", "Address already in use", "address already in use",
-                                                   "RendezvousConnectionError", "Connection refused", "DistNetworkError"))
-        if res.returncode == 0 or not rendezvous:
+        if res.returncode == 0:
             break
+        bind_failed = any(k_ in res.stderr for k_ in ("EADDRINUSE", "Address already in use", "address already in use"))
+        # the program's own frames in a traceback, or anything on stdout, mean it had started (the launcher's own traceback on a
+        # bind failure names torch/distributed files only)
+        program_ran = bool(res.stdout.strip()) or 'bench.py", line' in res.stderr
+        if not bind_failed or program_ran or k + 1 == attempts:
+            break
+        first = res
+        warnings.warn(f"run_ranks: the launcher could not bind port {port}; repeating once on a fresh port.  stderr tail of the "
+                      f"first attempt:\n{res.stderr[-1500:]}")
+    res.first_attempt = first
     return res

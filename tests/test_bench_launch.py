@@ -21,7 +21,7 @@ def test_gpus_2_without_a_launcher_spawns_two_ranks():
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout          # ONE JSON line, from rank 0
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["backend"] == "gloo"
+    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["backend"] == "gloo" and rec["rccl_ranks"] == 0   # gloo is not RCCL
     assert "launching 2 ranks" in p.stderr
 
 

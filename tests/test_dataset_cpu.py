@@ -105,6 +105,64 @@ def test_sequence_input_and_empty_shards():
     assert m.shape == (2, F) and not e
 
 
+@pytest.mark.parametrize("prefetch,workers", [(0, 1), (1, 1), (2, 3), (5, 8)])
+def test_prefetch_depths_give_the_same_matrix_and_errors(prefetch, workers):
+    """The overlapped pass (loader threads, `prefetch` batches ahead) and the inline pass (prefetch = 0) return the same rows and
+    the same error list; a loader that raises (clip 3) or returns a malformed clip (6) costs its own row only, and nothing hangs."""
+    _patched()
+    eng = FakeEngine()
+    matrix, errors = dataset.extract_dataset_clips(_clip, 10, eng, clips_per_step=3, rank=0, world=1, prefetch=prefetch, workers=workers)
+    assert np.array_equal(matrix.numpy(), _want(10), equal_nan=True)
+    assert [i for i, _ in errors] == [3, 5, 6]
+    assert eng.batches[0] == 3                               # whole batches reach the engine
+
+
+def test_slow_and_failing_loaders_do_not_deadlock_the_pass():
+    import time
+    _patched()
+
+    def slow(i):
+        time.sleep(0.02 * (i % 3))
+        if i % 4 == 1:
+            raise RuntimeError(f"decoder crashed on clip {i}")
+        return _clip(8)
+
+    timings = {}
+    matrix, errors = dataset.extract_dataset_clips(slow, 13, FakeEngine(), clips_per_step=2, rank=0, world=1, prefetch=3, workers=2,
+                                                   timings=timings)
+    assert [i for i, _ in errors] == [1, 5, 9] and all("decoder crashed" in m for _, m in errors)
+    ok = [i for i in range(13) if i % 4 != 1]
+    assert np.isnan(matrix.numpy()[[1, 5, 9]]).all() and np.isfinite(matrix.numpy()[ok]).all()
+    assert timings["loader_wait_s"] >= 0 and timings["h2d_bytes"] == 0
+
+
+def test_clips_per_step_must_be_positive():
+    _patched()
+    for bad in (0, -3):
+        with pytest.raises(ValueError, match="clips_per_step"):
+            dataset.extract_dataset_clips(_clip, 4, FakeEngine(), clips_per_step=bad, rank=0, world=1)
+
+
+def test_resume_recomputes_a_truncated_file_instead_of_failing_forever(tmp_path):
+    """A run killed mid-write used to leave a truncated .npy that every resume turned into a NaN row (round-3 advice).  Files are
+    now written under a temporary name and renamed; a file that still cannot be read, or has the wrong width, is recomputed and
+    overwritten."""
+    _patched()
+    out_dir = str(tmp_path / "feats")
+    first, _ = dataset.extract_dataset_clips(_clip, 3, FakeEngine(), clips_per_step=2, out_dir=out_dir, rank=0, world=1)
+    assert not [f for f in os.listdir(out_dir) if f.endswith(".tmp")]
+    p1 = os.path.join(out_dir, sampling.feature_file_name(1, "resnet50"))
+    p2 = os.path.join(out_dir, sampling.feature_file_name(2, "resnet50"))
+    with open(p1, "r+b") as f:
+        f.truncate(70)                                       # header survives, data gone
+    np.save(p2, np.zeros((2, F + 1), np.float32))            # a foreign file of the wrong width
+    eng = FakeEngine()
+    again, errors = dataset.extract_dataset_clips(_clip, 3, eng, clips_per_step=2, out_dir=out_dir, skip_existing=True, rank=0, world=1)
+    assert not errors and sum(eng.batches) == 2              # clips 1 and 2 went through the engine again, clip 0 did not
+    assert np.allclose(again.numpy(), first.numpy())
+    assert np.load(p1).shape == (2, F) and np.load(p2).shape == (3, F)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

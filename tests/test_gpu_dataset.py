@@ -91,6 +91,44 @@ def test_dataset_full_vectors_and_the_quality_head_on_a_matrix_with_a_failed_cli
     assert scores.shape == (3,) and bool(torch.isfinite(scores).all())
 
 
+def test_host_fed_overlapped_pass_equals_the_inline_pass_bit_for_bit():
+    """Clips in pageable host memory, loader threads + pinned staging + side-stream copies two batches ahead (the default) against
+    the inline pass (prefetch = 0, the round-3 code path): same rows bit for bit, same error list; a loader that raises costs its
+    own row; the engine's tail-split option is back to its value afterwards; a caller-pinned clip is copied straight from its buffer."""
+    rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    shapes = [(2, 240, 320), (1, 272, 400), (3, 240, 320), (2, 256, 256), (1, 240, 320), (2, 272, 400), (2, 240, 320)]
+    host = [synth.synthetic_clip(t, h, w, clip_id=640 + i) for i, (t, h, w) in enumerate(shapes)]
+
+    def source(i):
+        if i == 4:
+            raise OSError("video_5.mp4: truncated")
+        if i == 5:
+            return torch.from_numpy(host[5]).pin_memory()
+        return host[i]
+
+    assert eng.get_option("gemm_split_k") == 1
+    t_in, t_ov = {}, {}
+    inline, e0 = dataset.extract_dataset_clips(source, 7, eng, clips_per_step=2, rank=0, world=1, prefetch=0, timings=t_in)
+    over, e1 = dataset.extract_dataset_clips(source, 7, eng, clips_per_step=2, rank=0, world=1, prefetch=2, workers=3, timings=t_ov)
+    assert eng.get_option("gemm_split_k") == 1
+    assert [i for i, _ in e0] == [4] == [i for i, _ in e1] and "truncated" in e1[0][1]
+    ok = [0, 1, 2, 3, 5, 6]
+    assert bool(torch.isnan(over[4]).all()) and bool(torch.isfinite(over[ok]).all())
+    assert torch.equal(inline[ok], over[ok]), "the overlapped host-fed pass changed rows"
+    assert t_in["h2d_bytes"] == 0 and t_ov["h2d_bytes"] == sum(host[i].size for i in ok)
+    # batch-invariant rows: a clip alone (tail split off) gives the same bits
+    eng.set_option("gemm_split_k", 0)
+    try:
+        assert torch.equal(over[2], eng.clip_vector(torch.from_numpy(host[2]).cuda()))
+    finally:
+        eng.set_option("gemm_split_k", 1)
+    # a second pass reuses the pinned and device buffers of the first (same stager object on the engine)
+    st = eng._clip_stager
+    again, _ = dataset.extract_dataset_clips(source, 7, eng, clips_per_step=3, rank=0, world=1)
+    assert eng._clip_stager is st and torch.equal(again[ok], over[ok])
+
+
 def _bench_dataset(n_ranks, dump, extra_env=None):
     from tests.gpu_common import run_ranks
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -115,7 +153,8 @@ def test_bench_dataset_mode_two_ranks_on_one_gpu_equal_one_rank_bit_for_bit(tmp_
     one = _bench_dataset(1, str(tmp_path / "one.npy"))
     two = _bench_dataset(2, str(tmp_path / "two.npy"), {"RELAX_DIST_BACKEND": "gloo"})
     for rec, n in ((one, 1), (two, 2)):
-        assert rec["scaling"] == "strong" and rec["n_gpus"] == n and rec["rccl_ranks"] == n and rec["value"] > 0
+        assert rec["scaling"] == "strong" and rec["n_gpus"] == n and rec["ranks"] == n and rec["value"] > 0
+        assert (rec["backend"], rec["rccl_ranks"]) == ((None, 1) if n == 1 else ("gloo", 0))
         assert rec["config"]["dataset_clips"] == 7 and rec["errors"] == 0 and rec["all_gather_ms"] >= 0
     a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
     assert a.shape == (7, 19779) and np.isfinite(a).all()

@@ -132,7 +132,7 @@ def test_bench_two_ranks_sharing_the_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert "roofline" in out and "cpu_baseline" not in out          # the CPU baseline is an N = 1 leg
-    assert out["rccl_ranks"] == 2
+    assert out["ranks"] == 2 and out["backend"] == "gloo" and out["rccl_ranks"] == 0
 
 
 def test_bench_gpus_2_run_plainly_launches_its_own_ranks():
@@ -151,4 +151,45 @@ def test_bench_gpus_2_run_plainly_launches_its_own_ranks():
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == "gloo" and out["rccl_ranks"] == 0 and out["value"] > 0
+
+
+# ---- real RCCL: arms itself wherever the box has two GPUs (the pool's boxes have one: skipped there, with the reason printed) ----
+_TWO_GPUS = torch.cuda.is_available() and torch.cuda.device_count() >= 2
+_NEED_TWO = pytest.mark.skipif(not _TWO_GPUS, reason="real-RCCL test: needs >= 2 GPUs on the box (torch.cuda.device_count() < 2 here)")
+
+
+def _bench_plain(args, timeout=1200):
+    """`python bench.py ...` with no launcher and no backend override: N > 1 starts its own ranks under the default nccl (= RCCL)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RELAX_DIST_BACKEND")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+@_NEED_TWO
+def test_rccl_two_gpus_dataset_matrix_equals_one_rank_bit_for_bit(tmp_path):
+    """Config 4 as written over two GPUs under RCCL: contiguous shards, one all_gather_into_tensor over xGMI; with the tail split off
+    the [7, 19779] matrix is the one-rank matrix bit for bit (src/main_fragment_layerstack.py:269 has no cross-clip state)."""
+    import numpy as np
+    common = ["--workload", "config4", "--dataset-clips", "7", "--clips-per-step", "2", "--warmup", "1", "--gemm-split-k", "0",
+              "--resident-clips", "3"]
+    one = _bench_plain(["--gpus", "1"] + common + ["--dump-matrix", str(tmp_path / "one.npy")])
+    two = _bench_plain(["--gpus", "2"] + common + ["--dump-matrix", str(tmp_path / "two.npy")])
+    assert one["rccl_ranks"] == 1 and two["rccl_ranks"] == 2 and two["backend"] == "nccl" and two["ranks"] == 2
+    a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
+    assert a.shape == (7, 19779) and np.isfinite(a).all() and np.array_equal(a, b), "sharding over two GPUs changed the matrix"
+
+
+@_NEED_TWO
+def test_rccl_two_gpus_weak_scaling_line():
+    out = _bench_plain(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "config3", "--clips-per-step", "4"])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "nccl" and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["clips_per_step_per_gpu"] == 4 and "roofline" in out

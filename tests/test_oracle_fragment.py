@@ -54,6 +54,33 @@ def test_real_video_known_answer(golden_dir):
     assert np.array_equal(fragment_ref.merge_fragments(o["diff_frag"], ffrag), load("_residual_merged_frag"))
 
 
+def _load_set(golden_dir, stem, suffix):
+    p = os.path.join(golden_dir, "png_" + stem, f"{stem}{suffix}.png")
+    return np.ascontiguousarray(np.asarray(Image.open(p).convert("RGB"))[..., ::-1])
+
+
+def test_reference_1080p_set(golden_dir):
+    """The reference's 1080p example pair (the headline resolution): fragments, flow fragment and merge reproduced bit-exactly."""
+    stem = "TelevisionClip_1080P-68c6_1"
+    orig, nxt = _load_set(golden_dir, stem, ""), _load_set(golden_dir, stem, "_next")
+    o = fragment_ref.fragment_pair(orig, nxt)
+    assert np.array_equal(o["diff_frag"], _load_set(golden_dir, stem, "_residual_imp"))
+    assert np.array_equal(o["ori_frag"], _load_set(golden_dir, stem, "_ori_frag"))
+    flow = _load_set(golden_dir, stem, "_residual_of")
+    ffrag, _ = fragment_ref.extract_important_patches(flow, fragment_ref.get_patch_diff(flow))
+    assert np.array_equal(ffrag, _load_set(golden_dir, stem, "_residual_of_imp"))
+    assert np.array_equal(fragment_ref.merge_fragments(o["diff_frag"], ffrag), _load_set(golden_dir, stem, "_residual_merged_frag"))
+
+
+def test_reference_2160p_set(golden_dir):
+    stem = "Sports_2160P-0455_1"
+    flow = _load_set(golden_dir, stem, "_residual_of")
+    ffrag, _ = fragment_ref.extract_important_patches(flow, fragment_ref.get_patch_diff(flow))
+    assert np.array_equal(ffrag, _load_set(golden_dir, stem, "_residual_of_imp"))
+    assert np.array_equal(fragment_ref.merge_fragments(_load_set(golden_dir, stem, "_residual_imp"), ffrag),
+                          _load_set(golden_dir, stem, "_residual_merged_frag"))
+
+
 def test_tie_rule_is_lowest_index_first():
     diff = np.zeros((20, 20))
     pos = fragment_ref.select_positions(diff, 196)

@@ -1,3 +1,7 @@
+#!/bin/bash
+# (run through gpurun: GRAFT_REPO_ROOT is the snapshot of the repo on the GPU box; default: this script's repo)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+export GRAFT_REPO_ROOT
 # The non-headline BASELINE configurations on one GPU (config 2, config-4 shape, full ReLaX at 1080p / 2160p): bench lines
 # and a kernel profile of the 2160p full pipeline.  Outputs under gpurun_out/.
 R=$GRAFT_REPO_ROOT

@@ -1,3 +1,7 @@
+#!/bin/bash
+# (run through gpurun: GRAFT_REPO_ROOT is the snapshot of the repo on the GPU box; default: this script's repo)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+export GRAFT_REPO_ROOT
 # Where does the K loop of gemm_x6 wait?  Three PMC passes (each alone, kernel-trace only) over one ViT-B pass of 1024 fragments,
 # summed over the gemm_x6 dispatches:   tools/pmc_gemm_stalls.sh TAG   -> gpurun_out/pmc_stalls_TAG.txt
 R=$GRAFT_REPO_ROOT

@@ -1,3 +1,7 @@
+#!/bin/bash
+# (run through gpurun: GRAFT_REPO_ROOT is the snapshot of the repo on the GPU box; default: this script's repo)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+export GRAFT_REPO_ROOT
 # PMC passes over one ViT pass (tools/vit_step.py): per-kernel sums of the given counters.  tools/pmc_vit.sh <tag> <precision> <counters...>
 R=$GRAFT_REPO_ROOT
 TAG=$1; PREC=$2; shift; shift

@@ -1,3 +1,7 @@
+#!/bin/bash
+# (run through gpurun: GRAFT_REPO_ROOT is the snapshot of the repo on the GPU box; default: this script's repo)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+export GRAFT_REPO_ROOT
 # rocprofv3 kernel stats of one bench configuration: tools/prof_x6.sh <tag> <bench args...>
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift

@@ -1,3 +1,7 @@
+#!/bin/bash
+# (run through gpurun: GRAFT_REPO_ROOT is the snapshot of the repo on the GPU box; default: this script's repo)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+export GRAFT_REPO_ROOT
 set -x
 R=$GRAFT_REPO_ROOT
 python -m pytest -m gpu -q --timeout=900 tests > $R/gpurun_out/t9.log 2>&1

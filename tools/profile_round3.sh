@@ -1,3 +1,7 @@
+#!/bin/bash
+# (run through gpurun: GRAFT_REPO_ROOT is the snapshot of the repo on the GPU box; default: this script's repo)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+export GRAFT_REPO_ROOT
 # Round-3 evidence: bench lines, rocprofv3 kernel stats, PMC passes (own passes, kernel-trace only).  Run through gpurun.
 set -x
 R=$GRAFT_REPO_ROOT

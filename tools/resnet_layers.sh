@@ -1,3 +1,7 @@
+#!/bin/bash
+# (run through gpurun: GRAFT_REPO_ROOT is the snapshot of the repo on the GPU box; default: this script's repo)
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+export GRAFT_REPO_ROOT
 # per-dispatch durations of ONE ResNet-50 pass (rocprofv3 --kernel-trace), in launch order:
 #   tools/resnet_layers.sh <tag> [N]      -> gpurun_out/resnet_layers_<tag>.txt
 R=$GRAFT_REPO_ROOT
