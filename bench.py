@@ -541,13 +541,13 @@ def dataset_pass(eng, workload, n, B, rank, world, split_k, host_clips=False, pr
             rdist.barrier()
         torch.cuda.synchronize()
 
-    def one_pass(source, warm_clips):
+    def one_pass(source, warm_clips, ramp):
         for _ in range(warmup):
-            dataset.extract_dataset_clips(source, min(warm_clips, n), eng, **kw)
+            dataset.extract_dataset_clips(source, min(warm_clips, n), eng, ramp=False, **kw)
         barrier()
         timings = {}
         t0 = time.perf_counter()
-        matrix, errors = dataset.extract_dataset_clips(source, n, eng, timings=timings, **kw)
+        matrix, errors = dataset.extract_dataset_clips(source, n, eng, timings=timings, ramp=ramp, **kw)
         barrier()
         elapsed = time.perf_counter() - t0
         gather_s = timings["all_gather_s"]
@@ -557,7 +557,7 @@ def dataset_pass(eng, workload, n, B, rank, world, split_k, host_clips=False, pr
         assert matrix.shape == (n, F) and not errors and bool(torch.isfinite(matrix).all()), (matrix.shape, errors[:3])
         return matrix, elapsed, gather_s, timings
 
-    matrix, elapsed, gather_s, timings = one_pass(lambda i: resident[i % n_resident], B * world)
+    matrix, elapsed, gather_s, timings = one_pass(lambda i: resident[i % n_resident], B * world, False)
     if dump and rank == 0:
         np.save(dump, matrix.cpu().numpy())
     per_rank = -(-n // world)
@@ -575,8 +575,12 @@ def dataset_pass(eng, workload, n, B, rank, world, split_k, host_clips=False, pr
         "gemm_split_k": split_k, "prefetch_batches": prefetch, "loader_workers": workers}
     if host_clips:
         # the same pass with every clip in pageable host memory (numpy arrays, as a decoder would hand them over)
-        m_h, e_h, g_h, t_h = one_pass(lambda i: host[i % n_resident], (prefetch + 2) * B * world)
-        assert torch.equal(m_h, matrix), "the host-fed pass changed the matrix"
+        m_h, e_h, g_h, t_h = one_pass(lambda i: host[i % n_resident], (prefetch + 2) * B * world, True)
+        # (the host-fed pass opens with three short batches: with the tail split-K on, rows of those clips differ in the last bits)
+        if split_k == 0:
+            assert torch.equal(m_h, matrix), "the host-fed pass changed the matrix"
+        else:
+            assert torch.allclose(m_h, matrix, rtol=1e-4, atol=1e-6), "the host-fed pass changed the matrix"
         # what the copies would cost alone: one batch of this rank's clips, pinned -> device, timed on an idle GPU
         pin = [torch.from_numpy(host[j % n_resident]).pin_memory() for j in range(min(B, 8))]
         dst = [torch.empty_like(p, device="cuda") for p in pin]
@@ -590,7 +594,8 @@ def dataset_pass(eng, workload, n, B, rank, world, split_k, host_clips=False, pr
         rec["host_fed"] = {"value": n / e_h, "unit": "clips/s", "frac_of_device_resident": elapsed / e_h,
                            "h2d_hidden_frac": max(0.0, min(1.0, 1.0 - max(0.0, e_h - elapsed) / t_copy)) if t_copy > 0 else None,
                            "h2d_GB": t_h["h2d_bytes"] / 1e9, "h2d_alone_s": t_copy, "pinned_h2d_GBps": bw / 1e9,
-                           "loader_wait_s": t_h["loader_wait_s"], "extract_s": t_h["extract_s"], "matrix_equal_to_device_resident": True,
+                           "loader_wait_s": t_h["loader_wait_s"], "extract_s": t_h["extract_s"],
+                           "matrix_equal_to_device_resident": "bit for bit" if split_k == 0 else "to 1e-4 (tail split-K on: bits follow the batch composition)",
                            "note": "clips in pageable host memory -> loader threads copy them into pinned staging -> side-stream H2D of batch "
                                    "k+1 under the compute of batch k (relax-vqa_amd/dataset.py::ClipStager); never `value`"}
         del pin, dst

@@ -155,7 +155,7 @@ def _stager(engine):
 
 def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=True, vit=True, full=False, flow=True,
                           out_dir=None, network_name="resnet50", skip_existing=False, mat_path=None, data_name=None,
-                          rank=None, world=None, group=None, timings=None, prefetch=2, workers=4, batch_invariant=True):
+                          rank=None, world=None, group=None, timings=None, prefetch=2, workers=4, batch_invariant=True, ramp=True):
     """clips: callable i -> uint8 [T,2,H,W,3] (device tensor, host tensor or ndarray; T and the resolution may differ from
     clip to clip), or a sequence indexed the same way.  Only this rank's shard is ever requested; the callable runs in loader
     threads (`workers` of them, up to `prefetch` batches ahead of the engine), so it may block on I/O or decode.
@@ -163,6 +163,8 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
 
     prefetch = 0: no loader threads, no side stream - clips(i) is called in the driver thread as the batch is assembled (the
              round-3 behaviour; same rows bit for bit).
+    ramp (default, with prefetch > 0 and clips_per_step >= 16): the pass opens with batches of B/8, B/4, B/2 clips before the
+             full ones, so that the loading of the first batch - which nothing hides - is short.
     batch_invariant (default): the pass runs with the engine's tail split-K off, so a clip's row does not depend on which clips
              share its batch - i.e. not on the number of ranks (engine.clip_vectors); the option is restored afterwards.
     out_dir: write each clip's per-frame rows [T, F] as `video_{i+1}_{network_name}_feature_map_original.npy`
@@ -245,7 +247,16 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         except Exception as e:                          # noqa: BLE001 - the contract: the clip fails, the run goes on
             return ("err", f"{type(e).__name__}: {e}")
 
-    batches = [mine[lo:lo + B] for lo in range(0, len(mine), B)]
+    # ramp: the first batch has nothing to hide its loading under, so the pass opens with short batches (B/8, B/4, B/2) - the
+    # engine starts after an eighth of a batch has been loaded and every next batch loads under the previous one's compute
+    sizes = []
+    if ramp and prefetch > 0 and B >= 16 and len(mine) >= 2 * B:
+        sizes = [B // 8, B // 4, B // 2]
+    starts, at = [], 0
+    while at < len(mine):
+        starts.append(at)
+        at += sizes.pop(0) if sizes else B
+    batches = [mine[lo:hi] for lo, hi in zip(starts, starts[1:] + [len(mine)])]
     futures = {}
     loader_wait = 0.0
 
@@ -260,7 +271,7 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         results = [f.result() for f in futures.pop(b)] if pool is not None else [load(i) for i in batches[b]]
         loader_wait += time.perf_counter() - t_w
         slots, idxs, host, pinned = [], [], [], []
-        for slot, (i, r) in enumerate(zip(batches[b], results), start=b * B):
+        for slot, (i, r) in enumerate(zip(batches[b], results), start=starts[b]):
             if r[0] == "err":
                 errors.append((i, r[1]))
             elif r[0] == "row":
