@@ -16,8 +16,15 @@
 
 #include "relax_internal.h"
 
+// This file is compiled with -ffp-contract=off (Makefile): a * b + c is a multiply and an add, as in the oracle and in OpenCV's scalar code,
+// in EVERY kernel - left to itself the compiler fuses such expressions differently from one kernel to the next (also through the
+// __fmul_rn / __fadd_rn wrappers, which are plain operators in this toolchain), and results would depend on which kernel evaluated
+// them.  Where a fused multiply-add is wanted it is written: fmaf / fma / __fmaf_rn / __fma_rn.
 namespace relax {
 
+#ifndef RELAX_FLOW_ABLATE
+#define RELAX_FLOW_ABLATE 0     // diagnostic builds (tools/build_ablations.sh flow:<mask>, WRONG results, timing only): 1 no frame-1 gather,
+#endif                          // 2 no matrix arithmetic, 4 no strips (window slide + solve), 8 no column sums, 16 no frame-0 / flow loads
 constexpr int POLY_N = 5;
 constexpr int WINSIZE = 15;
 constexpr int ITERS = 3;
@@ -39,6 +46,10 @@ __device__ inline int reflect101(int i, int n) {
     return i < 0 ? 0 : (i >= n ? n - 1 : i);   // (only reached for n smaller than the kernel radius)
 }
 __device__ inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+// cv::resize's source coordinate of destination index d, (d + 0.5) * scale - 0.5 in double, and the flow magnitude: one definition each
+// with named roundings - a contraction into an FMA in one kernel and not in another would make results depend on the kernel
+__device__ __forceinline__ float resize_src_coord(int d, double scale) { return (float)__dsub_rn(__dmul_rn(d + 0.5, scale), 0.5); }
+__device__ __forceinline__ float flow_magnitude(float x, float y) { return sqrtf(__fmaf_rn(y, y, __fmul_rn(x, x))); }
 
 // uint8 BGR frame pair -> float gray [P][2][H][W]; (B*1868 + G*9617 + R*4899 + 2^13) >> 14
 __global__ __launch_bounds__(256) void flow_gray(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ next,
@@ -85,13 +96,16 @@ __global__ __launch_bounds__(256) void gauss_pass(const float* __restrict__ src,
     float acc = 0.f;
     for (int t = 0; t < gk.ksize; ++t) {
         const float v = VERTICAL ? img[(int64_t)reflect101(y + t - r, H) * W + x] : img[(int64_t)y * W + reflect101(x + t - r, W)];
-        acc += sk[t] * v;
+        acc = fmaf(sk[t], v, acc);
     }
     dst[(int64_t)blockIdx.z * ((int64_t)W * H) + (int64_t)y * W + x] = acc;
 }
 
 // 3-tap blur (pyramid levels 0 and 1), both passes in one kernel, 4 pixels per thread: reads the 3 rows once with 16-byte
 // loads, same products and order as gauss_pass<false> then gauss_pass<true> (horizontal first, rounded to float, then vertical).
+__device__ __forceinline__ f32x4 fma4(float k, f32x4 v, f32x4 a) {
+    return (f32x4){fmaf(k, v.x, a.x), fmaf(k, v.y, a.y), fmaf(k, v.z, a.z), fmaf(k, v.w, a.w)};
+}
 __global__ __launch_bounds__(256) void gauss3_v4(const float* __restrict__ src, float* __restrict__ dst, int H, int W, float k0,
                                                  float k1, float k2) {
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // grid (W / 1024, H, images)
@@ -106,13 +120,13 @@ __global__ __launch_bounds__(256) void gauss3_v4(const float* __restrict__ src, 
         const float l = row[reflect101(x0 - 1, W)], rr = row[reflect101(x0 + 4, W)];
         // acc = 0 + k0*v(-1); acc += k1*v(0); acc += k2*v(+1)
         f32x4 a = (f32x4){l, c.x, c.y, c.z} * k0;
-        a += k1 * c;
-        a += k2 * (f32x4){c.y, c.z, c.w, rr};
+        a = fma4(k1, c, a);
+        a = fma4(k2, (f32x4){c.y, c.z, c.w, rr}, a);
         hrow[t] = a;
     }
     f32x4 o = hrow[0] * k0;
-    o += k1 * hrow[1];
-    o += k2 * hrow[2];
+    o = fma4(k1, hrow[1], o);
+    o = fma4(k2, hrow[2], o);
     *reinterpret_cast<f32x4*>(dst + (int64_t)blockIdx.z * ((int64_t)W * H) + (int64_t)y * W + x0) = o;
 }
 
@@ -125,7 +139,7 @@ __device__ inline float lerp_rn(float a, float b, float t) { return __fadd_rn(__
 // pixel, so the blur is evaluated at those samples only - same taps, same order, same interpolation arithmetic as
 // gauss_pass + resize_linear_f32 (bit-identical), a fraction of the work.
 __device__ inline void linear_tap(int d, double scale, int n_in, int* s0, int* s1, float* f) {
-    float fx = (float)((d + 0.5) * scale - 0.5);
+    float fx = resize_src_coord(d, scale);
     int sx = (int)floorf(fx);
     fx -= (float)sx;
     if (sx < 0) { fx = 0.f; sx = 0; }
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(256) void gauss_h_sampled(const float* __restrict__
     linear_tap(e >> 1, scale_x, W, &s0, &s1, &f);
     const int x = (e & 1) ? s1 : s0;
     float acc = 0.f;
-    for (int t = 0; t < gk.ksize; ++t) acc += sk[t] * seg[x + t - r - xlo];
+    for (int t = 0; t < gk.ksize; ++t) acc = fmaf(sk[t], seg[x + t - r - xlo], acc);
     tmp[row * (2 * w) + e] = acc;
 }
 
@@ -188,10 +202,10 @@ __global__ __launch_bounds__(256) void gauss_v_sampled_resize(const float* __res
         const float k = sk[t];
         const float* p0 = img + (int64_t)reflect101(sy0 + t - r, H) * w * 2;
         const float* p1 = img + (int64_t)reflect101(sy1 + t - r, H) * w * 2;
-        a00 += k * p0[0];
-        a01 += k * p0[1];
-        a10 += k * p1[0];
-        a11 += k * p1[1];
+        a00 = fmaf(k, p0[0], a00);
+        a01 = fmaf(k, p0[1], a01);
+        a10 = fmaf(k, p1[0], a10);
+        a11 = fmaf(k, p1[1], a11);
     }
     dst[(b * h + dy) * w + dx] = lerp_rn(lerp_rn(a00, a01, fx), lerp_rn(a10, a11, fx), fy);
 }
@@ -206,12 +220,12 @@ __global__ __launch_bounds__(256) void resize_linear_f32(const float* __restrict
     const int dx = e / C;
     const int dy = blockIdx.y;
     const int64_t b = blockIdx.z;
-    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    float fx = resize_src_coord(dx, scale_x);
     int sx = (int)floorf(fx);
     fx -= (float)sx;
     if (sx < 0) { fx = 0.f; sx = 0; }
     if (sx >= W - 1) { fx = 0.f; sx = W - 1; }
-    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    float fy = resize_src_coord(dy, scale_y);
     int sy = (int)floorf(fy);
     fy -= (float)sy;
     if (sy < 0) { fy = 0.f; sy = 0; }
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(256) void resize_linear_f32(const float* __restrict
     dst[((b * h + dy) * w) * C + e] = __fmul_rn(lerp_rn(r0, r1, fy), mul);
 }
 
-// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][h][w][5].  A block owns a band of 246 output columns (256
+// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][5][h][w] (planar: every access of the consumers is a coalesced dword row).  A block owns a band of 246 output columns (256
 // threads = 246 + the 5-column halo on each side, replicated border) and a segment of rows, and walks down the rows:
 //   * vertical 11-tap filters (float, as OpenCV), one COLUMN per thread: the 11 rows of the window live in a register ring
 //     (static indices: the row loop is unrolled over the ring period), so every input value is loaded once per segment - with
@@ -264,9 +278,9 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
                     const float up = ring[(j + POLY_N - k) % POLY_RING];
                     const float dn = ring[(j + POLY_N + k) % POLY_RING];
                     const float p = up + dn;
-                    t0 += pc.g[k] * p;
-                    t1 += pc.xg[k] * (dn - up);
-                    t2 += pc.xxg[k] * p;
+                    t0 = fmaf(pc.g[k], p, t0);
+                    t1 = fmaf(pc.xg[k], dn - up, t1);
+                    t2 = fmaf(pc.xxg[k], p, t2);
                 }
                 ring[j] = entering;                         // row y + 6 takes the slot of row y - 5
                 lt[par][0][tid] = t0;
@@ -281,19 +295,20 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
                         const float p1 = lt[par][1][tid + k], m1 = lt[par][1][tid - k];
                         const float p2 = lt[par][2][tid + k], m2 = lt[par][2][tid - k];
                         const double tg = p0 + m0;
-                        b1 += tg * pc.g[k];
-                        b4 += tg * pc.xxg[k];
+                        b1 = fma(tg, (double)pc.g[k], b1);
+                        b4 = fma(tg, (double)pc.xxg[k], b4);
                         b2 += (p0 - m0) * pc.xg[k];
                         b3 += (p1 + m1) * pc.g[k];
                         b6 += (p1 - m1) * pc.xg[k];
                         b5 += (p2 + m2) * pc.g[k];
                     }
-                    float* o = R + (((int64_t)blockIdx.z * h + y) * w + x) * 5;
-                    o[1] = (float)(b2 * pc.ig11);
+                    const int64_t hw = (int64_t)h * w;
+                    float* o = R + (int64_t)blockIdx.z * 5 * hw + (int64_t)y * w + x;     // planar: coalesced stores
+                    o[1 * hw] = (float)(b2 * pc.ig11);
                     o[0] = (float)(b3 * pc.ig11);
-                    o[3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-                    o[2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-                    o[4] = (float)(b6 * pc.ig55);
+                    o[3 * hw] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+                    o[2 * hw] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+                    o[4 * hw] = (float)(b6 * pc.ig55);
                 }
                 par ^= 1;   // the next row writes the other buffer: its barrier orders these reads before the buffer's reuse
             }
@@ -301,52 +316,154 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
     }
 }
 
-// FarnebackUpdateMatrices for one pixel: R0 = its 5 expansion coefficients in frame 0, R1 = frame 1's coefficient image,
-// (dx, dy) = current flow.  out = the 5 entries of the pixel's G matrix / h vector.
-__device__ inline void matrix_entries(const float* __restrict__ R0, const float* __restrict__ R1, int x, int y, float dx, float dy,
-                                      int h, int w, float out[5]) {
+// FarnebackUpdateMatrices for one pixel, in two halves so that a kernel can keep the loads of one pixel in flight while it computes
+// another: `matrix_request` loads what the entries need (R0 = the pixel's 5 expansion coefficients in frame 0, the 2 x 2 x 5
+// coefficients of frame 1 around the displaced position), `matrix_compute` forms the 5 entries of the pixel's G matrix / h vector.
+struct MatrixPix {
+    float r0[5];          // frame 0 at (x, y)
+    float top[10];        // frame 1 at (x1, y1), (x1 + 1, y1): 5 coefficients each
+    float bot[10];        // frame 1 at (x1, y1 + 1), (x1 + 1, y1 + 1)
+    float fx, fy;         // fractional part of the displaced position
+    float dx, dy;         // the flow at the pixel
+    bool inb;             // displaced position inside the image (else the frame-1 terms are dropped)
+};
+// Loads go through a buffer resource over the pair's two coefficient images (planar [2][5][h][w]): one 32-bit byte offset per pixel in
+// a VGPR, the plane offsets in SGPRs - no 64-bit address arithmetic per load (17 VALU instructions per pixel with flat pointers).
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ float2 buf_f32x2(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void matrix_request(MatrixPix& p, __amdgpu_buffer_rsrc_t rs, int plane_bytes, int x, int y, float dx, float dy, int h,
+                                               int w) {
+    const int v0 = (y * w + x) * 4;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) p.r0[c] = (RELAX_FLOW_ABLATE & 16) ? dx : buf_f32(rs, v0, c * plane_bytes);
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     fx -= x1;
     fy -= y1;
+    p.fx = fx; p.fy = fy; p.dx = dx; p.dy = dy;
+    p.inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    // outside the image the values are not used: the loads go to a clamped (valid) address instead of sitting in a divergent branch
+    const int v1 = (clampi(y1, 0, h - 2) * w + clampi(x1, 0, w - 2)) * 4, v2 = v1 + w * 4;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {      // (x1, x1 + 1) pairs: one 8-byte load each
+        if (RELAX_FLOW_ABLATE & 1) {
+            p.top[c] = p.top[5 + c] = p.bot[c] = p.bot[5 + c] = p.r0[c];
+            continue;
+        }
+        const float2 t = buf_f32x2(rs, v1, (5 + c) * plane_bytes), u = buf_f32x2(rs, v2, (5 + c) * plane_bytes);
+        p.top[c] = t.x;
+        p.top[5 + c] = t.y;
+        p.bot[c] = u.x;
+        p.bot[5 + c] = u.y;
+    }
+}
+// Every product / sum below names its rounding (__fmul_rn / __fadd_rn / __fmaf_rn): left to itself the compiler contracts these
+// expressions into FMAs differently from one kernel to the next (packed FMAs in one, separate multiplies and adds in another), and
+// the flow would depend on which kernel evaluated it.  The bilinear sums are FMA chains, smallest index first.
+__device__ __forceinline__ float dot4_rn(float a0, float b0, float a1, float b1, float a2, float b2, float a3, float b3) {
+    return __fmaf_rn(a3, b3, __fmaf_rn(a2, b2, __fmaf_rn(a1, b1, __fmul_rn(a0, b0))));
+}
+__device__ __forceinline__ void matrix_compute(const MatrixPix& p, int x, int y, int h, int w, float out[5]) {
+    const float fx = p.fx, fy = p.fy, dx = p.dx, dy = p.dy;
     float r2, r3, r4, r5, r6;
-    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
-        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const float* p = R1 + ((int64_t)y1 * w + x1) * 5;
-        const int64_t st = (int64_t)w * 5;
-        r2 = a00 * p[0] + a01 * p[5] + a10 * p[st] + a11 * p[st + 5];
-        r3 = a00 * p[1] + a01 * p[6] + a10 * p[st + 1] + a11 * p[st + 6];
-        r4 = a00 * p[2] + a01 * p[7] + a10 * p[st + 2] + a11 * p[st + 7];
-        r5 = a00 * p[3] + a01 * p[8] + a10 * p[st + 3] + a11 * p[st + 8];
-        r6 = a00 * p[4] + a01 * p[9] + a10 * p[st + 4] + a11 * p[st + 9];
-        r4 = (R0[2] + r4) * 0.5f;
-        r5 = (R0[3] + r5) * 0.5f;
-        r6 = (R0[4] + r6) * 0.25f;
+    if (p.inb) {
+        const float gx = __fsub_rn(1.f, fx), gy = __fsub_rn(1.f, fy);
+        const float a00 = __fmul_rn(gx, gy), a01 = __fmul_rn(fx, gy), a10 = __fmul_rn(gx, fy), a11 = __fmul_rn(fx, fy);
+        r2 = dot4_rn(a00, p.top[0], a01, p.top[5], a10, p.bot[0], a11, p.bot[5]);
+        r3 = dot4_rn(a00, p.top[1], a01, p.top[6], a10, p.bot[1], a11, p.bot[6]);
+        r4 = dot4_rn(a00, p.top[2], a01, p.top[7], a10, p.bot[2], a11, p.bot[7]);
+        r5 = dot4_rn(a00, p.top[3], a01, p.top[8], a10, p.bot[3], a11, p.bot[8]);
+        r6 = dot4_rn(a00, p.top[4], a01, p.top[9], a10, p.bot[4], a11, p.bot[9]);
+        r4 = __fmul_rn(__fadd_rn(p.r0[2], r4), 0.5f);
+        r5 = __fmul_rn(__fadd_rn(p.r0[3], r5), 0.5f);
+        r6 = __fmul_rn(__fadd_rn(p.r0[4], r6), 0.25f);
     } else {
         r2 = r3 = 0.f;
-        r4 = R0[2];
-        r5 = R0[3];
-        r6 = R0[4] * 0.5f;
+        r4 = p.r0[2];
+        r5 = p.r0[3];
+        r6 = __fmul_rn(p.r0[4], 0.5f);
     }
-    r2 = (R0[0] - r2) * 0.5f;
-    r3 = (R0[1] - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
+    r2 = __fmul_rn(__fsub_rn(p.r0[0], r2), 0.5f);
+    r3 = __fmul_rn(__fsub_rn(p.r0[1], r3), 0.5f);
+    r2 = __fadd_rn(r2, __fmaf_rn(r6, dx, __fmul_rn(r4, dy)));
+    r3 = __fadd_rn(r3, __fmaf_rn(r5, dx, __fmul_rn(r6, dy)));
     const int BORDER = 5;
     if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
-        const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
-        const float sc = (x < BORDER ? border[x] : 1.f) * (x >= w - BORDER ? border[w - x - 1] : 1.f) *
-                         (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
-        r2 *= sc; r3 *= sc; r4 *= sc; r5 *= sc; r6 *= sc;
+        // OpenCV's border table {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance to the edge, as selects (an indexed constant array is a
+        // memory load, and its wait would drain the load pipeline of the fused iteration kernel)
+#define RELAX_BORDER(d_) ((d_) < 2 ? 0.14f : 0.4472f)
+        const float sc = __fmul_rn(__fmul_rn(x < BORDER ? RELAX_BORDER(x) : 1.f, x >= w - BORDER ? RELAX_BORDER(w - x - 1) : 1.f),
+                                   __fmul_rn(y < BORDER ? RELAX_BORDER(y) : 1.f, y >= h - BORDER ? RELAX_BORDER(h - y - 1) : 1.f));
+#undef RELAX_BORDER
+        r2 = __fmul_rn(r2, sc); r3 = __fmul_rn(r3, sc); r4 = __fmul_rn(r4, sc); r5 = __fmul_rn(r5, sc); r6 = __fmul_rn(r6, sc);
     }
-    out[0] = r4 * r4 + r6 * r6;
-    out[1] = (r4 + r5) * r6;
-    out[2] = r5 * r5 + r6 * r6;
-    out[3] = r4 * r2 + r6 * r3;
-    out[4] = r6 * r2 + r5 * r3;
+    out[0] = __fmaf_rn(r6, r6, __fmul_rn(r4, r4));
+    out[1] = __fmul_rn(__fadd_rn(r4, r5), r6);
+    out[2] = __fmaf_rn(r6, r6, __fmul_rn(r5, r5));
+    out[3] = __fmaf_rn(r6, r3, __fmul_rn(r4, r2));
+    out[4] = __fmaf_rn(r5, r3, __fmul_rn(r6, r2));
+}
+// The 2x2 solve of FarnebackUpdateFlow from the five box sums A (unscaled: the 1 / 225 of the box filter is folded into the
+// regulariser, 1e-3 * 225^2 = 50.625, so no sum is multiplied first): flow = (A0 A4 - A1 A3, A2 A3 - A1 A4) / (A0 A2 - A1^2 + 50.625),
+// in double with named FMAs (one form for every kernel that solves); the reciprocal is v_rcp_f64 refined by two Newton steps
+// (the full division sequence costs twice as much and the quotient is rounded to float anyway).
+__device__ __forceinline__ float2 solve_flow(double A0, double A1, double A2, double A3, double A4) {
+    const double det = __fma_rn(A0, A2, __fma_rn(-A1, A1, 50.625));     // >= 50.625 up to rounding: the sums form a Gram matrix
+    double r = __builtin_amdgcn_rcp(det);
+    r = __fma_rn(__fma_rn(-det, r, 1.0), r, r);
+    r = __fma_rn(__fma_rn(-det, r, 1.0), r, r);
+    const double nx = __fma_rn(A0, A4, -__dmul_rn(A1, A3));
+    const double ny = __fma_rn(A2, A3, -__dmul_rn(A1, A4));
+    return make_float2((float)__dmul_rn(nx, r), (float)__dmul_rn(ny, r));
+}
+__device__ inline void matrix_entries(__amdgpu_buffer_rsrc_t rs, int plane_bytes, int x, int y, float dx, float dy, int h, int w, float out[5]) {
+    MatrixPix p;
+    matrix_request(p, rs, plane_bytes, x, y, dx, dy, h, w);
+    matrix_compute(p, x, y, h, w, out);
 }
 
-// R [P][2][h][w][5], flow [P][h][w][2] -> M [P][5][h][w] (planar: the box filters stream it coalesced).
+// The pyramid step as the first matrix update of a level takes it: the flow at pixel (x, y) of this level = the coarser level's
+// flow resized by cv::resize INTER_LINEAR and doubled - the operations of resize_linear_f32<2>, bit for bit, in two halves like
+// the matrix entries (request the four coarse values / interpolate).
+struct FlowUp {
+    const float* src;     // coarser flow [P][H][W][2]
+    int H, W;
+    double scale_y, scale_x;
+};
+struct FlowUpPix {
+    float2 a00, a01, a10, a11;
+    float fx, fy;
+};
+__device__ __forceinline__ void flow_up_request(FlowUpPix& u, const FlowUp& up, const float* __restrict__ im, int x, int y) {
+    float fx = resize_src_coord(x, up.scale_x);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= up.W - 1) { fx = 0.f; sx = up.W - 1; }
+    float fy = resize_src_coord(y, up.scale_y);
+    int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    if (sy < 0) { fy = 0.f; sy = 0; }
+    if (sy >= up.H - 1) { fy = 0.f; sy = up.H - 1; }
+    const int sx1 = sx + 1 < up.W ? sx + 1 : up.W - 1;
+    const int sy1 = sy + 1 < up.H ? sy + 1 : up.H - 1;
+    u.a00 = *reinterpret_cast<const float2*>(im + ((int64_t)sy * up.W + sx) * 2);
+    u.a01 = *reinterpret_cast<const float2*>(im + ((int64_t)sy * up.W + sx1) * 2);
+    u.a10 = *reinterpret_cast<const float2*>(im + ((int64_t)sy1 * up.W + sx) * 2);
+    u.a11 = *reinterpret_cast<const float2*>(im + ((int64_t)sy1 * up.W + sx1) * 2);
+    u.fx = fx;
+    u.fy = fy;
+}
+__device__ __forceinline__ float2 flow_up_value(const FlowUpPix& u) {
+    return make_float2(__fmul_rn(lerp_rn(lerp_rn(u.a00.x, u.a01.x, u.fx), lerp_rn(u.a10.x, u.a11.x, u.fx), u.fy), 2.0f),
+                       __fmul_rn(lerp_rn(lerp_rn(u.a00.y, u.a01.y, u.fx), lerp_rn(u.a10.y, u.a11.y, u.fx), u.fy), 2.0f));
+}
+
+// R [P][2][5][h][w], flow [P][h][w][2] -> M [P][5][h][w] (planar: the box filters stream it coalesced).
 // One row of 256 columns per block.  The bilinear gather of row y reads rows y1, y1 + 1 of R1 and row y + 1 reads y1 + 1, y1 + 2:
 // the shared row should come from L2, but workgroups are dealt round-robin to the 8 XCDs, so with a plain (x, y) grid the
 // neighbouring rows ran on other XCDs and every R1 row was fetched twice from HBM (fetched / written bytes 3.45 against the
@@ -357,11 +474,6 @@ __device__ inline void matrix_entries(const float* __restrict__ R0, const float*
 // first matrix update of a level is its only reader (box_solve_fused writes the level's own flow), so the resized plane is never
 // stored: the update computes the two values where it needs them - the operations of resize_linear_f32<2>, bit for bit (one kernel
 // and 16 bytes per pixel fewer per level).
-struct FlowUp {
-    const float* src;     // coarser flow [P][H][W][2]
-    int H, W;
-    double scale_y, scale_x;
-};
 template <bool UP>
 __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict__ R, const float* __restrict__ flow,
                                                          float* __restrict__ M, int h, int w, int rpb, const FlowUp up) {
@@ -376,30 +488,17 @@ __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict
     float e[5];
     float fx0, fy0;
     if constexpr (UP) {
-        float fx = (float)((x + 0.5) * up.scale_x - 0.5);
-        int sx = (int)floorf(fx);
-        fx -= (float)sx;
-        if (sx < 0) { fx = 0.f; sx = 0; }
-        if (sx >= up.W - 1) { fx = 0.f; sx = up.W - 1; }
-        float fy = (float)((y + 0.5) * up.scale_y - 0.5);
-        int sy = (int)floorf(fy);
-        fy -= (float)sy;
-        if (sy < 0) { fy = 0.f; sy = 0; }
-        if (sy >= up.H - 1) { fy = 0.f; sy = up.H - 1; }
-        const int sx1 = sx + 1 < up.W ? sx + 1 : up.W - 1;
-        const int sy1 = sy + 1 < up.H ? sy + 1 : up.H - 1;
-        const float* im = up.src + pair * ((int64_t)up.H * up.W * 2);
-        const float2 a00 = *reinterpret_cast<const float2*>(im + ((int64_t)sy * up.W + sx) * 2);
-        const float2 a01 = *reinterpret_cast<const float2*>(im + ((int64_t)sy * up.W + sx1) * 2);
-        const float2 a10 = *reinterpret_cast<const float2*>(im + ((int64_t)sy1 * up.W + sx) * 2);
-        const float2 a11 = *reinterpret_cast<const float2*>(im + ((int64_t)sy1 * up.W + sx1) * 2);
-        fx0 = __fmul_rn(lerp_rn(lerp_rn(a00.x, a01.x, fx), lerp_rn(a10.x, a11.x, fx), fy), 2.0f);
-        fy0 = __fmul_rn(lerp_rn(lerp_rn(a00.y, a01.y, fx), lerp_rn(a10.y, a11.y, fx), fy), 2.0f);
+        FlowUpPix u;
+        flow_up_request(u, up, up.src + pair * ((int64_t)up.H * up.W * 2), x, y);
+        const float2 f = flow_up_value(u);
+        fx0 = f.x;
+        fy0 = f.y;
     } else {
         fx0 = flow[i * 2];
         fy0 = flow[i * 2 + 1];
     }
-    matrix_entries(R + (pair * 2) * hw * 5 + ((int64_t)y * w + x) * 5, R + (pair * 2 + 1) * hw * 5, x, y, fx0, fy0, h, w, e);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (pair * 2) * hw * 5), 0, (int)(hw * 40), 0x00020000);
+    matrix_entries(rs, (int)(hw * 4), x, y, fx0, fy0, h, w, e);
     float* o = M + pair * 5 * hw + ((int64_t)y * w + x);
 #pragma unroll
     for (int c = 0; c < 5; ++c) o[c * hw] = e[c];
@@ -512,19 +611,16 @@ __global__ __launch_bounds__(256) void box_solve_fused(const float* __restrict__
                             acc[c][e] = a;
                         }
                     }
-                    const double sc = 1.0 / (WINSIZE * WINSIZE);
                     float* dst = flow + (pair * hw + (int64_t)y * w + x0) * 2;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (x0 + e < w) {
-                            const double g11 = acc[0][e] * sc, g12 = acc[1][e] * sc, g22 = acc[2][e] * sc, h1 = acc[3][e] * sc,
-                                         h2 = acc[4][e] * sc;
-                            const double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
-                            const float fxo = (float)((g11 * h2 - g12 * h1) * idet), fyo = (float)((g22 * h1 - g12 * h2) * idet);
+                            const float2 f = solve_flow(acc[0][e], acc[1][e], acc[2][e], acc[3][e], acc[4][e]);
+                            const float fxo = f.x, fyo = f.y;
                             dst[2 * e] = fxo;
                             dst[2 * e + 1] = fyo;
                             if constexpr (MINMAX) {
-                                const unsigned u = __float_as_uint(sqrtf(fxo * fxo + fyo * fyo));
+                                const unsigned u = __float_as_uint(flow_magnitude(fxo, fyo));
                                 mag_lo = u < mag_lo ? u : mag_lo;
                                 mag_hi = u > mag_hi ? u : mag_hi;
                             }
@@ -532,6 +628,247 @@ __global__ __launch_bounds__(256) void box_solve_fused(const float* __restrict__
                     }
                 }
                 __syncthreads();   // the next group overwrites the three rows
+            }
+        }
+    }
+    if constexpr (MINMAX) {   // wave minimum / maximum, one atomic pair per wave
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned a = __shfl_xor(mag_lo, o), b = __shfl_xor(mag_hi, o);
+            mag_lo = a < mag_lo ? a : mag_lo;
+            mag_hi = b > mag_hi ? b : mag_hi;
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&mm[pair], mag_lo);                 // mins [0,P), maxs [P,2P)
+            atomicMax(&mm[gridDim.z + pair], mag_hi);
+        }
+    }
+}
+
+// ---- one Farneback iteration in ONE kernel ----------------------------------------------------------------------------
+// FarnebackUpdateMatrices + the 15x15 box blur + the 2x2 solve, without the matrix plane M ever going to HBM: per pixel and
+// iteration the memory system sees R0 (20 B), R1 at the displaced position (20 B), the flow in (8 B) and out (8 B) = 56 bytes
+// instead of 68 (update_matrices_k) + 20 + 8 (box_solve_fused) = 96.  update_matrices_k ran at the HBM rate and box_solve_fused
+// waited on its loads (3.2 TB/s with 2 waves per SIMD and 15 loads per thread and group in flight); here the two halves run side
+// by side on one CU as a producer / consumer pair of wave groups:
+//   * waves 4-7, the PRODUCERS: thread = a column of the band (256 = 240 outputs + 7 halo columns each side, replicated
+//     border).  Per step they form the matrix entries of the 3 rows that enter the box window next and put them into LDS.  The
+//     loads are software-pipelined across steps: the flow of step t + 2 (or the four coarse-flow values the pyramid step
+//     interpolates, UP) is requested while the R0 / R1 loads of step t + 1 - whose addresses need the flow of t + 1 - go out row by
+//     row as the entries of step t are computed from the registers the previous step filled.  3 rows x 27 dwords per thread stay
+//     in flight (83 KB per CU) across the barriers: raw s_barrier after `s_waitcnt lgkmcnt(0)`, never __syncthreads (its vmcnt(0)
+//     would drain the pipeline).
+//   * waves 0-3, the BOX waves: box_solve_fused's body.  Thread = the same column: the 15 window rows of the 5 planes in a
+//     register ring, running column sums in double (one add and one subtract per row), taken from LDS instead of HBM; the
+//     column sums of the 3 rows go to LDS in double, then 180 threads slide the 15-column window over 4-output strips and solve.
+//   One barrier per step: the box waves consume the rows the producers wrote during the PREVIOUS step (M double-buffered) and run
+//   the strips of the step before that (column sums double-buffered), so neither side ever waits for the other inside a step.
+// The ring starts as zeros and the first 5 steps (15 rows) fill it - `s += row - 0` - so the loop has no special first window:
+// entering rows y0 - 8 + 3t + r (the very first, y0 - 8, lies outside the window of y0 and enters as zeros).  Same additions in the
+// same order as box_solve_fused, same matrix entries as update_matrices_k (shared source above): the flow is bit-identical.
+constexpr int IT_ROWS = 3;
+constexpr int IT_OUT = FUSE_OUT;                 // 240 output columns per band
+constexpr int IT_STRIPS = IT_OUT / 4;
+constexpr int IT_FILL = WINSIZE / IT_ROWS;       // 5 steps fill the window
+constexpr size_t IT_M_BYTES = sizeof(float) * 2 * IT_ROWS * 5 * 256;
+constexpr size_t IT_LDS = IT_M_BYTES + sizeof(double) * 2 * IT_ROWS * 5 * 256;   // 30 KB + 60 KB
+static_assert(WINSIZE % IT_ROWS == 0 && IT_OUT + WINSIZE - 1 <= 256 && IT_ROWS * IT_STRIPS <= 256, "fused iteration geometry");
+
+#define RELAX_LDS_BARRIER()                                   \
+    do {                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_s_barrier();                         \
+    } while (0)
+
+template <bool UP, bool MINMAX>
+__global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ R, const float* __restrict__ flow_in,
+                                                      float* __restrict__ flow_out, int h, int w, int seg, const FlowUp up,
+                                                      unsigned* __restrict__ mm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef float MTile[IT_ROWS][5][256];
+    typedef double STile[IT_ROWS][5][256];
+    MTile* Mb = reinterpret_cast<MTile*>(smem);
+    STile* Sb = reinterpret_cast<STile*>(smem + IT_M_BYTES);
+    constexpr int m = WINSIZE / 2;
+    const int tid = threadIdx.x & 255;
+    const bool producer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;   // wave-uniform: a scalar branch
+    const int c0 = blockIdx.x * IT_OUT;                       // first output column of the band
+    const int xc = clampi(c0 - m + tid, 0, w - 1);            // this thread's column (clamped = replicated border)
+    const int y0 = blockIdx.y * seg;
+    const int y1 = y0 + seg < h ? y0 + seg : h;
+    const int64_t hw = (int64_t)h * w;
+    const int64_t pair = blockIdx.z;
+    const int Q = IT_FILL + (y1 - y0 + IT_ROWS - 1) / IT_ROWS;   // steps of entering rows; steps t >= 5 complete output rows
+
+    if (producer) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (pair * 2) * hw * 5), 0, (int)(hw * 40), 0x00020000);
+        const int plane_bytes = (int)(hw * 4);
+        const float* fin = UP ? up.src + pair * ((int64_t)up.H * up.W * 2) : flow_in + pair * hw * 2;
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fin), 0, UP ? 0 : (int)(hw * 8), 0x00020000);
+        // One step of operands in flight: while the entries of step t are computed row by row from the registers the previous step
+        // filled, the operands of step t + 1 go out into the registers just consumed, and the flow of step t + 2 (the operand addresses of
+        // a step need its flow a step earlier; two flow sets, even / odd steps).  The loop is unrolled over the two parities so that
+        // every loaded value is consumed from the register it landed in (a copy at the loop head waits for the youngest load:
+        // vmcnt(0)), and the body is straight-line code without a divergent branch (threads 254 / 255 compute two columns nobody
+        // reads): the compiler's wait-count bookkeeping turns pessimistic at control-flow joins.  (Two steps of operands in flight
+        // need 2 x 90 registers: over the 256 the two waves of a SIMD have each, it spilled.)
+#define IT_ROW(t_, r_) clampi(y0 - (m + 1) + IT_ROWS * (t_) + (r_), 0, h - 1)
+        [[maybe_unused]] FlowUpPix fu0[IT_ROWS], fu1[IT_ROWS];      // UP: the four coarse values per pixel
+        [[maybe_unused]] float f0x[IT_ROWS], f0y[IT_ROWS], f1x[IT_ROWS], f1y[IT_ROWS];
+        MatrixPix px[IT_ROWS];
+#define IT_REQUEST_FLOW(t_, r_, FU_, FX_, FY_)                                                               \
+    do {                                                                                                     \
+        const int y_ = IT_ROW(t_, r_);                                                                       \
+        if constexpr (UP) flow_up_request(FU_[r_], up, fin, xc, y_);                                         \
+        else {                                                                                               \
+            const float2 q_ = buf_f32x2(rsf, (y_ * w + xc) * 8, 0);                                          \
+            FX_[r_] = (RELAX_FLOW_ABLATE & 16) ? 0.25f : q_.x;                                               \
+            FY_[r_] = (RELAX_FLOW_ABLATE & 16) ? 0.5f : q_.y;                                                \
+        }                                                                                                    \
+    } while (0)
+#define IT_REQUEST_OPERANDS(t_, r_, FU_, FX_, FY_)                                                           \
+    do {                                                                                                     \
+        float dx_, dy_;                                                                                      \
+        if constexpr (UP) {                                                                                  \
+            const float2 f_ = flow_up_value(FU_[r_]);                                                        \
+            dx_ = f_.x; dy_ = f_.y;                                                                          \
+        } else {                                                                                             \
+            dx_ = FX_[r_]; dy_ = FY_[r_];                                                                    \
+        }                                                                                                    \
+        matrix_request(px[r_], rs, plane_bytes, xc, IT_ROW(t_, r_), dx_, dy_, h, w);                         \
+    } while (0)
+        // one step: FUC_ / FXC_ / FYC_ = the flow set of step t_ + 1 (consumed), FUN_ / .. = that of step t_ + 2 (requested)
+#define IT_STEP(t_, FUC_, FXC_, FYC_, FUN_, FXN_, FYN_, OPS_, FLOW_)                                         \
+    do {                                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < IT_ROWS; ++r) {                                                \
+            float e[5];                                                                                      \
+            if (RELAX_FLOW_ABLATE & 2) {                                                                     \
+                _Pragma("unroll") for (int c = 0; c < 5; ++c) e[c] = px[r].r0[c] + px[r].top[c] + px[r].bot[c] + px[r].top[5 + c] + px[r].bot[5 + c]; \
+            } else                                                                                           \
+                matrix_compute(px[r], xc, IT_ROW(t_, r), h, w, e);                                           \
+            const bool skip = (t_) == 0 && r == 0;   /* row y0 - 8 is outside the window of y0 */            \
+            _Pragma("unroll") for (int c = 0; c < 5; ++c) Mb[(t_) & 1][r][c][tid] = skip ? 0.f : e[c];      \
+            if (OPS_) IT_REQUEST_OPERANDS((t_) + 1, r, FUC_, FXC_, FYC_);                                    \
+            if (FLOW_) IT_REQUEST_FLOW((t_) + 2, r, FUN_, FXN_, FYN_);                                       \
+        }                                                                                                    \
+        RELAX_LDS_BARRIER();                                                                                 \
+    } while (0)
+#define IT_STEP_EVEN(t_, OPS_, FLOW_) IT_STEP(t_, fu1, f1x, f1y, fu0, f0x, f0y, OPS_, FLOW_)
+#define IT_STEP_ODD(t_, OPS_, FLOW_) IT_STEP(t_, fu0, f0x, f0y, fu1, f1x, f1y, OPS_, FLOW_)
+#pragma unroll
+        for (int r = 0; r < IT_ROWS; ++r) IT_REQUEST_FLOW(0, r, fu0, f0x, f0y);
+#pragma unroll
+        for (int r = 0; r < IT_ROWS; ++r) IT_REQUEST_FLOW(1, r, fu1, f1x, f1y);
+#pragma unroll
+        for (int r = 0; r < IT_ROWS; ++r) IT_REQUEST_OPERANDS(0, r, fu0, f0x, f0y);
+        int t = 0;
+        for (; t + 3 < Q; t += 2) {                            // steps t and t + 1 both request operands (t + 2 < Q) and flow (t + 3 < Q)
+            IT_STEP_EVEN(t, true, true);
+            IT_STEP_ODD(t + 1, true, true);
+        }
+        for (; t < Q; ++t) {                                   // the last one to three steps: requests by (uniform) condition
+            const bool ops = t + 1 < Q, flo = t + 2 < Q;
+            if (t & 1) IT_STEP_ODD(t, ops, flo);
+            else IT_STEP_EVEN(t, ops, flo);
+        }
+        RELAX_LDS_BARRIER();                                   // the barrier of step Q (the box waves' last column sums)
+#undef IT_STEP_EVEN
+#undef IT_STEP_ODD
+#undef IT_STEP
+#undef IT_REQUEST_OPERANDS
+#undef IT_REQUEST_FLOW
+#undef IT_ROW
+        return;
+    }
+
+    // ---- box waves ----
+    const int sr = tid / IT_STRIPS, sq = tid - sr * IT_STRIPS;
+    const int x0 = c0 + 4 * sq;
+    const bool strip = tid < IT_ROWS * IT_STRIPS && x0 < w;
+    const bool vec = (w & 3) == 0;                            // 32-byte aligned strips: two 16-byte stores
+    [[maybe_unused]] unsigned mag_lo = 0xffffffffu, mag_hi = 0u;
+    float ring[5][WINSIZE];   // slot of the row that enters at step t as row r: (3 t + r) % 15
+    double s[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        s[c] = 0;
+#pragma unroll
+        for (int k = 0; k < WINSIZE; ++k) ring[c][k] = 0.f;
+    }
+    for (int tb = 0; tb <= Q + 1; tb += IT_FILL) {
+#pragma unroll
+        for (int j = 0; j < IT_FILL; ++j) {
+            const int t = tb + j;                             // this step: V(t - 1), then H(t - 2)
+            if (t <= Q + 1) {                                 // uniform over the block
+                if (t >= 1 && t <= Q && !(RELAX_FLOW_ABLATE & 8)) {
+                    const int par = (t - 1) & 1;
+#pragma unroll
+                    for (int r = 0; r < IT_ROWS; ++r) {
+                        const int slot = (IT_ROWS * (j + IT_FILL - 1) + r) % WINSIZE;   // (3 (t - 1) + r) % 15: tb is a multiple of 5
+#pragma unroll
+                        for (int c = 0; c < 5; ++c) {
+                            const float cur = Mb[par][r][c][tid];
+                            s[c] += (double)cur - (double)ring[c][slot];
+                            ring[c][slot] = cur;
+                            Sb[par][r][c][tid] = s[c];
+                        }
+                    }
+                }
+                if (t >= IT_FILL + 2) {                       // (t <= Q + 1 holds)
+                    const int q = t - 2, par = q & 1;
+                    const int y = y0 + IT_ROWS * (q - IT_FILL) + sr;
+                    if (strip && y < y1 && !(RELAX_FLOW_ABLATE & 4)) {
+                        double acc[5][4];
+#pragma unroll
+                        for (int c = 0; c < 5; ++c) {
+                            double v[18];   // column sums at band columns 4*sq .. 4*sq + 17 (output o uses o .. o + 14)
+#pragma unroll
+                            for (int jj = 0; jj < 9; ++jj) {
+                                const double2 tt = *reinterpret_cast<const double2*>(&Sb[par][sr][c][4 * sq + 2 * jj]);
+                                v[2 * jj] = tt.x;
+                                v[2 * jj + 1] = tt.y;
+                            }
+                            double a = 0;
+#pragma unroll
+                            for (int jj = 0; jj < WINSIZE; ++jj) a += v[jj];
+                            acc[c][0] = a;
+#pragma unroll
+                            for (int e = 1; e < 4; ++e) {
+                                a += v[WINSIZE - 1 + e] - v[e - 1];
+                                acc[c][e] = a;
+                            }
+                        }
+                        float* dst = flow_out + (pair * hw + (int64_t)y * w + x0) * 2;
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float2 f = solve_flow(acc[0][e], acc[1][e], acc[2][e], acc[3][e], acc[4][e]);
+                            o[2 * e] = f.x;
+                            o[2 * e + 1] = f.y;
+                        }
+                        if (vec) {
+                            *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
+                            *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (x0 + e < w) {
+                                    dst[2 * e] = o[2 * e];
+                                    dst[2 * e + 1] = o[2 * e + 1];
+                                }
+                        }
+                        if constexpr (MINMAX) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (x0 + e < w) {
+                                    const unsigned u = __float_as_uint(flow_magnitude(o[2 * e], o[2 * e + 1]));
+                                    mag_lo = u < mag_lo ? u : mag_lo;
+                                    mag_hi = u > mag_hi ? u : mag_hi;
+                                }
+                        }
+                    }
+                }
+                if (t <= Q) RELAX_LDS_BARRIER();
             }
         }
     }
@@ -584,7 +921,7 @@ __global__ __launch_bounds__(256) void mag_minmax(const float* __restrict__ flow
         } else {
             x = f[i * 2]; y = f[i * 2 + 1];
         }
-        const unsigned u = __float_as_uint(sqrtf(x * x + y * y));
+        const unsigned u = __float_as_uint(flow_magnitude(x, y));
         lo = u < lo ? u : lo;
         hi = u > hi ? u : hi;
     }
@@ -613,7 +950,7 @@ __device__ inline void minmax_affine(double smin, double smax, float* scale, flo
 
 // one pixel of flow_to_rgb: (x, y) -> packed b | g << 8 | r << 16
 __device__ inline unsigned visualise_pixel(float x, float y, float mn, float mx) {
-    float mag = sqrtf(x * x + y * y);
+    float mag = flow_magnitude(x, y);
     const float ang = fast_atan2_deg(y, x) * (float)(M_PI / 180);
     // mag = normalize(mag); V = trunc(normalize(mag)): the 2nd min/max are the images of the 1st (monotone affine map)
     float s1, b1, s2, b2;
@@ -755,6 +1092,33 @@ static int visualise(relax_handle* h, const float* flow, int P, int HW, uint8_t*
     return RELAX_OK;
 }
 
+// Rows per block of the box-filter kernels.  Long segments keep the 15-row warm-up (and its re-read operands) small; shorter ones when
+// the level is small, so that a clip's 32 pairs still give every CU work.  The choice depends on the level's geometry only - never on
+// the number of pairs in the launch: the running column sums restart at a segment's first row, so the segmentation is part of what
+// fixes the last bits of the flow, and a pair's flow must not depend on its batch.
+static int flow_segment_rows(int bands, int hh) {
+    for (const int cand : {270, 135, 90, 60, 45})
+        if (bands * ((hh + cand - 1) / cand) >= 16) return cand;
+    return 30;
+}
+
+template <bool UP, bool MINMAX>
+static int launch_flow_iteration(relax_handle* h, const float* R, const float* flow_in, float* flow_out, int hh, int w, int P, const FlowUp& up,
+                                 unsigned* mm, hipStream_t s) {
+    static bool attr_set[kMaxDevices] = {};   // per (instantiation, device)
+    if (!attr_set[h->device]) {
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_iteration<UP, MINMAX>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)IT_LDS));
+        attr_set[h->device] = true;
+    }
+    const int bands = (w + IT_OUT - 1) / IT_OUT;
+    const int seg = flow_segment_rows(bands, hh);
+    hipLaunchKernelGGL((flow_iteration<UP, MINMAX>), dim3(bands, (hh + seg - 1) / seg, P), dim3(512), IT_LDS, s, R, flow_in, flow_out, hh, w,
+                       seg, up, mm);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
 static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next, int64_t pair_stride, int P, int H, int W,
                       float* flow_out, uint8_t* bgr_out, hipStream_t s) {
     const int64_t HW = (int64_t)H * W;
@@ -765,7 +1129,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
     float* tmp = gray + (size_t)P * 2 * HW;
     float* blur = tmp + (size_t)P * 2 * HW;
     float* I = blur + (size_t)P * 2 * HW;
-    float* R = I + (size_t)P * 2 * HW;         // [P][2][h][w][5]
+    float* R = I + (size_t)P * 2 * HW;         // [P][2][5][h][w]
     float* M = R + (size_t)P * 10 * HW;        // [P][h][w][5]
     float* flowA = M + (size_t)P * 5 * HW;     // [P][h][w][2]
     float* flowB = flowA + (size_t)P * 2 * HW;
@@ -832,35 +1196,63 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
             while (seg > 11 && (int64_t)bands * ((hh + seg - 1) / seg) * P * 2 < 2048) seg -= 11;
             hipLaunchKernelGGL(poly_expansion, dim3(bands, (hh + seg - 1) / seg, P * 2), dim3(256), 0, s, Isrc, R, hh, w, seg, pc);
         }
-        // measurement (relax_profile_read kind 5): the dominant kernel of the stage, with its algorithmic bytes: per pixel
-        // 2 x 5 floats of R at the pixel + 5 floats of R1 gathered at the displaced position (counted once: neighbours share
-        // the lines) ... = 40 + 8 (flow) + 20 (M written) = 68 bytes
-        const double um_bytes = 68.0 * (double)hw * P;
-        int um_span;
-        RELAX_TRY(prof_begin(h, s, 3, um_bytes, &um_span));
-        if (prev_flow) {
-            const FlowUp up{prev_flow, ph, pw, (double)ph / hh, (double)pw / w};
-            hipLaunchKernelGGL(update_matrices_k<true>, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8, up);
-        } else {
-            hipLaunchKernelGGL(update_matrices_k<false>, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8, FlowUp{});
-        }
-        RELAX_TRY(prof_end(h, s, um_span));
-        {
-            int seg = 135;   // a multiple of the 15-row ring period
-            const int bands = (w + FUSE_OUT - 1) / FUSE_OUT;
-            while (seg > 30 && (int64_t)bands * ((hh + seg - 1) / seg) * P < 1024) seg -= 15;   // enough blocks to fill the chip
-            const dim3 gf(bands, (hh + seg - 1) / seg, P);
+        if (h->gemm.flow_fused) {
+            // one kernel per iteration (flow_iteration): M stays on the chip.  The iterations ping-pong between the two flow buffers:
+            // a block reads flow rows its neighbours may already have rewritten otherwise.
+            // measurement (relax_profile_read kind 5): algorithmic bytes per pixel = 2 x 5 floats of R at the pixel and at the displaced
+            // position (counted once: neighbours share the lines) + the flow in and out = 56 bytes
+            const double it_bytes = 56.0 * (double)hw * P;
+            float* other = (cur == flowA) ? flowB : flowA;
+            const float* in = cur;                // coarsest level: zeros
+            float* out = other;
+            const FlowUp up = prev_flow ? FlowUp{prev_flow, ph, pw, (double)ph / hh, (double)pw / w} : FlowUp{};
+            if (prev_flow) out = cur;             // finer levels: the first iteration interpolates the coarser flow (in `other`)
             for (int it = 0; it < ITERS; ++it) {
-                if (k == 0 && it == ITERS - 1 && bgr_out) {   // the final flow: its magnitude range is taken on the way out
+                int span;
+                RELAX_TRY(prof_begin(h, s, 3, it_bytes, &span));
+                if (it == 0 && prev_flow) {
+                    RELAX_TRY((launch_flow_iteration<true, false>(h, R, nullptr, out, hh, w, P, up, nullptr, s)));
+                } else if (k == 0 && it == ITERS - 1 && bgr_out) {   // the final flow: its magnitude range is taken on the way out
                     RELAX_TRY(minmax_reset(h, P, mm, s));
-                    hipLaunchKernelGGL(box_solve_fused<true>, gf, dim3(256), 0, s, M, cur, hh, w, seg, mm);
+                    RELAX_TRY((launch_flow_iteration<false, true>(h, R, in, out, hh, w, P, FlowUp{}, mm, s)));
                 } else {
-                    hipLaunchKernelGGL(box_solve_fused<false>, gf, dim3(256), 0, s, M, cur, hh, w, seg, nullptr);
+                    RELAX_TRY((launch_flow_iteration<false, false>(h, R, in, out, hh, w, P, FlowUp{}, nullptr, s)));
                 }
-                if (it < ITERS - 1) {
-                    RELAX_TRY(prof_begin(h, s, 3, um_bytes, &um_span));
-                    hipLaunchKernelGGL(update_matrices_k<false>, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8, FlowUp{});
-                    RELAX_TRY(prof_end(h, s, um_span));
+                RELAX_TRY(prof_end(h, s, span));
+                in = out;
+                out = (out == flowA) ? flowB : flowA;
+            }
+            cur = const_cast<float*>(in);         // the level's result
+        } else {
+            // measurement (relax_profile_read kind 5): the dominant kernel of the stage, with its algorithmic bytes: per pixel
+            // 2 x 5 floats of R at the pixel + 5 floats of R1 gathered at the displaced position (counted once: neighbours share
+            // the lines) ... = 40 + 8 (flow) + 20 (M written) = 68 bytes
+            const double um_bytes = 68.0 * (double)hw * P;
+            int um_span;
+            RELAX_TRY(prof_begin(h, s, 3, um_bytes, &um_span));
+            if (prev_flow) {
+                const FlowUp up{prev_flow, ph, pw, (double)ph / hh, (double)pw / w};
+                hipLaunchKernelGGL(update_matrices_k<true>, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8, up);
+            } else {
+                hipLaunchKernelGGL(update_matrices_k<false>, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8, FlowUp{});
+            }
+            RELAX_TRY(prof_end(h, s, um_span));
+            {
+                const int bands = (w + FUSE_OUT - 1) / FUSE_OUT;
+                const int seg = flow_segment_rows(bands, hh);   // multiples of the 15-row ring period; the same segments as flow_iteration
+                const dim3 gf(bands, (hh + seg - 1) / seg, P);
+                for (int it = 0; it < ITERS; ++it) {
+                    if (k == 0 && it == ITERS - 1 && bgr_out) {   // the final flow: its magnitude range is taken on the way out
+                        RELAX_TRY(minmax_reset(h, P, mm, s));
+                        hipLaunchKernelGGL(box_solve_fused<true>, gf, dim3(256), 0, s, M, cur, hh, w, seg, mm);
+                    } else {
+                        hipLaunchKernelGGL(box_solve_fused<false>, gf, dim3(256), 0, s, M, cur, hh, w, seg, nullptr);
+                    }
+                    if (it < ITERS - 1) {
+                        RELAX_TRY(prof_begin(h, s, 3, um_bytes, &um_span));
+                        hipLaunchKernelGGL(update_matrices_k<false>, g_um, dim3(256), 0, s, R, cur, M, hh, w, (hh + 7) / 8, FlowUp{});
+                        RELAX_TRY(prof_end(h, s, um_span));
+                    }
                 }
             }
         }

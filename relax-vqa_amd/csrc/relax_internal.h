@@ -188,6 +188,8 @@ struct GemmOptions {
     int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)
     int group_m = 8;   // "gemm_group_m": row-tiles per L2 group
     int flow_max_pairs = 0;  // "flow_max_pairs": cap on the pairs per optical-flow chunk (0 = by workspace size only)
+    int flow_fused = 1;      // "flow_fused": 1 = one kernel per Farneback iteration (flow_iteration: M never leaves the chip); 0 = update_matrices_k +
+                             // box_solve_fused (M through HBM) - same bits, the A/B switch of a test
     int fp32_rows = 1;     // "x6_fp32_rows": bf16x6 contractions onto 64 / 128 columns take fp32 activation rows and split them in the K loop
                            // (ResNet-50 layer1 / layer2 block outputs travel as fp32); 0 = split planes everywhere (same bits, more bytes: the A/B switch of a test)
     int debug_poison = 0;  // "debug_poison": fill every workspace with 0xFF bytes when it is requested (test mode: reads of unwritten workspace surface as NaN)

@@ -121,3 +121,23 @@ def test_full_relax_clip_with_flow():
     assert bool(torch.isfinite(out["resnet"]).all()) and bool(torch.isfinite(out["vit"]).all())
     vec = engine().full_clip_vector(frames, flow=True)
     assert vec.shape == (35203,)
+
+
+@pytest.mark.parametrize("h,w,t", [(200, 264, 2), (97, 131, 1), (150, 203, 2), (32, 48, 1), (16, 16, 1), (540, 960, 2), (283, 1000, 1), (1080, 1920, 1)])
+def test_fused_iteration_kernel_equals_the_two_kernel_path_bit_for_bit(h, w, t):
+    """flow_iteration (matrix entries + box blur + solve in one kernel, M never in HBM; the default) against update_matrices_k +
+    box_solve_fused (option flow_fused = 0): the same matrix entries (shared source), the same additions in the same order - flow
+    and flow image identical bit for bit, for every pair of a batch, on sizes with one to four pyramid levels, partial bands,
+    short segments and rows that are not a multiple of 3 or 4."""
+    frames = torch.from_numpy(np.stack([np.stack(_smooth_pair(h, w, 40 + i)) for i in range(t)])).cuda()
+    eng = engine()
+    assert eng.get_option("flow_fused") == 1
+    flow1, img1 = eng.optical_flow(frames, want_flow=True, want_image=True)
+    eng.set_option("flow_fused", 0)
+    try:
+        flow0, img0 = eng.optical_flow(frames, want_flow=True, want_image=True)
+    finally:
+        eng.set_option("flow_fused", 1)
+    assert bool(torch.isfinite(flow1).all())
+    assert torch.equal(flow1, flow0), (float((flow1 - flow0).abs().max()), float((flow1 != flow0).float().mean()))
+    assert torch.equal(img1, img0)
