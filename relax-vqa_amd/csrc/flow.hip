@@ -238,6 +238,162 @@ __global__ __launch_bounds__(256) void resize_linear_f32(const float* __restrict
     dst[((b * h + dy) * w) * C + e] = __fmul_rn(lerp_rn(r0, r1, fy), mul);
 }
 
+// ---- the whole pyramid of one frame in ONE pass over its bytes -------------------------------------------------------------
+// OpenCV's Farneback builds every pyramid level from the full-resolution frame: GaussianBlur (3 / 3 / 9 / 19 taps for the
+// scales 1, 1/2, 1/4, 1/8) then cv::resize.  As separate kernels (flow_gray, gauss3_v4 x 2, resize_linear_f32, gauss_h_sampled x 2,
+// gauss_v_sampled_resize x 2) that is 42 bytes of HBM traffic per pixel and frame; here a block walks down a band of 256 columns
+// once, reading the uint8 frame (3 bytes per pixel) and writing the four level inputs (4 + 1 + 1/4 + 1/16 floats per pixel):
+//   per input row: 68 threads turn 3 dwords each into 4 gray values (the row lives in LDS, reflect-101 halo of 8 columns);
+//   every thread forms the two horizontal 3-tap blurs of its column (levels 0 / 1) and keeps the last rows in registers: the
+//   vertical 3-tap of level 0 gives I0 row y - 1, that of level 1 + the 2 x 2 bilinear combine (lane pairs) I1 row (y - 1) / 2;
+//   threads 0-127 / 128-191 form the horizontal 9- / 19-tap blurs at the two sample columns of every level-2 / level-3 output
+//   column into LDS rings of 16 / 32 rows, and when the last row of an output row's window has arrived, its vertical taps at
+//   the two sample rows and the bilinear combine.
+// Exact scales only (H and W multiples of 8: the sample positions are then 2 d + {0, 1}, 4 d + {1, 2}, 8 d + {3, 4} with weights
+// 1/2; other sizes take the separate kernels), the same products in the same order as those kernels: bit-identical level inputs.
+// One barrier per row: the gray row is double-buffered, and the vertical part of levels 2 / 3 runs one row late.
+struct PyramidTaps {
+    float k0[3], k1[3], k2[9], k3[19];
+};
+constexpr int PYR_HALO = 8;
+constexpr int PYR_G = 256 + 2 * PYR_HALO;     // gray values per row and band
+__global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ next, int64_t pair_stride,
+                                                     int H, int W, float* __restrict__ I0, float* __restrict__ I1, float* __restrict__ I2,
+                                                     float* __restrict__ I3, int seg, const PyramidTaps tp) {
+    __shared__ float g[2][PYR_G];
+    __shared__ float ring2[16][128];
+    __shared__ float ring3[32][64];
+    const int x = threadIdx.x;
+    const int c0 = blockIdx.x * 256;
+    const int c = c0 + x;
+    const int y0 = blockIdx.y * seg;                       // seg is a multiple of 8
+    const int y1 = y0 + seg < H ? y0 + seg : H;
+    const int img = blockIdx.z;                            // pair * 2 + which
+    const uint8_t* src = ((img & 1) ? next : orig) + (int64_t)(img >> 1) * pair_stride;
+    const int64_t HW = (int64_t)H * W;
+    float* o0 = I0 + (int64_t)img * HW;
+    float* o1 = I1 + (int64_t)img * (HW / 4);
+    float* o2 = I2 + (int64_t)img * (HW / 16);
+    float* o3 = I3 + (int64_t)img * (HW / 64);
+    // stage A role: thread q < 68 owns the 4 gray values of columns c0 - 8 + 4 q .. + 3
+    const int cq = c0 - PYR_HALO + 4 * x;
+    const bool loader = x < PYR_G / 4;
+    const bool fast = loader && cq >= 0 && cq + 3 < W;     // whole group inside the row: three aligned dwords
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
+    float slow[4] = {0.f, 0.f, 0.f, 0.f};
+#define PYR_GRAY(b_, g_, r_) (float)(((int)(b_) * 1868 + (int)(g_) * 9617 + (int)(r_) * 4899 + (1 << 13)) >> 14)
+    auto request_row = [&](int y) {
+        if (!loader) return;
+        const uint8_t* row = src + (int64_t)reflect101(y, H) * W * 3;
+        if (fast) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(row + (int64_t)cq * 3);
+            w0 = p[0]; w1 = p[1]; w2 = p[2];
+        } else {                                           // image edge: reflected columns, byte loads
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint8_t* q = row + (int64_t)reflect101(cq + i, W) * 3;
+                slow[i] = PYR_GRAY(q[0], q[1], q[2]);
+            }
+        }
+    };
+    float h0m1 = 0.f, h0m2 = 0.f, h1m1 = 0.f, h1m2 = 0.f, b1prev = 0.f;
+    request_row(y0 - 6);
+    for (int y = y0 - 6; y <= y1 + 6; ++y) {
+        const int par = y & 1;
+        if (loader && y <= y1 + 5) {                       // A: the gray values of row y, then the request for row y + 1
+            float* gq = &g[par][4 * x];
+            if (fast) {
+                gq[0] = PYR_GRAY(w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255);     // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+                gq[1] = PYR_GRAY(w0 >> 24, w1 & 255, (w1 >> 8) & 255);
+                gq[2] = PYR_GRAY((w1 >> 16) & 255, w1 >> 24, w2 & 255);
+                gq[3] = PYR_GRAY((w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gq[i] = slow[i];
+            }
+            if (y < y1 + 5) request_row(y + 1);
+        }
+        __syncthreads();
+        const float* gr = g[par];
+        const int gi = x + PYR_HALO;
+        if (y <= y1 + 5) {
+            // B: horizontal passes of row y
+            float h0c = gr[gi - 1] * tp.k0[0];
+            h0c = fmaf(tp.k0[1], gr[gi], h0c);
+            h0c = fmaf(tp.k0[2], gr[gi + 1], h0c);
+            float h1c = gr[gi - 1] * tp.k1[0];
+            h1c = fmaf(tp.k1[1], gr[gi], h1c);
+            h1c = fmaf(tp.k1[2], gr[gi + 1], h1c);
+            // levels 0 / 1: output row r = y - 1 (rows r - 1, r, r + 1 of the horizontal blurs)
+            const int r = y - 1;
+            float v0 = h0m2 * tp.k0[0];
+            v0 = fmaf(tp.k0[1], h0m1, v0);
+            v0 = fmaf(tp.k0[2], h0c, v0);
+            float b1 = h1m2 * tp.k1[0];
+            b1 = fmaf(tp.k1[1], h1m1, b1);
+            b1 = fmaf(tp.k1[2], h1c, b1);
+            const bool in_rows = r >= y0 && r < y1;
+            if (in_rows && c < W) o0[(int64_t)r * W + c] = v0;
+            // level 1: rows 2 d, 2 d + 1 and columns 2 d, 2 d + 1 of the blurred frame, weights 1/2 (all lanes take part in the exchange)
+            const float a01 = __shfl_down(b1prev, 1), a11 = __shfl_down(b1, 1);
+            if (in_rows && (r & 1) && !(x & 1) && c < W)
+                o1[(int64_t)(r >> 1) * (W / 2) + (c >> 1)] = lerp_rn(lerp_rn(b1prev, a01, 0.5f), lerp_rn(b1, a11, 0.5f), 0.5f);
+            h0m2 = h0m1; h0m1 = h0c;
+            h1m2 = h1m1; h1m1 = h1c;
+            b1prev = b1;
+            if (x < 128) {                                 // level 2: the 9-tap blur at columns 4 d + 1, 4 d + 2
+                const int gs = PYR_HALO + 4 * (x >> 1) + 1 + (x & 1);
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = fmaf(tp.k2[t], gr[gs + t - 4], acc);
+                ring2[y & 15][x] = acc;
+            } else if (x < 192) {                          // level 3: the 19-tap blur at columns 8 d + 3, 8 d + 4
+                const int e = x - 128;
+                const int gs = PYR_HALO + 8 * (e >> 1) + 3 + (e & 1);
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 19; ++t) acc = fmaf(tp.k3[t], gr[gs + t - 9], acc);
+                ring3[y & 31][e] = acc;
+            }
+        }
+        // levels 2 / 3, one row late (the rows up to y - 1 are in the rings since the barrier above)
+        const int yy = y - 1;
+        if (x < 128) {
+            if (((yy - 6) & 3) == 0) {                     // uniform: the window of output row d = (yy - 6) / 4 is complete
+                const int d = (yy - 6) >> 2;
+                if (d >= (y0 >> 2) && d < (y1 >> 2)) {
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        a0 = fmaf(tp.k2[t], ring2[(4 * d + 1 + t - 4) & 15][x], a0);
+                        a1 = fmaf(tp.k2[t], ring2[(4 * d + 2 + t - 4) & 15][x], a1);
+                    }
+                    const float a01 = __shfl_down(a0, 1), a11 = __shfl_down(a1, 1);
+                    const int dx = (c0 >> 2) + (x >> 1);
+                    if (!(x & 1) && dx < (W >> 2)) o2[(int64_t)d * (W >> 2) + dx] = lerp_rn(lerp_rn(a0, a01, 0.5f), lerp_rn(a1, a11, 0.5f), 0.5f);
+                }
+            }
+        } else if (x < 192) {
+            if (((yy - 13) & 7) == 0) {
+                const int d = (yy - 13) >> 3;
+                if (d >= (y0 >> 3) && d < (y1 >> 3)) {
+                    const int e = x - 128;
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 19; ++t) {
+                        a0 = fmaf(tp.k3[t], ring3[(8 * d + 3 + t - 9) & 31][e], a0);
+                        a1 = fmaf(tp.k3[t], ring3[(8 * d + 4 + t - 9) & 31][e], a1);
+                    }
+                    const float a01 = __shfl_down(a0, 1), a11 = __shfl_down(a1, 1);
+                    const int dx = (c0 >> 3) + (e >> 1);
+                    if (!(e & 1) && dx < (W >> 3)) o3[(int64_t)d * (W >> 3) + dx] = lerp_rn(lerp_rn(a0, a01, 0.5f), lerp_rn(a1, a11, 0.5f), 0.5f);
+                }
+            }
+        }
+    }
+#undef PYR_GRAY
+}
+
 // FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][5][h][w] (planar: every access of the consumers is a coalesced dword row).  A block owns a band of 246 output columns (256
 // threads = 246 + the 5-column halo on each side, replicated border) and a segment of rows, and walks down the rows:
 //   * vertical 11-tap filters (float, as OpenCV), one COLUMN per thread: the 11 rows of the window live in a register ring
@@ -1137,12 +1293,6 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
 
     PolyConsts pc;
     prepare_poly(&pc);
-    if (HW % 4 == 0 && pair_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(orig) | reinterpret_cast<uintptr_t>(next)) & 3) == 0 &&
-        (reinterpret_cast<uintptr_t>(gray) & 15) == 0)
-        hipLaunchKernelGGL(flow_gray_v4, dim3(nblocks(HW / 4), 1, P * 2), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray);
-    else
-        hipLaunchKernelGGL(flow_gray, dim3(nblocks(HW), 1, P * 2), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray);
-
     int levels = 0;
     {
         double sc = 1.0;
@@ -1151,6 +1301,32 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
             if (W * sc < 32 || H * sc < 32) break;
         }
     }
+    // the four level inputs in one pass over the frames (pyramid_fused) when the scales are exact: blur -> level 0, I -> level 1,
+    // tmp -> levels 2 and 3; otherwise the gray plane and the per-level blur / resize kernels below
+    const bool pyr = h->gemm.flow_pyramid_fused && levels == 3 && H % 8 == 0 && W % 8 == 0 && pair_stride % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(orig) | reinterpret_cast<uintptr_t>(next)) & 3) == 0;
+    float* lvl_in[4] = {blur, I, tmp, tmp + (size_t)P * 2 * (HW / 16)};
+    if (pyr) {
+        PyramidTaps tp;
+        for (int k = 0; k <= 3; ++k) {
+            const double scale = 1.0 / (1 << k), sigma = (1. / scale - 1) * 0.5;
+            int smooth = (int)lrint(sigma * 5) | 1;
+            if (smooth < 3) smooth = 3;
+            GaussKernel gk;
+            make_gauss(smooth, sigma, &gk);
+            RELAX_REQUIRE(h, gk.ksize == (k < 2 ? 3 : (k == 2 ? 9 : 19)), "optical flow: unexpected smoothing kernel %d at level %d", gk.ksize, k);
+            float* dst = k == 0 ? tp.k0 : (k == 1 ? tp.k1 : (k == 2 ? tp.k2 : tp.k3));
+            for (int i = 0; i < gk.ksize; ++i) dst[i] = gk.k[i];
+        }
+        const int seg = 256;
+        hipLaunchKernelGGL(pyramid_fused, dim3((W + 255) / 256, (H + seg - 1) / seg, P * 2), dim3(256), 0, s, orig, next, pair_stride, H, W,
+                           lvl_in[0], lvl_in[1], lvl_in[2], lvl_in[3], seg, tp);
+    } else if (HW % 4 == 0 && pair_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(orig) | reinterpret_cast<uintptr_t>(next)) & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(gray) & 15) == 0)
+        hipLaunchKernelGGL(flow_gray_v4, dim3(nblocks(HW / 4), 1, P * 2), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray);
+    else
+        hipLaunchKernelGGL(flow_gray, dim3(nblocks(HW), 1, P * 2), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray);
+
     float* prev_flow = nullptr;
     int ph = 0, pw = 0;
     float* cur = flowA;
@@ -1170,7 +1346,9 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
         make_gauss(smooth, sigma, &gk);
         const float* Isrc;
         const dim3 g_full(nblocks(W), H, P * 2), g_lvl2(nblocks(w), hh, P * 2), g_um(nblocks(w), 8 * ((hh + 7) / 8), P);
-        if (k >= 2) {   // coarse levels: blur only where the resize samples
+        if (pyr) {
+            Isrc = lvl_in[k];
+        } else if (k >= 2) {   // coarse levels: blur only where the resize samples
             hipLaunchKernelGGL(gauss_h_sampled, dim3(nblocks(2 * w), H, P * 2), dim3(256), 0, s, gray, tmp, H, W, w, (double)W / w, gk);
             hipLaunchKernelGGL(gauss_v_sampled_resize, g_lvl2, dim3(256), 0, s, tmp, I, H, W, hh, w, (double)H / hh,
                                (double)W / w, gk);

@@ -188,6 +188,8 @@ struct GemmOptions {
     int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)
     int group_m = 8;   // "gemm_group_m": row-tiles per L2 group
     int flow_max_pairs = 0;  // "flow_max_pairs": cap on the pairs per optical-flow chunk (0 = by workspace size only)
+    int flow_pyramid_fused = 1;  // "flow_pyramid_fused": 1 = the four pyramid-level inputs of a frame in one pass over its bytes (pyramid_fused; frames whose
+                                 // height and width are multiples of 8), 0 = gray plane + per-level blur / resize kernels (any size) - same bits
     int flow_fused = 1;      // "flow_fused": 1 = one kernel per Farneback iteration (flow_iteration: M never leaves the chip); 0 = update_matrices_k +
                              // box_solve_fused (M through HBM) - same bits, the A/B switch of a test
     int fp32_rows = 1;     // "x6_fp32_rows": bf16x6 contractions onto 64 / 128 columns take fp32 activation rows and split them in the K loop

@@ -141,3 +141,23 @@ def test_fused_iteration_kernel_equals_the_two_kernel_path_bit_for_bit(h, w, t):
     assert bool(torch.isfinite(flow1).all())
     assert torch.equal(flow1, flow0), (float((flow1 - flow0).abs().max()), float((flow1 != flow0).float().mean()))
     assert torch.equal(img1, img0)
+
+
+@pytest.mark.parametrize("h,w,t", [(256, 256, 1), (264, 520, 2), (512, 272, 1), (1080, 1920, 1), (720, 1280, 2), (2160, 3840, 1)])
+def test_fused_pyramid_equals_the_per_level_kernels_bit_for_bit(h, w, t):
+    """pyramid_fused (the four level inputs of a frame in one pass over its uint8 bytes; frames whose sides are multiples of 8)
+    against flow_gray + the per-level blur / resize kernels (option flow_pyramid_fused = 0): same products in the same order, so
+    the flow and its image are identical bit for bit - bands that end inside the last 256 columns, segments that end inside the
+    last 256 rows, reflected borders on all four sides."""
+    frames = torch.from_numpy(np.stack([np.stack(_smooth_pair(h, w, 60 + i)) for i in range(t)])).cuda()
+    eng = engine()
+    assert eng.get_option("flow_pyramid_fused") == 1
+    flow1, img1 = eng.optical_flow(frames, want_flow=True, want_image=True)
+    eng.set_option("flow_pyramid_fused", 0)
+    try:
+        flow0, img0 = eng.optical_flow(frames, want_flow=True, want_image=True)
+    finally:
+        eng.set_option("flow_pyramid_fused", 1)
+    assert bool(torch.isfinite(flow1).all())
+    assert torch.equal(flow1, flow0), (float((flow1 - flow0).abs().max()), float((flow1 != flow0).float().mean()))
+    assert torch.equal(img1, img0)
