@@ -394,18 +394,19 @@ __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__
 #undef PYR_GRAY
 }
 
-// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][5][h][w] (planar: every access of the consumers is a coalesced dword row).  A block owns a band of 246 output columns (256
-// threads = 246 + the 5-column halo on each side, replicated border) and a segment of rows, and walks down the rows:
-//   * vertical 11-tap filters (float, as OpenCV), one COLUMN per thread: the 11 rows of the window live in a register ring
-//     (static indices: the row loop is unrolled over the ring period), so every input value is loaded once per segment - with
-//     one row per block, as before, each thread re-read its 11 rows and the kernel ran at the L2 rate on 84 bytes per pixel
-//     (1.55 ms per 2160p launch for 4.4 GB of HBM traffic); the row entering the window is requested a step ahead;
+// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][5][h][w] (planar: every access of the consumers is a coalesced
+// dword row).  A block owns a band of 246 output columns (256 threads = 246 + the 5-column halo on each side, replicated border)
+// and a segment of rows, and walks down the rows:
+//   * vertical 11-tap filters (float, as OpenCV), one COLUMN per thread: the 11 rows of the window live in a register ring of 16
+//     slots (static indices: the row loop is unrolled over the 16), so every input value is loaded once per segment - with one row
+//     per block each thread re-read its 11 rows and the kernel ran at the L2 rate on 84 bytes per pixel; the other 5 slots hold the
+//     rows requested ahead;
 //   * the three vertical results go through LDS (double-buffered: one barrier per row), and the horizontal 11-tap part (double
 //     accumulators, as OpenCV) reads its neighbours there.
-// Same operations in the same order as the one-row form: bit-identical output.  The intermediate [h][w][3] plane never goes to
-// HBM: 4 + 20 bytes per pixel.
+// The intermediate [h][w][3] plane never goes to HBM: 4 + 20 bytes per pixel.
 constexpr int POLY_OUT = 256 - 2 * POLY_N;   // 246
 constexpr int POLY_RING = 2 * POLY_N + 1;    // 11
+constexpr int POLY_SLOTS = 16;               // the window + 5 rows in flight
 __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ I, float* __restrict__ R, int h, int w, int seg,
                                                       PolyConsts pc) {
     __shared__ float lt[2][3][256];
@@ -416,29 +417,30 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
     const int y1 = y0 + seg < h ? y0 + seg : h;
     const float* col = I + (int64_t)blockIdx.z * ((int64_t)w * h) + xc;
     const bool writer = tid >= POLY_N && tid < 256 - POLY_N && x < w;
-    float ring[POLY_RING];    // at the row y = y0 + s: slot (s + i) % 11 holds row y - 5 + i (clamped), i = 0 .. 10
+    // at the row y = y0 + s: slot (s + i) % 16 holds row y - 5 + i (clamped): i = 0 .. 10 the window, i = 11 .. 15 rows already
+    // requested (with one row requested per step a thread had ONE 4-byte load in flight and the kernel waited on the read latency:
+    // 3.3 TB/s; five rows ahead the reads are no longer what it waits for)
+    float ring[POLY_SLOTS];
 #pragma unroll
-    for (int i = 0; i < POLY_RING; ++i) ring[i] = col[(int64_t)clampi(y0 - POLY_N + i, 0, h - 1) * w];
-    float nxt = col[(int64_t)clampi(y0 + POLY_N + 1, 0, h - 1) * w];   // enters the window at the next row
+    for (int i = 0; i < POLY_SLOTS; ++i) ring[i] = col[(int64_t)clampi(y0 - POLY_N + i, 0, h - 1) * w];
     int par = 0;
-    for (int yb = y0; yb < y1; yb += POLY_RING) {
+    for (int yb = y0; yb < y1; yb += POLY_SLOTS) {
 #pragma unroll
-        for (int j = 0; j < POLY_RING; ++j) {
+        for (int j = 0; j < POLY_SLOTS; ++j) {
             const int y = yb + j;
             if (y < y1) {                                   // uniform over the block
-                const float entering = nxt;
-                nxt = col[(int64_t)clampi(y + POLY_N + 2, 0, h - 1) * w];
-                float t0 = ring[(j + POLY_N) % POLY_RING] * pc.g[0], t1 = 0.f, t2 = 0.f;
+                const float entering = col[(int64_t)clampi(y + POLY_N + 1 + (POLY_SLOTS - POLY_RING), 0, h - 1) * w];   // row y + 11
+                float t0 = ring[(j + POLY_N) % POLY_SLOTS] * pc.g[0], t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int k = 1; k <= POLY_N; ++k) {
-                    const float up = ring[(j + POLY_N - k) % POLY_RING];
-                    const float dn = ring[(j + POLY_N + k) % POLY_RING];
+                    const float up = ring[(j + POLY_N - k) % POLY_SLOTS];
+                    const float dn = ring[(j + POLY_N + k) % POLY_SLOTS];
                     const float p = up + dn;
                     t0 = fmaf(pc.g[k], p, t0);
                     t1 = fmaf(pc.xg[k], dn - up, t1);
                     t2 = fmaf(pc.xxg[k], p, t2);
                 }
-                ring[j] = entering;                         // row y + 6 takes the slot of row y - 5
+                ring[j] = entering;                         // row y + 11 takes the slot of row y - 5
                 lt[par][0][tid] = t0;
                 lt[par][1][tid] = t1;
                 lt[par][2][tid] = t2;
@@ -1369,9 +1371,9 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
             }
         }
         {
-            int seg = 66;   // a multiple of the 11-row ring period; shorter segments when the level is small (enough blocks for 256 CUs)
+            int seg = 64;   // rows per block (16 to fill the ring before the first one); shorter segments when the level is small (enough blocks for 256 CUs)
             const int bands = (w + POLY_OUT - 1) / POLY_OUT;
-            while (seg > 11 && (int64_t)bands * ((hh + seg - 1) / seg) * P * 2 < 2048) seg -= 11;
+            while (seg > 16 && (int64_t)bands * ((hh + seg - 1) / seg) * P * 2 < 2048) seg -= 16;
             hipLaunchKernelGGL(poly_expansion, dim3(bands, (hh + seg - 1) / seg, P * 2), dim3(256), 0, s, Isrc, R, hh, w, seg, pc);
         }
         if (h->gemm.flow_fused) {
