@@ -23,8 +23,8 @@
 namespace relax {
 
 #ifndef RELAX_FLOW_ABLATE
-#define RELAX_FLOW_ABLATE 0     // diagnostic builds (tools/build_ablations.sh flow:<mask>, WRONG results, timing only): 1 no frame-1 gather,
-#endif                          // 2 no matrix arithmetic, 4 no strips (window slide + solve), 8 no column sums, 16 no frame-0 / flow loads
+#define RELAX_FLOW_ABLATE 0     // diagnostic builds (tools/build_ablations.sh flow:<mask>, WRONG results, timing only):
+#endif                          // 2 no matrix arithmetic, 4 no strips (window slide + solve), 8 no column sums, 16 no flow loads
 constexpr int POLY_N = 5;
 constexpr int WINSIZE = 15;
 constexpr int ITERS = 3;
@@ -394,8 +394,9 @@ __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__
 #undef PYR_GRAY
 }
 
-// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][5][h][w] (planar: every access of the consumers is a coalesced
-// dword row).  A block owns a band of 246 output columns (256 threads = 246 + the 5-column halo on each side, replicated border)
+// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][h][w][5] (a pixel's five coefficients side by side: the
+// iteration kernel then reads ONE sequential stream per frame; with five planes [5][h][w] - coalesced dword rows - a 2160p pair took
+// 0.73 instead of 0.68 ms: sixteen streams per block cost more in DRAM pages than the strided lanes cost in the load unit).  A block owns a band of 246 output columns (256 threads = 246 + the 5-column halo on each side, replicated border)
 // and a segment of rows, and walks down the rows:
 //   * vertical 11-tap filters (float, as OpenCV), one COLUMN per thread: the 11 rows of the window live in a register ring of 16
 //     slots (static indices: the row loop is unrolled over the 16), so every input value is loaded once per segment - with one row
@@ -461,12 +462,12 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
                         b5 += (p2 + m2) * pc.g[k];
                     }
                     const int64_t hw = (int64_t)h * w;
-                    float* o = R + (int64_t)blockIdx.z * 5 * hw + (int64_t)y * w + x;     // planar: coalesced stores
-                    o[1 * hw] = (float)(b2 * pc.ig11);
+                    float* o = R + ((int64_t)blockIdx.z * hw + (int64_t)y * w + x) * 5;
+                    o[1] = (float)(b2 * pc.ig11);
                     o[0] = (float)(b3 * pc.ig11);
-                    o[3 * hw] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-                    o[2 * hw] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-                    o[4 * hw] = (float)(b6 * pc.ig55);
+                    o[3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+                    o[2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+                    o[4] = (float)(b6 * pc.ig55);
                 }
                 par ^= 1;   // the next row writes the other buffer: its barrier orders these reads before the buffer's reuse
             }
@@ -485,19 +486,26 @@ struct MatrixPix {
     float dx, dy;         // the flow at the pixel
     bool inb;             // displaced position inside the image (else the frame-1 terms are dropped)
 };
-// Loads go through a buffer resource over the pair's two coefficient images (planar [2][5][h][w]): one 32-bit byte offset per pixel in
-// a VGPR, the plane offsets in SGPRs - no 64-bit address arithmetic per load (17 VALU instructions per pixel with flat pointers).
+// Loads go through a buffer resource over the pair's two coefficient images ([2][h][w][5]): one 32-bit byte offset per pixel in a VGPR,
+// the frame offset in an SGPR - no 64-bit address arithmetic per load (17 VALU instructions per pixel with flat pointers); the 5 / 10
+// contiguous floats of a pixel / a pixel pair arrive as 16- + 4-byte and 16- + 16- + 8-byte loads.
 __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
 __device__ __forceinline__ float2 buf_f32x2(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
 }
-__device__ __forceinline__ void matrix_request(MatrixPix& p, __amdgpu_buffer_rsrc_t rs, int plane_bytes, int x, int y, float dx, float dy, int h,
+__device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void matrix_request(MatrixPix& p, __amdgpu_buffer_rsrc_t rs, int frame_bytes, int x, int y, float dx, float dy, int h,
                                                int w) {
-    const int v0 = (y * w + x) * 4;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) p.r0[c] = (RELAX_FLOW_ABLATE & 16) ? dx : buf_f32(rs, v0, c * plane_bytes);
+    const int v0 = (y * w + x) * 20;
+    {
+        const f32x4 a = buf_f32x4(rs, v0, 0);
+        p.r0[0] = a.x; p.r0[1] = a.y; p.r0[2] = a.z; p.r0[3] = a.w;
+        p.r0[4] = buf_f32(rs, v0 + 16, 0);
+    }
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     fx -= x1;
@@ -505,18 +513,17 @@ __device__ __forceinline__ void matrix_request(MatrixPix& p, __amdgpu_buffer_rsr
     p.fx = fx; p.fy = fy; p.dx = dx; p.dy = dy;
     p.inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
     // outside the image the values are not used: the loads go to a clamped (valid) address instead of sitting in a divergent branch
-    const int v1 = (clampi(y1, 0, h - 2) * w + clampi(x1, 0, w - 2)) * 4, v2 = v1 + w * 4;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {      // (x1, x1 + 1) pairs: one 8-byte load each
-        if (RELAX_FLOW_ABLATE & 1) {
-            p.top[c] = p.top[5 + c] = p.bot[c] = p.bot[5 + c] = p.r0[c];
-            continue;
-        }
-        const float2 t = buf_f32x2(rs, v1, (5 + c) * plane_bytes), u = buf_f32x2(rs, v2, (5 + c) * plane_bytes);
-        p.top[c] = t.x;
-        p.top[5 + c] = t.y;
-        p.bot[c] = u.x;
-        p.bot[5 + c] = u.y;
+    const int v1 = (clampi(y1, 0, h - 2) * w + clampi(x1, 0, w - 2)) * 20, v2 = v1 + w * 20;
+    {
+        const int f1 = frame_bytes;          // frame 1
+        const f32x4 a = buf_f32x4(rs, v1, f1), b = buf_f32x4(rs, v1 + 16, f1);
+        const float2 c2 = buf_f32x2(rs, v1 + 32, f1);
+        p.top[0] = a.x; p.top[1] = a.y; p.top[2] = a.z; p.top[3] = a.w; p.top[4] = b.x;
+        p.top[5] = b.y; p.top[6] = b.z; p.top[7] = b.w; p.top[8] = c2.x; p.top[9] = c2.y;
+        const f32x4 d = buf_f32x4(rs, v2, f1), e = buf_f32x4(rs, v2 + 16, f1);
+        const float2 f2 = buf_f32x2(rs, v2 + 32, f1);
+        p.bot[0] = d.x; p.bot[1] = d.y; p.bot[2] = d.z; p.bot[3] = d.w; p.bot[4] = e.x;
+        p.bot[5] = e.y; p.bot[6] = e.z; p.bot[7] = e.w; p.bot[8] = f2.x; p.bot[9] = f2.y;
     }
 }
 // Every product / sum below names its rounding (__fmul_rn / __fadd_rn / __fmaf_rn): left to itself the compiler contracts these
@@ -578,9 +585,9 @@ __device__ __forceinline__ float2 solve_flow(double A0, double A1, double A2, do
     const double ny = __fma_rn(A2, A3, -__dmul_rn(A1, A4));
     return make_float2((float)__dmul_rn(nx, r), (float)__dmul_rn(ny, r));
 }
-__device__ inline void matrix_entries(__amdgpu_buffer_rsrc_t rs, int plane_bytes, int x, int y, float dx, float dy, int h, int w, float out[5]) {
+__device__ inline void matrix_entries(__amdgpu_buffer_rsrc_t rs, int frame_bytes, int x, int y, float dx, float dy, int h, int w, float out[5]) {
     MatrixPix p;
-    matrix_request(p, rs, plane_bytes, x, y, dx, dy, h, w);
+    matrix_request(p, rs, frame_bytes, x, y, dx, dy, h, w);
     matrix_compute(p, x, y, h, w, out);
 }
 
@@ -621,7 +628,7 @@ __device__ __forceinline__ float2 flow_up_value(const FlowUpPix& u) {
                        __fmul_rn(lerp_rn(lerp_rn(u.a00.y, u.a01.y, u.fx), lerp_rn(u.a10.y, u.a11.y, u.fx), u.fy), 2.0f));
 }
 
-// R [P][2][5][h][w], flow [P][h][w][2] -> M [P][5][h][w] (planar: the box filters stream it coalesced).
+// R [P][2][h][w][5], flow [P][h][w][2] -> M [P][5][h][w] (planar: the box filters stream it coalesced).
 // One row of 256 columns per block.  The bilinear gather of row y reads rows y1, y1 + 1 of R1 and row y + 1 reads y1 + 1, y1 + 2:
 // the shared row should come from L2, but workgroups are dealt round-robin to the 8 XCDs, so with a plain (x, y) grid the
 // neighbouring rows ran on other XCDs and every R1 row was fetched twice from HBM (fetched / written bytes 3.45 against the
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict
         fy0 = flow[i * 2 + 1];
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (pair * 2) * hw * 5), 0, (int)(hw * 40), 0x00020000);
-    matrix_entries(rs, (int)(hw * 4), x, y, fx0, fy0, h, w, e);
+    matrix_entries(rs, (int)(hw * 20), x, y, fx0, fy0, h, w, e);
     float* o = M + pair * 5 * hw + ((int64_t)y * w + x);
 #pragma unroll
     for (int c = 0; c < 5; ++c) o[c * hw] = e[c];
@@ -860,7 +867,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
 
     if (producer) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (pair * 2) * hw * 5), 0, (int)(hw * 40), 0x00020000);
-        const int plane_bytes = (int)(hw * 4);
+        const int frame_bytes = (int)(hw * 20);
         const float* fin = UP ? up.src + pair * ((int64_t)up.H * up.W * 2) : flow_in + pair * hw * 2;
         [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fin), 0, UP ? 0 : (int)(hw * 8), 0x00020000);
         // One step of operands in flight: while the entries of step t are computed row by row from the registers the previous step
@@ -893,7 +900,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
         } else {                                                                                             \
             dx_ = FX_[r_]; dy_ = FY_[r_];                                                                    \
         }                                                                                                    \
-        matrix_request(px[r_], rs, plane_bytes, xc, IT_ROW(t_, r_), dx_, dy_, h, w);                         \
+        matrix_request(px[r_], rs, frame_bytes, xc, IT_ROW(t_, r_), dx_, dy_, h, w);                         \
     } while (0)
         // one step: FUC_ / FXC_ / FYC_ = the flow set of step t_ + 1 (consumed), FUN_ / .. = that of step t_ + 2 (requested)
 #define IT_STEP(t_, FUC_, FXC_, FYC_, FUN_, FXN_, FYN_, OPS_, FLOW_)                                         \
@@ -1287,7 +1294,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
     float* tmp = gray + (size_t)P * 2 * HW;
     float* blur = tmp + (size_t)P * 2 * HW;
     float* I = blur + (size_t)P * 2 * HW;
-    float* R = I + (size_t)P * 2 * HW;         // [P][2][5][h][w]
+    float* R = I + (size_t)P * 2 * HW;         // [P][2][h][w][5]
     float* M = R + (size_t)P * 10 * HW;        // [P][h][w][5]
     float* flowA = M + (size_t)P * 5 * HW;     // [P][h][w][2]
     float* flowB = flowA + (size_t)P * 2 * HW;
