@@ -122,23 +122,28 @@ def hbm_traffic_per_launch(workload, clips_per_step, precision):
     return None
 
 
+FLOW_KERNELS = ("relax::flow_", "relax::poly_expansion", "relax::pyramid_fused", "relax::gauss", "relax::resize_linear_f32", "relax::update_matrices_k",
+                "relax::box_solve_fused", "relax::mag_minmax")
+
+
 def measure_hbm_traffic(workload, clips_per_step, precision, split_k):
     """roofline.traffic measured in THIS run: two child passes of this script under rocprofv3 (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`:
     separate passes, kernel-trace only, as the gfx950 guide prescribes; FETCH_SIZE doubled: it reports half of a 16-B-per-lane
-    streaming read), one warm-up + one step each; bytes per launch of the dominant kernel family (gemm_x6*, conv1_x6).  The children are
-    started as CHILD processes (never exec) with the program itself after `--`, each bounded to 150 s.
-    Returns (bytes per launch | None, note)."""
+    streaming read), one warm-up + one step each; bytes per launch of the dominant kernel family (gemm_x6*, conv1_x6) and, for the
+    full pipelines, the bytes of all Farneback kernels per clip (one stage call per clip).  The children are started as CHILD
+    processes (never exec) with the program itself after `--`, each bounded to 150 s.
+    Returns (bytes per contraction launch | None, note, flow-stage bytes per clip | None)."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
     if shutil.which("rocprofv3") is None:
-        return None, "rocprofv3 not on PATH"
+        return None, "rocprofv3 not on PATH", None
     if any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
-        return None, "this run is itself being profiled"
+        return None, "this run is itself being profiled", None
     tmp = tempfile.mkdtemp(prefix="relax_pmc_", dir="/tmp")
-    tot, launches = {}, 0
+    tot, flow_tot, launches = {}, {}, 0
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
@@ -148,22 +153,27 @@ def measure_hbm_traffic(workload, clips_per_step, precision, split_k):
             res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=150)
             files = glob.glob(os.path.join(out, "*", "*counter_collection.csv"))
             if res.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode}): {res.stderr[-300:]}"
-            total, ids = 0.0, set()
+                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode}): {res.stderr[-300:]}", None
+            total, flow_total, ids = 0.0, 0.0, set()
             for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
-                if r["Counter_Name"] != counter or not ("relax::gemm_x6" in r["Kernel_Name"] or "relax::conv1_x6" in r["Kernel_Name"]):
+                if r["Counter_Name"] != counter:
                     continue
-                total += float(r["Counter_Value"])
-                ids.add(r["Dispatch_Id"])
+                if "relax::gemm_x6" in r["Kernel_Name"] or "relax::conv1_x6" in r["Kernel_Name"]:
+                    total += float(r["Counter_Value"])
+                    ids.add(r["Dispatch_Id"])
+                elif any(k in r["Kernel_Name"] for k in FLOW_KERNELS):
+                    flow_total += float(r["Counter_Value"])
             tot[counter] = total * 1024.0          # KiB -> bytes
+            flow_tot[counter] = flow_total * 1024.0
             launches = len(ids)
         if not launches:
-            return None, "no gemm_x6 dispatch in the PMC pass"
+            return None, "no gemm_x6 dispatch in the PMC pass", None
+        flow_per_clip = (2.0 * flow_tot["FETCH_SIZE"] + flow_tot["WRITE_SIZE"]) / (2 * clips_per_step) if flow_tot["WRITE_SIZE"] > 0 else None
         return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / launches, (
             f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, one child pass each (1 warm-up + 1 step), "
-            f"(2 x FETCH_SIZE + WRITE_SIZE) over the {launches} gemm_x6 / conv1_x6 dispatches of the pass")
+            f"(2 x FETCH_SIZE + WRITE_SIZE) over the {launches} gemm_x6 / conv1_x6 dispatches of the pass"), flow_per_clip
     except subprocess.TimeoutExpired:
-        return None, "a rocprofv3 pass did not finish in 150 s"
+        return None, "a rocprofv3 pass did not finish in 150 s", None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -345,7 +355,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         prof = {"gemm": eng.profile_read(3 if x6 else 0), "frag": eng.profile_read(1), "gemm_bytes": eng.profile_read(4 if x6 else 2),
-                "flow": eng.profile_read(5), "other": eng.profile_read(0 if x6 else 3)}
+                "flow": eng.profile_read(5), "flow_stage": eng.profile_read(6), "other": eng.profile_read(0 if x6 else 3)}
         eng.profile_enable(False)
         return elapsed, out, prof
 
@@ -418,11 +428,9 @@ def main():
                    "roofline": {"bound": "mfma", "kernel": "gemm_x6 + conv1_x6", "unit": "TFLOP/s", "peak": BF16_MATRIX_PEAK_TFLOPS,
                                 "achieved": 6 * g_flops / (g_ms * 1e-3) / 1e12, "frac": 6 * g_flops / (g_ms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS,
                                 "kernel_time_share_of_step": g_ms * 1e-3 / e_o}}
-            fl_ms, fl_bytes, fl_n = prof_o["flow"]
-            if fl_n:
-                rec["roofline_flow_stage"] = {"bound": "hbm", "kernel": FLOW_KERNEL, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                                              "achieved": fl_bytes / (fl_ms * 1e-3) / 1e9, "frac": fl_bytes / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                              "kernel_time_share_of_step": fl_ms * 1e-3 / e_o}
+            fs = flow_stage_record(prof_o, e_o)
+            if fs is not None:
+                rec["roofline_flow_stage"] = fs
             others[name] = rec
             del step_o, clips_o, out_o
         torch.cuda.empty_cache()
@@ -435,9 +443,10 @@ def main():
     traffic, traffic_note = hbm_traffic_per_launch(args.workload, B, precision), (
         "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (own passes, FETCH doubled per the gfx950 guide), from the "
         "committed profile of this workload, batch and precision: profiles/r03_hbm_traffic.json (null when none matches the run)")
+    flow_traffic = None
     if world == 1 and not args.no_measure_traffic and x6:
         torch.cuda.synchronize()
-        live, note = measure_hbm_traffic(args.workload, B, precision, args.gemm_split_k)
+        live, note, flow_traffic = measure_hbm_traffic(args.workload, B, precision, args.gemm_split_k)
         if live is not None:
             traffic, traffic_note = live, note
         else:
@@ -486,12 +495,9 @@ def main():
             },
         }
         if full and flow_launches:
-            result["roofline_flow_stage"] = {
-                "bound": "hbm", "kernel": FLOW_KERNEL,
-                "achieved": flow_bytes / (flow_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": flow_bytes / (flow_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                "algorithmic_bytes_per_pixel_level_iteration": 68, "launches": flow_launches,
-                "avg_launch_us": flow_ms * 1e3 / flow_launches, "kernel_time_share_of_step": flow_ms * 1e-3 / elapsed}
+            fs = flow_stage_record(prof, elapsed, flow_traffic)
+            if fs is not None:
+                result["roofline_flow_stage"] = fs
         if fast is not None:
             result["exact_fp32_mode" if other == "fp32" else "bf16x6_mode"] = fast
         if h2d is not None:
@@ -507,7 +513,30 @@ def main():
         dist.destroy_process_group()
 
 
-FLOW_KERNEL = "update_matrices_k (Farneback: matrix entries from the two polynomial expansions and the flow)"
+FLOW_KERNEL = ("flow_iteration (one Farneback iteration per launch: matrix entries from the two polynomial expansions and the flow, 15x15 box "
+               "filter, 2x2 solve; 56 algorithmic bytes per pixel)")
+
+
+def flow_stage_record(prof, elapsed_s, traffic_per_clip=None):
+    """roofline_flow_stage: the WHOLE Farneback stage (pyramid, polynomial expansion, 4 levels x 3 iterations, visualisation) against
+    HBM: achieved = the algorithmic bytes of all its kernels (inputs read once, outputs written once per kernel) / the stage's time,
+    first launch to last (HIP events on the launch stream); `dominant_kernel` = the iteration kernel alone."""
+    st_ms, st_bytes, st_n = prof["flow_stage"]
+    it_ms, it_bytes, it_n = prof["flow"]
+    if not st_n or st_ms <= 0:
+        return None
+    rec = {"bound": "hbm", "kernel": "the whole Farneback stage: pyramid_fused, poly_expansion, flow_iteration x 12, flow_visualise",
+           "achieved": st_bytes / (st_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": st_bytes / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "algorithmic_bytes_per_stage": st_bytes / st_n, "stages": st_n, "avg_stage_ms": st_ms / st_n,
+           "traffic": traffic_per_clip,
+           "traffic_over_algorithmic": (traffic_per_clip / (st_bytes / st_n)) if traffic_per_clip else None,
+           "time_share_of_step": st_ms * 1e-3 / elapsed_s,
+           "dominant_kernel": {"kernel": FLOW_KERNEL, "achieved": it_bytes / (it_ms * 1e-3) / 1e9 if it_ms > 0 else 0.0, "unit": "GB/s",
+                               "frac": (it_bytes / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if it_ms > 0 else 0.0,
+                               "algorithmic_bytes_per_pixel_level_iteration": 56, "launches": it_n,
+                               "avg_launch_us": it_ms * 1e3 / max(it_n, 1), "time_share_of_step": it_ms * 1e-3 / elapsed_s}}
+    return rec
 DTYPE_TEXT = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into two bf16 terms, fp32 accumulate; reduced precision)",
               "bf16x6": "f32 (fp32 operands as 3 bf16 planes, 6 partial products on the bf16 MFMA, fp32 accumulate: fp32-grade)"}
 

@@ -77,6 +77,7 @@ int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_
     sp.bytes = bytes;
     sp.kind = kind;
     RELAX_HIP_CHECK(h, hipEventRecord(sp.start, s));
+    RELAX_HIP_CHECK(h, hipEventRecord(sp.stop, s));     // re-recorded by prof_end; an error path that never gets there leaves an empty span, not an unrecorded event
     p.spans.push_back(sp);
     *span_idx = static_cast<int>(p.spans.size()) - 1;
     return RELAX_OK;
@@ -277,10 +278,10 @@ int relax_profile_enable(relax_handle* h, int on) {
 
 int relax_profile_read(relax_handle* h, int kind, double* total_ms, double* total_work, int64_t* launches) {
     if (!h) return RELAX_ERR_INVALID;
-    RELAX_REQUIRE(h, kind >= 0 && kind <= 5, "relax_profile_read: kind must be 0..5");
+    RELAX_REQUIRE(h, kind >= 0 && kind <= 6, "relax_profile_read: kind must be 0..6");
     RELAX_TRY(prof_drain(h));
     // read kind -> (span kind, which total): 2 and 4 return the algorithmic HBM bytes of the contraction launches
-    static const int span_of[6] = {0, 1, 0, 2, 2, 3};
+    static const int span_of[7] = {0, 1, 0, 2, 2, 3, 4};
     const int k = span_of[kind];
     const bool bytes = kind == 2 || kind == 4;
     if (total_ms) *total_ms = h->prof.total_ms[k];

@@ -25,6 +25,15 @@ namespace relax {
 #ifndef RELAX_FLOW_ABLATE
 #define RELAX_FLOW_ABLATE 0     // diagnostic builds (tools/build_ablations.sh flow:<mask>, WRONG results, timing only):
 #endif                          // 2 no matrix arithmetic, 4 no strips (window slide + solve), 8 no column sums, 16 no flow loads
+// Workgroup barrier for data that goes through LDS only: waits for this wave's LDS operations, not for its global loads and
+// stores (__syncthreads() also waits vmcnt(0): in a row-walking kernel that drains the rows requested ahead and the stores of the
+// row just written at every row).
+#define RELAX_LDS_BARRIER()                                   \
+    do {                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_s_barrier();                         \
+    } while (0)
+
 constexpr int POLY_N = 5;
 constexpr int WINSIZE = 15;
 constexpr int ITERS = 3;
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__
             }
             if (y < y1 + 5) request_row(y + 1);
         }
-        __syncthreads();
+        RELAX_LDS_BARRIER();
         const float* gr = g[par];
         const int gi = x + PYR_HALO;
         if (y <= y1 + 5) {
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
                 lt[par][0][tid] = t0;
                 lt[par][1][tid] = t1;
                 lt[par][2][tid] = t2;
-                __syncthreads();
+                RELAX_LDS_BARRIER();
                 if (writer) {
                     double b1 = t0 * pc.g[0], b2 = 0, b3 = t1 * pc.g[0], b4 = 0, b5 = t2 * pc.g[0], b6 = 0;
 #pragma unroll
@@ -839,12 +848,6 @@ constexpr size_t IT_M_BYTES = sizeof(float) * 2 * IT_ROWS * 5 * 256;
 constexpr size_t IT_LDS = IT_M_BYTES + sizeof(double) * 2 * IT_ROWS * 5 * 256;   // 30 KB + 60 KB
 static_assert(WINSIZE % IT_ROWS == 0 && IT_OUT + WINSIZE - 1 <= 256 && IT_ROWS * IT_STRIPS <= 256, "fused iteration geometry");
 
-#define RELAX_LDS_BARRIER()                                   \
-    do {                                                      \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
-        __builtin_amdgcn_s_barrier();                         \
-    } while (0)
-
 template <bool UP, bool MINMAX>
 __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ R, const float* __restrict__ flow_in,
                                                       float* __restrict__ flow_out, int h, int w, int seg, const FlowUp up,
@@ -1113,16 +1116,23 @@ __device__ inline void minmax_affine(double smin, double smax, float* scale, flo
     *shift = (float)(0.0 - smin * sc);
 }
 
+// the two NORM_MINMAX maps of flow_to_rgb for a pair whose magnitudes span [mn, mx]: mag = normalize(mag); V = trunc(normalize(mag)) -
+// the 2nd min / max are the images of the 1st (monotone affine map).  Four double divisions: once per thread, not per pixel.
+struct VisNorm {
+    float s1, b1, s2, b2;
+};
+__device__ inline VisNorm visualise_norm(float mn, float mx) {
+    VisNorm n;
+    minmax_affine(mn, mx, &n.s1, &n.b1);
+    minmax_affine((double)(mn * n.s1 + n.b1), (double)(mx * n.s1 + n.b1), &n.s2, &n.b2);
+    return n;
+}
 // one pixel of flow_to_rgb: (x, y) -> packed b | g << 8 | r << 16
-__device__ inline unsigned visualise_pixel(float x, float y, float mn, float mx) {
+__device__ inline unsigned visualise_pixel(float x, float y, const VisNorm& n) {
     float mag = flow_magnitude(x, y);
     const float ang = fast_atan2_deg(y, x) * (float)(M_PI / 180);
-    // mag = normalize(mag); V = trunc(normalize(mag)): the 2nd min/max are the images of the 1st (monotone affine map)
-    float s1, b1, s2, b2;
-    minmax_affine(mn, mx, &s1, &b1);
-    mag = mag * s1 + b1;
-    minmax_affine((double)(mn * s1 + b1), (double)(mx * s1 + b1), &s2, &b2);
-    const float vf = mag * s2 + b2;
+    mag = mag * n.s1 + n.b1;
+    const float vf = mag * n.s2 + n.b2;
     const float hue = ang * 180.f / (float)M_PI / 2.f;
     const int Hh = (int)(uint8_t)(int)hue;              // numpy float32 -> uint8 assignment truncates
     const int Vv = (int)(uint8_t)(int)vf;
@@ -1150,7 +1160,7 @@ __global__ __launch_bounds__(256) void flow_visualise(const float* __restrict__ 
     if (pix >= HW) return;
     const int pair = blockIdx.z;
     const int64_t i = (int64_t)pair * HW + pix;
-    const unsigned c = visualise_pixel(flow[i * 2], flow[i * 2 + 1], __uint_as_float(mm[pair]), __uint_as_float(mm[P + pair]));
+    const unsigned c = visualise_pixel(flow[i * 2], flow[i * 2 + 1], visualise_norm(__uint_as_float(mm[pair]), __uint_as_float(mm[P + pair])));
     uint8_t* o = bgr + i * 3;
     o[0] = (uint8_t)c;
     o[1] = (uint8_t)(c >> 8);
@@ -1165,9 +1175,9 @@ __global__ __launch_bounds__(256) void flow_visualise_v4(const float* __restrict
     const int pair = blockIdx.z;
     const int64_t i = (int64_t)pair * HW + pix;
     const f32x4 a = *reinterpret_cast<const f32x4*>(flow + i * 2), b = *reinterpret_cast<const f32x4*>(flow + i * 2 + 4);
-    const float mn = __uint_as_float(mm[pair]), mx = __uint_as_float(mm[P + pair]);
-    const unsigned c0 = visualise_pixel(a.x, a.y, mn, mx), c1 = visualise_pixel(a.z, a.w, mn, mx);
-    const unsigned c2 = visualise_pixel(b.x, b.y, mn, mx), c3 = visualise_pixel(b.z, b.w, mn, mx);
+    const VisNorm n = visualise_norm(__uint_as_float(mm[pair]), __uint_as_float(mm[P + pair]));
+    const unsigned c0 = visualise_pixel(a.x, a.y, n), c1 = visualise_pixel(a.z, a.w, n);
+    const unsigned c2 = visualise_pixel(b.x, b.y, n), c3 = visualise_pixel(b.z, b.w, n);
     uint32_t* o = reinterpret_cast<uint32_t*>(bgr + i * 3);
     o[0] = c0 | (c1 << 24);
     o[1] = (c1 >> 8) | (c2 << 16);
@@ -1302,6 +1312,10 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
 
     PolyConsts pc;
     prepare_poly(&pc);
+    // measurement (relax_profile_read kind 6): the whole stage, first launch to last; its algorithmic bytes are added up launch by launch
+    double stage_bytes = 0;
+    int stage_span;
+    RELAX_TRY(prof_begin(h, s, 4, 0.0, &stage_span));
     int levels = 0;
     {
         double sc = 1.0;
@@ -1330,11 +1344,13 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
         const int seg = 256;
         hipLaunchKernelGGL(pyramid_fused, dim3((W + 255) / 256, (H + seg - 1) / seg, P * 2), dim3(256), 0, s, orig, next, pair_stride, H, W,
                            lvl_in[0], lvl_in[1], lvl_in[2], lvl_in[3], seg, tp);
+        stage_bytes += 2.0 * P * HW * (3 + 4 * (1 + 0.25 + 0.0625 + 0.015625));      // the frames once, the four level inputs once
     } else if (HW % 4 == 0 && pair_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(orig) | reinterpret_cast<uintptr_t>(next)) & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(gray) & 15) == 0)
         hipLaunchKernelGGL(flow_gray_v4, dim3(nblocks(HW / 4), 1, P * 2), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray);
     else
         hipLaunchKernelGGL(flow_gray, dim3(nblocks(HW), 1, P * 2), dim3(256), 0, s, orig, next, pair_stride, (int)HW, gray);
+    if (!pyr) stage_bytes += 2.0 * P * HW * (3 + 4);
 
     float* prev_flow = nullptr;
     int ph = 0, pw = 0;
@@ -1355,6 +1371,8 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
         make_gauss(smooth, sigma, &gk);
         const float* Isrc;
         const dim3 g_full(nblocks(W), H, P * 2), g_lvl2(nblocks(w), hh, P * 2), g_um(nblocks(w), 8 * ((hh + 7) / 8), P);
+        if (!pyr)   // per-level blur (+ resize): the gray frame read once, the level input written once (+ the full-size blur written and read at level 1)
+            stage_bytes += 2.0 * P * (4.0 * HW + 4.0 * hw + (k == 1 ? 8.0 * HW : 0.0));
         if (pyr) {
             Isrc = lvl_in[k];
         } else if (k >= 2) {   // coarse levels: blur only where the resize samples
@@ -1382,6 +1400,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
             const int bands = (w + POLY_OUT - 1) / POLY_OUT;
             while (seg > 16 && (int64_t)bands * ((hh + seg - 1) / seg) * P * 2 < 2048) seg -= 16;
             hipLaunchKernelGGL(poly_expansion, dim3(bands, (hh + seg - 1) / seg, P * 2), dim3(256), 0, s, Isrc, R, hh, w, seg, pc);
+            stage_bytes += 2.0 * P * hw * 24;      // 4 bytes in, 5 coefficients out per pixel and frame
         }
         if (h->gemm.flow_fused) {
             // one kernel per iteration (flow_iteration): M stays on the chip.  The iterations ping-pong between the two flow buffers:
@@ -1389,6 +1408,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
             // measurement (relax_profile_read kind 5): algorithmic bytes per pixel = 2 x 5 floats of R at the pixel and at the displaced
             // position (counted once: neighbours share the lines) + the flow in and out = 56 bytes
             const double it_bytes = 56.0 * (double)hw * P;
+            stage_bytes += ITERS * it_bytes;
             float* other = (cur == flowA) ? flowB : flowA;
             const float* in = cur;                // coarsest level: zeros
             float* out = other;
@@ -1415,6 +1435,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
             // 2 x 5 floats of R at the pixel + 5 floats of R1 gathered at the displaced position (counted once: neighbours share
             // the lines) ... = 40 + 8 (flow) + 20 (M written) = 68 bytes
             const double um_bytes = 68.0 * (double)hw * P;
+            stage_bytes += ITERS * (um_bytes + 28.0 * (double)hw * P);      // + box_solve_fused: M read, flow written
             int um_span;
             RELAX_TRY(prof_begin(h, s, 3, um_bytes, &um_span));
             if (prev_flow) {
@@ -1451,7 +1472,12 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
     RELAX_HIP_CHECK(h, hipGetLastError());
     if (flow_out)
         RELAX_HIP_CHECK(h, hipMemcpyAsync(flow_out, prev_flow, sizeof(float) * P * 2 * HW, hipMemcpyDeviceToDevice, s));
-    if (bgr_out) RELAX_TRY(visualise(h, prev_flow, P, (int)HW, bgr_out, mm, s, true));
+    if (bgr_out) {
+        RELAX_TRY(visualise(h, prev_flow, P, (int)HW, bgr_out, mm, s, true));
+        stage_bytes += 11.0 * P * HW;              // the flow read, 3 bytes per pixel written
+    }
+    if (stage_span >= 0) h->prof.spans[stage_span].work = stage_bytes;
+    RELAX_TRY(prof_end(h, s, stage_span));
     return RELAX_OK;
 }
 

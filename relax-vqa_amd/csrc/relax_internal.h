@@ -169,8 +169,8 @@ struct Profiler {
     bool on = false;
     std::vector<ProfSpan> spans;
     std::vector<hipEvent_t> pool;
-    // span kinds: 0 fp32 / bf16x3 contraction, 1 patch score, 2 bf16x6 contraction, 3 Farneback matrix update
-    static constexpr int kKinds = 4;
+    // span kinds: 0 fp32 / bf16x3 contraction, 1 patch score, 2 bf16x6 contraction, 3 Farneback iteration kernel, 4 the whole Farneback stage
+    static constexpr int kKinds = 5;
     double total_ms[kKinds] = {};
     double total_work[kKinds] = {};
     double total_bytes[kKinds] = {};
