@@ -221,6 +221,7 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     else if (k == "gemm_group_m") h->gemm.group_m = value > 0 ? value : 1;
     else if (k == "flow_max_pairs") h->gemm.flow_max_pairs = value > 0 ? value : 0;
     else if (k == "flow_fused") h->gemm.flow_fused = value != 0;
+    else if (k == "flow_seg_rows") h->gemm.flow_seg_rows = value > 0 ? value : 0;
     else if (k == "flow_pyramid_fused") h->gemm.flow_pyramid_fused = value != 0;
     else if (k == "x6_fp32_rows") h->gemm.fp32_rows = value != 0;
     else if (k == "debug_poison") h->gemm.debug_poison = value != 0;
@@ -251,6 +252,7 @@ int relax_get_option(relax_handle* h, const char* key, int* value) {
     else if (k == "gemm_group_m") *value = h->gemm.group_m;
     else if (k == "flow_max_pairs") *value = h->gemm.flow_max_pairs;
     else if (k == "flow_fused") *value = h->gemm.flow_fused;
+    else if (k == "flow_seg_rows") *value = h->gemm.flow_seg_rows;
     else if (k == "flow_pyramid_fused") *value = h->gemm.flow_pyramid_fused;
     else if (k == "x6_fp32_rows") *value = h->gemm.fp32_rows;
     else if (k == "debug_poison") *value = h->gemm.debug_poison;

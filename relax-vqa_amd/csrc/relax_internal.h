@@ -188,6 +188,8 @@ struct GemmOptions {
     int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)
     int group_m = 8;   // "gemm_group_m": row-tiles per L2 group
     int flow_max_pairs = 0;  // "flow_max_pairs": cap on the pairs per optical-flow chunk (0 = by workspace size only)
+    int flow_seg_rows = 0;       // "flow_seg_rows": rows per block of the Farneback iteration kernels, 0 = by the level's geometry (tests: the segmentation
+                                 // restarts the running column sums - the flow must not depend on it)
     int flow_pyramid_fused = 1;  // "flow_pyramid_fused": 1 = the four pyramid-level inputs of a frame in one pass over its bytes (pyramid_fused; frames whose
                                  // height and width are multiples of 8), 0 = gray plane + per-level blur / resize kernels (any size) - same bits
     int flow_fused = 1;      // "flow_fused": 1 = one kernel per Farneback iteration (flow_iteration: M never leaves the chip); 0 = update_matrices_k +

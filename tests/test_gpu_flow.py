@@ -161,3 +161,18 @@ def test_fused_pyramid_equals_the_per_level_kernels_bit_for_bit(h, w, t):
     assert bool(torch.isfinite(flow1).all())
     assert torch.equal(flow1, flow0), (float((flow1 - flow0).abs().max()), float((flow1 != flow0).float().mean()))
     assert torch.equal(img1, img0)
+
+
+def test_flow_does_not_depend_on_the_row_segmentation():
+    """A block of the iteration kernels restarts the running column sums (double) at its first row; those sums are exact for these
+    magnitudes, so where the segments start must not change a bit of the flow."""
+    frames = torch.from_numpy(np.stack([np.stack(_smooth_pair(540, 960, 90))])).cuda()
+    eng = engine()
+    ref, _ = eng.optical_flow(frames, want_flow=True, want_image=False)
+    try:
+        for seg in (30, 45, 135, 270):
+            eng.set_option("flow_seg_rows", seg)
+            got, _ = eng.optical_flow(frames, want_flow=True, want_image=False)
+            assert torch.equal(got, ref), seg
+    finally:
+        eng.set_option("flow_seg_rows", 0)
