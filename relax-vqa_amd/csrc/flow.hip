@@ -269,7 +269,7 @@ constexpr int PYR_G = 256 + 2 * PYR_HALO;     // gray values per row and band
 __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ next, int64_t pair_stride,
                                                      int H, int W, float* __restrict__ I0, float* __restrict__ I1, float* __restrict__ I2,
                                                      float* __restrict__ I3, int seg, const PyramidTaps tp) {
-    __shared__ float g[2][PYR_G];
+    __shared__ __attribute__((aligned(16))) float g[2][PYR_G];
     __shared__ float ring2[16][128];
     __shared__ float ring3[32][64];
     const int x = threadIdx.x;
@@ -310,16 +310,16 @@ __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__
     for (int y = y0 - 6; y <= y1 + 6; ++y) {
         const int par = y & 1;
         if (loader && y <= y1 + 5) {                       // A: the gray values of row y, then the request for row y + 1
-            float* gq = &g[par][4 * x];
+            f32x4 gv;                                      // one 16-byte store (four scalar stores at a 16-byte lane stride conflict 4 ways)
             if (fast) {
-                gq[0] = PYR_GRAY(w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255);     // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
-                gq[1] = PYR_GRAY(w0 >> 24, w1 & 255, (w1 >> 8) & 255);
-                gq[2] = PYR_GRAY((w1 >> 16) & 255, w1 >> 24, w2 & 255);
-                gq[3] = PYR_GRAY((w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24);
+                gv.x = PYR_GRAY(w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255);     // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+                gv.y = PYR_GRAY(w0 >> 24, w1 & 255, (w1 >> 8) & 255);
+                gv.z = PYR_GRAY((w1 >> 16) & 255, w1 >> 24, w2 & 255);
+                gv.w = PYR_GRAY((w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24);
             } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) gq[i] = slow[i];
+                gv = (f32x4){slow[0], slow[1], slow[2], slow[3]};
             }
+            *reinterpret_cast<f32x4*>(&g[par][4 * x]) = gv;
             if (y < y1 + 5) request_row(y + 1);
         }
         RELAX_LDS_BARRIER();
