@@ -421,7 +421,14 @@ class RelaxEngine:
         fp32 rounding; bit for bit only with set_option("gemm_split_k", 0) (see clip_vectors).
         whole_frames: optional list of uint8 [Ts,H,W,3] per clip - ALL sampled frames (src/demo_test.py:76-87 averages the
         whole-frame features over every sampled frame, including a last one that has no `next` partner and therefore no
-        pair); default: the first frame of every pair."""
+        pair); default: the first frame of every pair.
+        = full_features(full_prepare(...)): the two halves can run on different streams (full_prepare is byte / HBM work -
+        fragments, Farneback flow, resizes -, full_features the contractions), see FullPipeline."""
+        return self.full_features(self.full_prepare(clips, flow=flow, flow_images=flow_images, whole_frames=whole_frames))
+
+    def full_prepare(self, clips, flow=True, flow_images=None, whole_frames=None):
+        """The input half of full_clip_vectors: fragments (difference + flow, merged), whole-frame resizes -> the two backbone
+        input batches.  Everything is enqueued on the current stream."""
         counts = [int(c.shape[0]) for c in clips]
         wf = [c[:, 0] for c in clips] if whole_frames is None else list(whole_frames)
         wcounts = [int(w.shape[0]) for w in wf]
@@ -446,10 +453,16 @@ class RelaxEngine:
         # the fragments are the same for both backbones
         self._check(self.lib.relax_copy_bytes(self.h, _ptr(vit_in), _ptr(rn_in), n * frag_bytes, _stream()), "relax_copy_bytes")
         self._check(self.lib.relax_copy_bytes(self.h, _ptr(vit_in[n:]), _ptr(rn_in[n + nw:]), n * frag_bytes, _stream()), "relax_copy_bytes")
+        return dict(rn_in=rn_in, vit_in=vit_in, counts=counts, wcounts=wcounts, n=n, nw=nw)
+
+    def full_features(self, prep):
+        """The backbone half of full_clip_vectors: prep from full_prepare (of this or another engine on the same device) ->
+        fp32 [clips, 35203]."""
+        rn_in, vit_in, counts, wcounts, n, nw = (prep[k] for k in ("rn_in", "vit_in", "counts", "wcounts", "n", "nw"))
         ls, pool = self.resnet50_clip_features(rn_in, n + nw)
         _, vp = self.vit_features(vit_in, tokens=False, pooled=True)
         d = self.vit_dim
-        out = torch.empty((len(clips), LAYER_STACK_DIM + 3 * d + LAYER_STACK_DIM + RN50_POOL_DIM + 6 * d), dtype=torch.float32,
+        out = torch.empty((len(counts), LAYER_STACK_DIM + 3 * d + LAYER_STACK_DIM + RN50_POOL_DIM + 6 * d), dtype=torch.float32,
                           device=self.device)
         c0 = LAYER_STACK_DIM + 3 * d
         self._segment_means(out, [(ls, n, 0), (vp, 2 * n, LAYER_STACK_DIM)], wcounts)

@@ -3,5 +3,5 @@
 : "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04
-RELAX_DEBUG_POISON=1 python -m pytest tests -m gpu -q -x 2>&1 | tail -3 | tee gpurun_out/r04/poison_ws.txt
-RELAX_TEST_POISON_OUT=1 python -m pytest tests -m gpu -q -x 2>&1 | tail -3 | tee gpurun_out/r04/poison_out.txt
+RELAX_DEBUG_POISON=1 python -m pytest tests -m gpu -q -x > /tmp/poison_ws.log 2>&1; echo "RELAX_DEBUG_POISON=1 rc=$? $(grep -E ' passed| failed| error' /tmp/poison_ws.log | tail -1)" | tee gpurun_out/r04/poison_ws.txt
+RELAX_TEST_POISON_OUT=1 python -m pytest tests -m gpu -q -x > /tmp/poison_out.log 2>&1; echo "RELAX_TEST_POISON_OUT=1 rc=$? $(grep -E ' passed| failed| error' /tmp/poison_out.log | tail -1)" | tee gpurun_out/r04/poison_out.txt
