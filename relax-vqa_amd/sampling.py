@@ -5,6 +5,8 @@ decodes the video (or already holds the frames) and these helpers reproduce whic
   frame_interval          src/main_fragment_layerstack.py:274-277   (2 samples per second)
   sampled_frame_indices   src/video_frames_extract.py:12-20 (not(mod(n,k))), :61-66 (not(mod(n-1,k))), pairing by sorted
                           index with zip truncation src/main_fragment_layerstack.py:283-293
+  frame_pair_paths / load_clip_from_frames   src/main_fragment_layerstack.py:283-296: the sampled frames the reference's ffmpeg step left on disk
+                          (`{video}_{n}.png`, `{video}_{n}_next.png`), paired by sorted index, read as cv2.imread reads them (uint8 BGR)
   feature_file_name       src/main_fragment_layerstack.py:67-68,349-354  video_{i+1}_{network}_feature_map_original.npy
   features_matrix / save_mat  src/data_processing/extract_npy2mat.py:117-130, 79-84 (np.mean over frames; .mat key = dataset)
 """
@@ -34,6 +36,40 @@ def pair_frames(video_frames, framerate):
     if not pairs:
         return np.empty((0, 2) + tuple(video_frames.shape[1:]), dtype=video_frames.dtype)
     return np.stack([np.stack([video_frames[a], video_frames[b]]) for a, b in pairs])
+
+
+def frame_pair_paths(sampled_frame_path, video_name):
+    """-> [(frame path, next-frame path), ...] as the reference pairs them (src/main_fragment_layerstack.py:283-293):
+    `{video_name}_{n}.png` sorted by n, `{video_name}_{n}_next.png` sorted by n, zipped (the longer list is truncated)."""
+    import glob
+    base = glob.escape(os.path.join(sampled_frame_path, video_name))
+    originals = sorted((p for p in glob.glob(base + "_*.png") if "_next" not in os.path.basename(p)),
+                       key=lambda x: int(x.split("_")[-1].split(".")[0]))
+    following = sorted(glob.glob(base + "_*_next.png"), key=lambda x: int(x.split("_")[-2]))
+    return list(zip(originals, following))
+
+
+def read_frame_bgr(path):
+    """A frame file as `cv2.imread(path)` returns it (src/main_fragment_layerstack.py:295-296): uint8 [H,W,3], BGR, alpha dropped,
+    gray replicated.  Decoded with Pillow (the GIL is released while it decodes: loader threads read frames in parallel)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB"))[..., ::-1])
+
+
+def load_clip_from_frames(sampled_frame_path, video_name):
+    """The sampled frames of one video on disk -> uint8 [T,2,H,W,3] BGR, the input of relax_fragment_pairs / of
+    dataset.extract_dataset_clips (as its `clips(i)` callable: the decode then runs in the loader threads, ahead of the engine).
+    Raises if the directory holds no pair or the frames differ in size."""
+    pairs = frame_pair_paths(sampled_frame_path, video_name)
+    if not pairs:
+        raise FileNotFoundError(f"no `{video_name}_<n>.png` / `{video_name}_<n>_next.png` pair under {sampled_frame_path}")
+    frames = [(read_frame_bgr(a), read_frame_bgr(b)) for a, b in pairs]
+    shape = frames[0][0].shape
+    for (a, b), (pa, pb) in zip(frames, pairs):
+        if a.shape != shape or b.shape != shape:
+            raise ValueError(f"{pa} / {pb}: frame sizes differ inside one video ({a.shape}, {b.shape} vs {shape})")
+    return np.stack([np.stack(p) for p in frames])
 
 
 def feature_file_name(video_index, network_name, resolution=None):

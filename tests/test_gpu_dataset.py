@@ -129,6 +129,25 @@ def test_host_fed_overlapped_pass_equals_the_inline_pass_bit_for_bit():
     assert eng._clip_stager is st and torch.equal(again[ok], over[ok])
 
 
+def test_dataset_pass_from_frame_files_equals_the_pass_from_arrays(tmp_path):
+    """The reference's data flow (src/main_fragment_layerstack.py:283-296): sampled frames as PNG files on disk, read in the loader
+    threads (sampling.load_clip_from_frames = cv2.imread's BGR bytes) -> the same [n, 19779] matrix, bit for bit, as from the arrays."""
+    from PIL import Image
+    rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    arrays = [synth.synthetic_clip(t, 240, 320, clip_id=660 + i) for i, t in enumerate((2, 1, 3))]
+    for v, c in enumerate(arrays):
+        d = tmp_path / f"video{v}"
+        d.mkdir()
+        for k in range(c.shape[0]):
+            Image.fromarray(c[k, 0][..., ::-1]).save(d / f"clip_{k * 12}.png")
+            Image.fromarray(c[k, 1][..., ::-1]).save(d / f"clip_{k * 12}_next.png")
+    from_files, e1 = dataset.extract_dataset_clips(lambda i: sampling.load_clip_from_frames(str(tmp_path / f"video{i}"), "clip"), 3, eng,
+                                                   clips_per_step=2, rank=0, world=1)
+    from_arrays, e2 = dataset.extract_dataset_clips(arrays, 3, eng, clips_per_step=2, rank=0, world=1, prefetch=0)
+    assert not e1 and not e2 and torch.equal(from_files, from_arrays)
+
+
 def _bench_dataset(n_ranks, dump, extra_env=None):
     from tests.gpu_common import run_ranks
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}

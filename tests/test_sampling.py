@@ -1,5 +1,8 @@
 """Sampling semantics / file formats: pure host logic."""
+import os
+
 import numpy as np
+import pytest
 import scipy.io
 
 import relax_vqa_amd  # noqa: F401
@@ -32,3 +35,65 @@ def test_file_names_and_mat_roundtrip(tmp_path):
     assert mat.shape == (2, 7) and np.allclose(mat[1], np.load(paths[1]).mean(axis=0))
     out = sampling.save_mat(str(tmp_path / "f" / "x.mat"), "konvid_1k", mat)
     assert np.allclose(scipy.io.loadmat(out)["konvid_1k"], mat)
+
+
+def test_frame_files_are_paired_and_read_like_the_reference(tmp_path):
+    """`{video}_{n}.png` / `{video}_{n}_next.png` as the reference's ffmpeg step leaves them (src/video_frames_extract.py:51-69): paired
+    by NUMERIC index (10 after 2), the list without a partner truncated (src/main_fragment_layerstack.py:283-293), read as cv2.imread
+    reads them - BGR, gray frames replicated, alpha dropped."""
+    from PIL import Image
+    from relax_vqa_amd import sampling
+    g = np.random.default_rng(3)
+    d = tmp_path / "frames"
+    d.mkdir()
+    rgb = {n: g.integers(0, 256, (24, 40, 3), dtype=np.uint8) for n in (1, 2, 10, 11)}
+    nxt = {n: g.integers(0, 256, (24, 40, 3), dtype=np.uint8) for n in (1, 2, 10)}       # frame 11 has no `next`
+    for n, a in rgb.items():
+        Image.fromarray(a).save(d / f"my_video_{n}.png")
+    for n, a in nxt.items():
+        Image.fromarray(a).save(d / f"my_video_{n}_next.png")
+    Image.fromarray(rgb[1]).save(d / "other_video_1.png")                                  # another video in the same directory
+    pairs = sampling.frame_pair_paths(str(d), "my_video")
+    assert [os.path.basename(a) for a, _ in pairs] == ["my_video_1.png", "my_video_2.png", "my_video_10.png"]
+    assert [os.path.basename(b) for _, b in pairs] == ["my_video_1_next.png", "my_video_2_next.png", "my_video_10_next.png"]
+    clip = sampling.load_clip_from_frames(str(d), "my_video")
+    assert clip.shape == (3, 2, 24, 40, 3) and clip.dtype == np.uint8
+    for t, n in enumerate((1, 2, 10)):
+        assert np.array_equal(clip[t, 0], rgb[n][..., ::-1]) and np.array_equal(clip[t, 1], nxt[n][..., ::-1])
+    # gray and RGBA files come out as 3-channel BGR
+    Image.fromarray(rgb[1][..., 0]).save(d / "gray_1.png")
+    Image.fromarray(np.dstack([rgb[2], np.full((24, 40), 7, np.uint8)])).save(d / "gray_1_next.png")
+    c2 = sampling.load_clip_from_frames(str(d), "gray")
+    assert np.array_equal(c2[0, 0], np.repeat(rgb[1][..., :1], 3, axis=2)) and np.array_equal(c2[0, 1], rgb[2][..., ::-1])
+    with pytest.raises(FileNotFoundError):
+        sampling.load_clip_from_frames(str(d), "missing_video")
+
+
+def test_dataset_pass_from_frame_directories(tmp_path):
+    """The reference's data flow end to end on the host side: frame files on disk -> loader threads decode them -> batches (a stand-in
+    engine here); an undecodable video costs its own row."""
+    import torch
+    from PIL import Image
+    from relax_vqa_amd import dataset, sampling
+    from tests.test_dataset_cpu import F, FakeEngine
+    dataset.feature_dim = lambda engine, resnet=True, vit=True, full=False: F
+    g = np.random.default_rng(5)
+    clips = []
+    for v in range(4):
+        t = 1 + v % 3
+        c = g.integers(0, 255, (t, 2, 32, 48, 3), dtype=np.uint8)
+        clips.append(c)
+        d = tmp_path / f"v{v}"
+        d.mkdir()
+        if v == 2:
+            (d / "vid_1.png").write_bytes(b"not a png")
+            (d / "vid_1_next.png").write_bytes(b"not a png")
+            continue
+        for k in range(t):
+            Image.fromarray(c[k, 0][..., ::-1]).save(d / f"vid_{k * 15}.png")
+            Image.fromarray(c[k, 1][..., ::-1]).save(d / f"vid_{k * 15}_next.png")
+    matrix, errors = dataset.extract_dataset_clips(lambda i: sampling.load_clip_from_frames(str(tmp_path / f"v{i}"), "vid"), 4, FakeEngine(),
+                                                   clips_per_step=2, rank=0, world=1, workers=3)
+    assert [i for i, _ in errors] == [2] and bool(torch.isnan(matrix[2]).all())
+    for v in (0, 1, 3):
+        assert np.array_equal(matrix[v].numpy(), FakeEngine._rows(clips[v]).mean(dim=0).numpy())

@@ -40,7 +40,7 @@ for k in sorted(tm, key=lambda k: -tm[k]):
     us = tm[k] / d / 1e3
     s = sq[k]; wc = max(s["SQ_WAVE_CYCLES"], 1)
     hit = tc[k]["TCC_HIT_sum"] / max(tc[k]["TCC_HIT_sum"] + tc[k]["TCC_MISS_sum"], 1)
-    print("%-34s %5d %9.1f %10.1f %9.2f %7.2f %7.2f %7.2f %7.2f %7.3f" % (k[:34], d, us, mb, mb / us / 1e0 / 1e6 * 1e6 / 1e6, hit, s["SQ_ACTIVE_INST_ANY"] / wc, s["SQ_WAIT_INST_ANY"] / wc, s["SQ_WAIT_ANY"] / wc, s["SQ_LDS_BANK_CONFLICT"] / max(s["SQ_BUSY_CYCLES"], 1)))
+    print("%-34s %5d %9.1f %10.1f %9.2f %7.2f %7.2f %7.2f %7.2f %7.3f" % (k[:34], d, us, mb, mb / us, hit, s["SQ_ACTIVE_INST_ANY"] / wc, s["SQ_WAIT_INST_ANY"] / wc, s["SQ_WAIT_ANY"] / wc, s["SQ_LDS_BANK_CONFLICT"] / max(s["SQ_BUSY_CYCLES"], 1)))
     if sq2[k]:
         print("    extra:", {kk: round(v / d) for kk, v in sq2[k].items()})
 PY
