@@ -111,7 +111,7 @@ def _cpu_model():
 
 def hbm_traffic_per_launch(workload, clips_per_step, precision):
     """PMC-measured HBM bytes per contraction launch, if a committed profile exists for this exact workload and precision."""
-    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -442,7 +442,7 @@ def main():
 
     traffic, traffic_note = hbm_traffic_per_launch(args.workload, B, precision), (
         "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (own passes, FETCH doubled per the gfx950 guide), from the "
-        "committed profile of this workload, batch and precision: profiles/r03_hbm_traffic.json (null when none matches the run)")
+        "committed profile of this workload, batch and precision: profiles/r04_hbm_traffic.json (null when none matches the run)")
     flow_traffic = None
     if world == 1 and not args.no_measure_traffic and x6:
         torch.cuda.synchronize()
