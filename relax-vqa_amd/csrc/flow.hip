@@ -5,12 +5,16 @@
 //   src/main_fragment_layerstack.py:162-175  flow_to_rgb (cartToPolar, NORM_MINMAX, hue = ang*180/pi/2, HSV -> BGR)
 // The algorithm is OpenCV's (opencv-python 4.9, modules/video/src/optflowgf.cpp), restated - not ported from source,
 // which is not available here - and pinned by tolerance to the reference's example flow PNGs (oracle/flow_ref.py).
-// All stages are HBM-bound streaming kernels, batched over the pairs of a clip (one launch per stage per pyramid
-// level for ALL pairs, so the coarse levels still fill the chip):
-//   gray (fixed-point BGR2GRAY) -> per level: Gaussian blur of the full-resolution frame (3/3/9/19 taps, reflect-101)
-//   -> linear resize -> polynomial expansion (one kernel) -> matrix update -> 3 x (15x15 box blur in double + 2x2 solve,
-//   one kernel [-> matrix update]) -> x2 linear upsampling of the flow into the next finer level.
-// Then: magnitude min/max reduction, fastAtan2, normalisation, 8-bit HSV -> BGR (float formula, truncated).
+// All stages are streaming kernels, batched over the pairs of a clip (one launch per stage and pyramid level for ALL pairs, so the
+// coarse levels still fill the chip):
+//   pyramid_fused: the uint8 frames -> gray (fixed-point BGR2GRAY) -> the four level inputs (Gaussian blur of the full-resolution frame,
+//   3 / 3 / 9 / 19 taps, reflect-101, then the linear resize) in ONE pass over the frame's bytes   [sides not multiples of 8: flow_gray +
+//   gauss3_v4 / gauss_pass / gauss_h_sampled / gauss_v_sampled_resize / resize_linear_f32 per level]
+//   per level, coarsest first: poly_expansion (both passes of the polynomial expansion) -> 3 x flow_iteration (matrix update + 15x15 box
+//   blur in double + 2x2 solve in one kernel; the first one takes the x2 linear upsampling of the coarser level's flow on the fly, the
+//   last one of the finest level the magnitude range)   [flow_fused = 0: update_matrices_k + box_solve_fused, the matrix plane through HBM]
+//   flow_visualise: fastAtan2, normalisation, 8-bit HSV -> BGR (float formula, truncated).
+// DESIGN.md section 3.3 has the measurements and what was tried and not kept.
 #include <cfloat>
 #include <cmath>
 
