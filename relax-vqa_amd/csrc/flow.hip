@@ -1312,6 +1312,8 @@ static int launch_flow_iteration(relax_handle* h, const float* R, const float* f
 static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next, int64_t pair_stride, int P, int H, int W,
                       float* flow_out, uint8_t* bgr_out, hipStream_t s) {
     const int64_t HW = (int64_t)H * W;
+    // the matrix kernels address a pair's two coefficient images through ONE buffer resource with 32-bit byte offsets
+    RELAX_REQUIRE(h, HW * 40 < (int64_t)0x7fffffff, "optical flow: frames of %d x %d exceed the 2 GB a buffer resource addresses (40 bytes per pixel)", W, H);
     // workspace carve (floats unless noted), all sized for level 0
     const size_t per_pair = (size_t)HW * (2 + 2 + 2 + 2 + 10 + 5 + 2 + 2) * sizeof(float) + 16;
     RELAX_TRY(ensure_buf(h, h->flow_ws, per_pair * P));
