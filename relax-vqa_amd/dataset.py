@@ -69,6 +69,7 @@ class ClipStager:
         self.on_gpu = device.type == "cuda"
         self._lock = threading.Lock()
         self._pinned_free = {}                       # nbytes -> [pinned flat uint8 tensors]
+        self._pooled_bytes = 0
         self.bytes_copied = 0
         if self.on_gpu:
             self.copy_stream = torch.cuda.Stream(device=device)
@@ -87,16 +88,21 @@ class ClipStager:
         with self._lock:
             free = self._pinned_free.get(n)
             buf = free.pop() if free else None
+            if buf is not None:
+                self._pooled_bytes -= n
         if buf is None:
             buf = torch.empty(n, dtype=torch.uint8, pin_memory=True)
         buf.copy_(t.reshape(-1))                     # releases the GIL: the loader threads copy in parallel
         return buf.view(t.shape), buf
 
+    POOL_LIMIT_BYTES = 32 << 30      # pinned staging kept for reuse (a dataset of many distinct clip sizes must not pin the host's memory)
+
     def give_back(self, bufs):
         with self._lock:
             for b in bufs:
-                if b is not None:
+                if b is not None and self._pooled_bytes + b.numel() <= self.POOL_LIMIT_BYTES:
                     self._pinned_free.setdefault(b.numel(), []).append(b)
+                    self._pooled_bytes += b.numel()
 
     # ---- driver-thread side --------------------------------------------------------------------------------
     def upload(self, clips):
