@@ -844,6 +844,27 @@ __global__ __launch_bounds__(256) void box_solve_fused(const float* __restrict__
 // The ring starts as zeros and the first 5 steps (15 rows) fill it - `s += row - 0` - so the loop has no special first window:
 // entering rows y0 - 8 + 3t + r (the very first, y0 - 8, lies outside the window of y0 and enters as zeros).  Same additions in the
 // same order as box_solve_fused, same matrix entries as update_matrices_k (shared source above): the flow is bit-identical.
+#ifdef RELAX_FLOW_STAMPS   // diagnostic build (tools/build_ablations.sh flowstamps): ticks per phase of a step, one producer and one box wave of one block per launch
+__device__ unsigned long long g_flow_stamps[16];
+#define IT_STAMP_DECL unsigned long long st_t_ = __builtin_amdgcn_s_memtime(), st_[6] = {0, 0, 0, 0, 0, 0}
+#define IT_STAMP(i_)                                                         \
+    {                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime();          \
+        st_[i_] += n_ - st_t_;                                               \
+        st_t_ = n_;                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    }
+#define IT_STAMP_WAIT_LOADS   /* everything this step consumes has landed: the wait as one number (the product waits row by row) */ \
+    {                                                                        \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
+        IT_STAMP(5);                                                         \
+    }
+#else
+#define IT_STAMP_DECL
+#define IT_STAMP(i_)
+#define IT_STAMP_WAIT_LOADS
+#endif
 constexpr int IT_ROWS = 3;
 constexpr int IT_OUT = FUSE_OUT;                 // 240 output columns per band
 constexpr int IT_STRIPS = IT_OUT / 4;
@@ -912,6 +933,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
         // one step: FUC_ / FXC_ / FYC_ = the flow set of step t_ + 1 (consumed), FUN_ / .. = that of step t_ + 2 (requested)
 #define IT_STEP(t_, FUC_, FXC_, FYC_, FUN_, FXN_, FYN_, OPS_, FLOW_)                                         \
     do {                                                                                                     \
+        IT_STAMP_WAIT_LOADS;                                                                                 \
         if constexpr (UP) {   /* the coarse flow is small and mostly in L2: ONE set, requested at the top of the step that consumes it \
                                  (with two sets in flight this instantiation needed 267 registers and spilled) */                     \
             if (OPS_) { _Pragma("unroll") for (int r = 0; r < IT_ROWS; ++r) flow_up_request(fu0[r], up, fin, xc, IT_ROW((t_) + 1, r)); } \
@@ -931,7 +953,9 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
                 if (FLOW_) IT_REQUEST_FLOW((t_) + 2, r, FUN_, FXN_, FYN_);                                   \
             }                                                                                                \
         }                                                                                                    \
+        IT_STAMP(0);   /* entries + requests (includes the waits for the operands) */                         \
         RELAX_LDS_BARRIER();                                                                                 \
+        IT_STAMP(1);   /* barrier */                                                                          \
     } while (0)
 #define IT_STEP_EVEN(t_, OPS_, FLOW_) IT_STEP(t_, fu1, f1x, f1y, fu0, f0x, f0y, OPS_, FLOW_)
 #define IT_STEP_ODD(t_, OPS_, FLOW_) IT_STEP(t_, fu0, f0x, f0y, fu1, f1x, f1y, OPS_, FLOW_)
@@ -943,6 +967,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
         }
 #pragma unroll
         for (int r = 0; r < IT_ROWS; ++r) IT_REQUEST_OPERANDS(0, r, fu0, f0x, f0y);
+        IT_STAMP_DECL;
         int t = 0;
         for (; t + 3 < Q; t += 2) {                            // steps t and t + 1 both request operands (t + 2 < Q) and flow (t + 3 < Q)
             IT_STEP_EVEN(t, true, true);
@@ -954,6 +979,14 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
             else IT_STEP_EVEN(t, ops, flo);
         }
         RELAX_LDS_BARRIER();                                   // the barrier of step Q (the box waves' last column sums)
+#ifdef RELAX_FLOW_STAMPS
+        if (threadIdx.x == 256 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && (g_flow_stamps[15] == 0 || g_flow_stamps[15] == (unsigned long long)w)) {
+            atomicAdd(&g_flow_stamps[0], st_[0]);
+            atomicAdd(&g_flow_stamps[1], st_[1]);
+            atomicAdd(&g_flow_stamps[3], st_[5]);
+            atomicAdd(&g_flow_stamps[2], (unsigned long long)Q);
+        }
+#endif
 #undef IT_STEP_EVEN
 #undef IT_STEP_ODD
 #undef IT_STEP
@@ -977,11 +1010,13 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < WINSIZE; ++k) ring[c][k] = 0.f;
     }
+    IT_STAMP_DECL;
     for (int tb = 0; tb <= Q + 1; tb += IT_FILL) {
 #pragma unroll
         for (int j = 0; j < IT_FILL; ++j) {
             const int t = tb + j;                             // this step: V(t - 1), then H(t - 2)
             if (t <= Q + 1) {                                 // uniform over the block
+                IT_STAMP(5);
                 if (t >= 1 && t <= Q && !(RELAX_FLOW_ABLATE & 8)) {
                     const int par = (t - 1) & 1;
 #pragma unroll
@@ -996,6 +1031,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
                         }
                     }
                 }
+                IT_STAMP(2);   // column sums
                 if (t >= IT_FILL + 2) {                       // (t <= Q + 1 holds)
                     const int q = t - 2, par = q & 1;
                     const int y = y0 + IT_ROWS * (q - IT_FILL) + sr;
@@ -1050,10 +1086,20 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
                         }
                     }
                 }
+                IT_STAMP(3);   // strips: window slide + solve + stores
                 if (t <= Q) RELAX_LDS_BARRIER();
+                IT_STAMP(4);   // barrier
             }
         }
     }
+#ifdef RELAX_FLOW_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && (g_flow_stamps[15] == 0 || g_flow_stamps[15] == (unsigned long long)w)) {
+        atomicAdd(&g_flow_stamps[4], st_[2]);
+        atomicAdd(&g_flow_stamps[5], st_[3]);
+        atomicAdd(&g_flow_stamps[6], st_[4]);
+        atomicAdd(&g_flow_stamps[7], (unsigned long long)(Q + 2));
+    }
+#endif
     if constexpr (MINMAX) {   // wave minimum / maximum, one atomic pair per wave
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
@@ -1529,6 +1575,18 @@ int relax_optical_flow(relax_handle* h, const uint8_t* orig, const uint8_t* next
     return RELAX_OK;
 }
 
+
+#ifdef RELAX_FLOW_STAMPS
+int relax_debug_flow_stamps(unsigned long long* out16, int reset, int only_width) {   // diagnostic builds only (tools/flow_stamps.py)
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(relax::g_flow_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        z[15] = (unsigned long long)only_width;   // 0: launches of every level
+        if (hipMemcpyToSymbol(HIP_SYMBOL(relax::g_flow_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 int relax_flow_to_rgb(relax_handle* h, const float* flow, int T, int H, int W, uint8_t* flow_bgr, relax_stream stream) {
     if (!h) return RELAX_ERR_INVALID;

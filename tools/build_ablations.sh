@@ -7,6 +7,7 @@
 #   (the bf16x6 loop ablations of round 2 - RELAX_X6_ABLATE - were deleted from gemm_x6.hip in round 3 together with the other
 #    experiment branches; their measurements are in DESIGN.md section 3.2 and the code is in the history: commit a51794b)
 #   tools/build_ablations.sh att_stamps     fp32 attention kernel with per-phase cycle shares
+#   tools/build_ablations.sh flowstamps     fused Farneback iteration with tick stamps per phase of a step (tools/flow_stamps.py prints them)
 #   tools/build_ablations.sh flow:<mask>    fused Farneback iteration without parts of its work (-DRELAX_FLOW_ABLATE=mask, WRONG results, timing only)
 #   tools/build_ablations.sh a6stamps       bf16x6 attention kernel with ticks per phase of an item (tools/attn_stamps.py prints them)
 # use: RELAX_HIP_LIB=tools/abl/librelax_<name>.so python tools/gemm_bench.py ...
@@ -26,6 +27,7 @@ for n in "$@"; do
     x6stamps) $CC -DRELAX_X6_STAMPS -c gemm_x6.hip -o /tmp/gemm_x6_stamps.o; link gemm_x6.o /tmp/gemm_x6_stamps.o x6stamps ;;
     f32:*) $CC -DRELAX_F32_ABLATE=${n#f32:} -c gemm.hip -o /tmp/gemm_f32abl.o; link gemm.o /tmp/gemm_f32abl.o f32abl${n#f32:} ;;
     att_stamps) $CC -DRELAX_ATT_STAMPS=0 -c layers.hip -o /tmp/layers_stamps.o; link layers.o /tmp/layers_stamps.o att_stamps ;;
+    flowstamps) $FLOWCC -DRELAX_FLOW_STAMPS -c flow.hip -o /tmp/flow_stamps.o; link flow.o /tmp/flow_stamps.o flowstamps ;;
     flow:*) $FLOWCC -DRELAX_FLOW_ABLATE=${n#flow:} -c flow.hip -o /tmp/flow_abl${n#flow:}.o; link flow.o /tmp/flow_abl${n#flow:}.o flowabl${n#flow:} ;;
     a6stamps) $CC -DRELAX_A6_STAMPS -c attention_x6.hip -o /tmp/attention_x6_stamps.o; link attention_x6.o /tmp/attention_x6_stamps.o a6stamps ;;
     *) $CC -DRELAX_X3_ABLATE=$n -c gemm.hip -o /tmp/gemm_abl$n.o; link gemm.o /tmp/gemm_abl$n.o abl$n ;;
