@@ -423,7 +423,8 @@ constexpr int POLY_RING = 2 * POLY_N + 1;    // 11
 constexpr int POLY_SLOTS = 16;               // the window + 5 rows in flight
 __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ I, float* __restrict__ R, int h, int w, int seg,
                                                       PolyConsts pc) {
-    __shared__ float lt[2][3][256];
+    __shared__ f32x4 lt[2][256];                           // (t0, t1, t2, -) of a column side by side: one 16-byte read per neighbour
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x;
     const int x = blockIdx.x * POLY_OUT - POLY_N + tid;     // grid (w / 246, h / seg, images)
     const int xc = clampi(x, 0, w - 1);
@@ -437,6 +438,29 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
     float ring[POLY_SLOTS];
 #pragma unroll
     for (int i = 0; i < POLY_SLOTS; ++i) ring[i] = col[(int64_t)clampi(y0 - POLY_N + i, 0, h - 1) * w];
+    // The 5 coefficients of a pixel are 20 bytes: stored from the thread that computed them that is a 16- and a 4-byte store at a
+    // 20-byte lane stride, most of them misaligned.  A row's 246 x 5 floats go through LDS instead (placed so that LDS and global
+    // offsets agree mod 16 bytes) and leave one row later as aligned 16-byte stores, consecutive lanes on consecutive addresses.
+    // (What the kernel waits for is its stores either way - 323 us per launch, 106 without them, profiles/r04_poly_ablations.txt -
+    // and the band-row store pattern itself streams at 3.6 - 4.6 TB/s, tools/micro/write_bw.hip: this form is 1.3 % faster.)
+    __shared__ __attribute__((aligned(16))) float st[2][POLY_OUT * 5 + 8];
+    const int x_first = blockIdx.x * POLY_OUT;
+    const int n_row = (w - x_first < POLY_OUT ? w - x_first : POLY_OUT) * 5;      // floats of a row of this band
+    auto flush = [&](const float* sbuf, int64_t g0) {   // g0: float index in R of the band's first value of that row
+        const int lo = (int)((reinterpret_cast<uintptr_t>(R + g0) >> 2) & 3), hi = lo + n_row;
+        float* const gq = R + (g0 - lo);                 // 16-byte aligned
+        for (int f0 = 4 * tid; f0 < hi; f0 += 4 * 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sbuf + f0);
+            if (f0 >= lo && f0 + 4 <= hi) *reinterpret_cast<f32x4*>(gq + f0) = v;
+            else {
+                if (f0 + 0 >= lo && f0 + 0 < hi) gq[f0 + 0] = v.x;
+                if (f0 + 1 >= lo && f0 + 1 < hi) gq[f0 + 1] = v.y;
+                if (f0 + 2 >= lo && f0 + 2 < hi) gq[f0 + 2] = v.z;
+                if (f0 + 3 >= lo && f0 + 3 < hi) gq[f0 + 3] = v.w;
+            }
+        }
+    };
+    int64_t g_prev = -1;                                    // the row waiting in the staging buffer (none yet)
     int par = 0;
     for (int yb = y0; yb < y1; yb += POLY_SLOTS) {
 #pragma unroll
@@ -444,47 +468,56 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
             const int y = yb + j;
             if (y < y1) {                                   // uniform over the block
                 const float entering = col[(int64_t)clampi(y + POLY_N + 1 + (POLY_SLOTS - POLY_RING), 0, h - 1) * w];   // row y + 11
-                float t0 = ring[(j + POLY_N) % POLY_SLOTS] * pc.g[0], t1 = 0.f, t2 = 0.f;
+                // pairs of independent fp32 operations as 2-vectors (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two IEEE operations per
+                // instruction, the same roundings): 143 instead of 172 vector instructions per pixel
+                f32x2 t02 = {ring[(j + POLY_N) % POLY_SLOTS] * pc.g[0], 0.f};   // (t0, t2)
+                float t1 = 0.f;
 #pragma unroll
                 for (int k = 1; k <= POLY_N; ++k) {
                     const float up = ring[(j + POLY_N - k) % POLY_SLOTS];
                     const float dn = ring[(j + POLY_N + k) % POLY_SLOTS];
                     const float p = up + dn;
-                    t0 = fmaf(pc.g[k], p, t0);
+                    t02 = __builtin_elementwise_fma((f32x2){pc.g[k], pc.xxg[k]}, (f32x2){p, p}, t02);
                     t1 = fmaf(pc.xg[k], dn - up, t1);
-                    t2 = fmaf(pc.xxg[k], p, t2);
                 }
                 ring[j] = entering;                         // row y + 11 takes the slot of row y - 5
-                lt[par][0][tid] = t0;
-                lt[par][1][tid] = t1;
-                lt[par][2][tid] = t2;
+                const float t0 = t02.x, t2 = t02.y;
+                lt[par][tid] = (f32x4){t0, t1, t2, 0.f};
                 RELAX_LDS_BARRIER();
+                if (g_prev >= 0) flush(st[par ^ 1], g_prev);   // the row before this one (its values were staged before the barrier)
+                const int64_t g_row = (((int64_t)blockIdx.z * h + y) * w + x_first) * 5;
                 if (writer) {
                     double b1 = t0 * pc.g[0], b2 = 0, b3 = t1 * pc.g[0], b4 = 0, b5 = t2 * pc.g[0], b6 = 0;
 #pragma unroll
                     for (int k = 1; k <= POLY_N; ++k) {
-                        const float p0 = lt[par][0][tid + k], m0 = lt[par][0][tid - k];
-                        const float p1 = lt[par][1][tid + k], m1 = lt[par][1][tid - k];
-                        const float p2 = lt[par][2][tid + k], m2 = lt[par][2][tid - k];
-                        const double tg = p0 + m0;
+                        const f32x4 P = lt[par][tid + k], M = lt[par][tid - k];
+                        const f32x2 p01 = {P.x, P.y}, m01 = {M.x, M.y};
+                        const f32x2 s01 = p01 + m01;                               // (p0 + m0, p1 + m1)
+                        const f32x2 d01 = (p01 - m01) * (f32x2){pc.xg[k], pc.xg[k]};   // ((p0 - m0) xg, (p1 - m1) xg)
+                        const float s2 = P.z + M.z;
+                        const double tg = s01.x;
                         b1 = fma(tg, (double)pc.g[k], b1);
                         b4 = fma(tg, (double)pc.xxg[k], b4);
-                        b2 += (p0 - m0) * pc.xg[k];
-                        b3 += (p1 + m1) * pc.g[k];
-                        b6 += (p1 - m1) * pc.xg[k];
-                        b5 += (p2 + m2) * pc.g[k];
+                        b2 += d01.x;
+                        b3 += s01.y * pc.g[k];
+                        b6 += d01.y;
+                        b5 += s2 * pc.g[k];
                     }
-                    const int64_t hw = (int64_t)h * w;
-                    float* o = R + ((int64_t)blockIdx.z * hw + (int64_t)y * w + x) * 5;
+                    float* o = st[par] + (int)((reinterpret_cast<uintptr_t>(R + g_row) >> 2) & 3) + (tid - POLY_N) * 5;   // lane stride 5 words: no bank conflict
                     o[1] = (float)(b2 * pc.ig11);
                     o[0] = (float)(b3 * pc.ig11);
                     o[3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
                     o[2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
                     o[4] = (float)(b6 * pc.ig55);
                 }
-                par ^= 1;   // the next row writes the other buffer: its barrier orders these reads before the buffer's reuse
+                g_prev = g_row;
+                par ^= 1;   // the next row writes the other buffers: its barrier orders these reads / writes before their reuse
             }
         }
+    }
+    if (g_prev >= 0) {                                      // the last row of the segment
+        RELAX_LDS_BARRIER();
+        flush(st[par ^ 1], g_prev);
     }
 }
 
