@@ -18,16 +18,17 @@ __global__ __launch_bounds__(256) void k_copy(const f32x4* a, f32x4* b, size_t n
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
 }
 // read r16 + write w16 16-byte units per thread and row: bands of 256 threads walking down `rows` rows of an image `pitch16` units wide
-__global__ __launch_bounds__(256) void k_rows(const f32x4* in, f32x4* out, int rows, int in_pitch16, int out_pitch16, int w16) {
+__global__ __launch_bounds__(256) void k_rows(const f32x4* in, f32x4* out, int rows, int in_pitch16, int out_pitch16, int w16, int band_stride16 = 0, int n16 = 0) {
     const int band = blockIdx.x, seg = blockIdx.y;
     const size_t img = blockIdx.z;
     const f32x4* src = in + img * (size_t)in_pitch16 * rows * gridDim.y + (size_t)seg * rows * in_pitch16 + band * 64;
-    f32x4* dst = out + img * (size_t)out_pitch16 * rows * gridDim.y + (size_t)seg * rows * out_pitch16 + band * 64 * w16;
+    f32x4* dst = out + img * (size_t)out_pitch16 * rows * gridDim.y + (size_t)seg * rows * out_pitch16 + band * (band_stride16 ? band_stride16 : 64 * w16);
+    const int nq = n16 ? n16 : 64 * w16;
     for (int y = 0; y < rows; ++y) {
         f32x4 v = {0, 0, 0, 0};
         if (threadIdx.x < 64) v = src[(size_t)y * in_pitch16 + threadIdx.x];
         v.x += __shfl(v.y, (threadIdx.x + 1) & 63);
-        for (int q = threadIdx.x; q < 64 * w16; q += 256) dst[(size_t)y * out_pitch16 + q] = v;
+        for (int q = threadIdx.x; q < nq; q += 256) dst[(size_t)y * out_pitch16 + q] = v;
     }
 }
 
@@ -93,6 +94,22 @@ int main() {
         time("rows: 1 KB in + 5 KB out per band row", moved, [&] { hipLaunchKernelGGL(k_rows, dim3(16, segs, imgs), dim3(256), 0, 0, a, b, rows, W16in, W16out, 5); });
         const double moved1 = (double)imgs * segs * rows * (W16in + W16in) * 16.0;
         time("rows: 1 KB in + 1 KB out per band row", moved1, [&] { hipLaunchKernelGGL(k_rows, dim3(16, segs, imgs), dim3(256), 0, 0, a, b, rows, W16in, W16in, 1); });
+    }
+    // the same bytes written as wider chunks per block row (the pitch stays one 2160p coefficient row, 76.8 KB): does the rate depend on the chunk?
+    for (int bands : {16, 8, 4, 2, 1}) {
+        const int pitch16 = 4800, w16 = 4800 / bands / 64 * 64 / 64, rows = 60, segs = 36, imgs = 16;   // w16 units per thread-of-64 and row
+        const double moved = (double)imgs * segs * rows * bands * (64.0 * w16 + 64) * 16.0;
+        char name[96];
+        snprintf(name, sizeof(name), "rows: %d bands, %.1f KB out per band row", bands, 64.0 * w16 * 16 / 1024);
+        time(name, moved, [&] { hipLaunchKernelGGL(k_rows, dim3(bands, segs, imgs), dim3(256), 0, 0, a, b, rows, 1024, pitch16, w16); });
+    }
+    // where a band's chunk starts: poly_expansion's 246-pixel bands are 4920 bytes wide (start 56 b mod 128); 224 pixels = 4480 bytes = 35 lines
+    for (int n16 : {308, 320, 280}) {
+        const int pitch16 = 4800, rows = 60, segs = 36, imgs = 16, bands = 4800 / n16;
+        const double moved = (double)imgs * segs * rows * bands * (n16 + 64.0) * 16.0;
+        char name[96];
+        snprintf(name, sizeof(name), "rows: bands of %d x 16 B (start %d mod 128)", n16, n16 * 16 % 128);
+        time(name, moved, [&] { hipLaunchKernelGGL(k_rows, dim3(bands, segs, imgs), dim3(256), 0, 0, a, b, rows, 1024, pitch16, 5, n16, n16); });
     }
     {   // 2160p level 0: 16 bands x 36 segments of 60 rows x 16 images
         const int w = 3840, rows = 60, segs = 36, imgs = 16;
