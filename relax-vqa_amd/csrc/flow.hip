@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__
 //   * the three vertical results go through LDS (double-buffered: one barrier per row), and the horizontal 11-tap part (double
 //     accumulators, as OpenCV) reads its neighbours there.
 // The intermediate [h][w][3] plane never goes to HBM: 4 + 20 bytes per pixel.
-constexpr int POLY_OUT = 256 - 2 * POLY_N;   // 246
+constexpr int POLY_OUT = 256 - 2 * POLY_N;   // 246 (224-pixel bands, whose rows start on 128-byte lines, measured the same: profiles/r04_write_bw.txt has the pattern alone)
 constexpr int POLY_RING = 2 * POLY_N + 1;    // 11
 constexpr int POLY_SLOTS = 16;               // the window + 5 rows in flight
 __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ I, float* __restrict__ R, int h, int w, int seg,
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
     const int y0 = blockIdx.y * seg;
     const int y1 = y0 + seg < h ? y0 + seg : h;
     const float* col = I + (int64_t)blockIdx.z * ((int64_t)w * h) + xc;
-    const bool writer = tid >= POLY_N && tid < 256 - POLY_N && x < w;
+    const bool writer = tid >= POLY_N && tid < POLY_N + POLY_OUT && x < w;
     // at the row y = y0 + s: slot (s + i) % 16 holds row y - 5 + i (clamped): i = 0 .. 10 the window, i = 11 .. 15 rows already
     // requested (with one row requested per step a thread had ONE 4-byte load in flight and the kernel waited on the read latency:
     // 3.3 TB/s; five rows ahead the reads are no longer what it waits for)
