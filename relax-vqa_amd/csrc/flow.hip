@@ -407,9 +407,9 @@ __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__
 #undef PYR_GRAY
 }
 
-// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R [B][h][w][5] (a pixel's five coefficients side by side: the
-// iteration kernel then reads ONE sequential stream per frame; with five planes [5][h][w] - coalesced dword rows - a 2160p pair took
-// 0.73 instead of 0.68 ms: sixteen streams per block cost more in DRAM pages than the strided lanes cost in the load unit).  A block owns a band of 246 output columns (256 threads = 246 + the 5-column halo on each side, replicated border)
+// FarnebackPolyExp, both passes in one kernel: I [B][h][w] -> R, per pair [2][h][w][4] + [2][h][w] (c0..c3 of a pixel as one 16-byte
+// unit, c4 in a plane of its own: two sequential streams per frame, every access a whole aligned unit.  History: five planes [5][h][w] -
+// coalesced dword rows, sixteen streams per block - took 0.73 ms per 2160p pair, the five coefficients side by side [h][w][5] 0.68).  A block owns a band of 246 output columns (256 threads = 246 + the 5-column halo on each side, replicated border)
 // and a segment of rows, and walks down the rows:
 //   * vertical 11-tap filters (float, as OpenCV), one COLUMN per thread: the 11 rows of the window live in a register ring of 16
 //     slots (static indices: the row loop is unrolled over the 16), so every input value is loaded once per segment - with one row
@@ -438,29 +438,16 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
     float ring[POLY_SLOTS];
 #pragma unroll
     for (int i = 0; i < POLY_SLOTS; ++i) ring[i] = col[(int64_t)clampi(y0 - POLY_N + i, 0, h - 1) * w];
-    // The 5 coefficients of a pixel are 20 bytes: stored from the thread that computed them that is a 16- and a 4-byte store at a
-    // 20-byte lane stride, most of them misaligned.  A row's 246 x 5 floats go through LDS instead (placed so that LDS and global
-    // offsets agree mod 16 bytes) and leave one row later as aligned 16-byte stores, consecutive lanes on consecutive addresses.
-    // (What the kernel waits for is its stores either way - 323 us per launch, 106 without them, profiles/r04_poly_ablations.txt -
-    // and the band-row store pattern itself streams at 3.6 - 4.6 TB/s, tools/micro/write_bw.hip: this form is 1.3 % faster.)
-    __shared__ __attribute__((aligned(16))) float st[2][POLY_OUT * 5 + 8];
-    const int x_first = blockIdx.x * POLY_OUT;
-    const int n_row = (w - x_first < POLY_OUT ? w - x_first : POLY_OUT) * 5;      // floats of a row of this band
-    auto flush = [&](const float* sbuf, int64_t g0) {   // g0: float index in R of the band's first value of that row
-        const int lo = (int)((reinterpret_cast<uintptr_t>(R + g0) >> 2) & 3), hi = lo + n_row;
-        float* const gq = R + (g0 - lo);                 // 16-byte aligned
-        for (int f0 = 4 * tid; f0 < hi; f0 += 4 * 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(sbuf + f0);
-            if (f0 >= lo && f0 + 4 <= hi) *reinterpret_cast<f32x4*>(gq + f0) = v;
-            else {
-                if (f0 + 0 >= lo && f0 + 0 < hi) gq[f0 + 0] = v.x;
-                if (f0 + 1 >= lo && f0 + 1 < hi) gq[f0 + 1] = v.y;
-                if (f0 + 2 >= lo && f0 + 2 < hi) gq[f0 + 2] = v.z;
-                if (f0 + 3 >= lo && f0 + 3 < hi) gq[f0 + 3] = v.w;
-            }
-        }
-    };
-    int64_t g_prev = -1;                                    // the row waiting in the staging buffer (none yet)
+    // Output layout (a pair = two consecutive images z): [frame][h][w][4] holds c0..c3 of a pixel as one aligned 16-byte unit, then
+    // [frame][h][w] holds c4 - 40 bytes per pixel and pair as before, but a wave's stores (here) and loads (matrix_request) are whole
+    // consecutive 16-byte / 4-byte units.  With the five coefficients side by side (20 bytes per pixel: 16- + 4-byte accesses at a
+    // 20-byte lane stride) the texture-address FIFO of the iteration kernels was full 3.1 x as often as a memory instruction was
+    // active (profiles/r04_flow_ta.txt): their producers waited for the load unit, not for HBM.
+    const int64_t hw = (int64_t)h * w;
+    float* const Rp = R + (int64_t)(blockIdx.z >> 1) * hw * 10;
+    float* const R4 = Rp + (int64_t)(blockIdx.z & 1) * hw * 4;
+    float* const R1 = Rp + hw * 8 + (int64_t)(blockIdx.z & 1) * hw;
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // (odd h * w: the second pair starts 8 bytes off a 16-byte line)
     int par = 0;
     for (int yb = y0; yb < y1; yb += POLY_SLOTS) {
 #pragma unroll
@@ -484,8 +471,6 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
                 const float t0 = t02.x, t2 = t02.y;
                 lt[par][tid] = (f32x4){t0, t1, t2, 0.f};
                 RELAX_LDS_BARRIER();
-                if (g_prev >= 0) flush(st[par ^ 1], g_prev);   // the row before this one (its values were staged before the barrier)
-                const int64_t g_row = (((int64_t)blockIdx.z * h + y) * w + x_first) * 5;
                 if (writer) {
                     double b1 = t0 * pc.g[0], b2 = 0, b3 = t1 * pc.g[0], b4 = 0, b5 = t2 * pc.g[0], b6 = 0;
 #pragma unroll
@@ -503,21 +488,17 @@ __global__ __launch_bounds__(256) void poly_expansion(const float* __restrict__ 
                         b6 += d01.y;
                         b5 += s2 * pc.g[k];
                     }
-                    float* o = st[par] + (int)((reinterpret_cast<uintptr_t>(R + g_row) >> 2) & 3) + (tid - POLY_N) * 5;   // lane stride 5 words: no bank conflict
-                    o[1] = (float)(b2 * pc.ig11);
-                    o[0] = (float)(b3 * pc.ig11);
-                    o[3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-                    o[2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-                    o[4] = (float)(b6 * pc.ig55);
+                    const int64_t px = (int64_t)y * w + x;
+                    const float o1 = (float)(b2 * pc.ig11);
+                    const float o0 = (float)(b3 * pc.ig11);
+                    const float o3 = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+                    const float o2 = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+                    *reinterpret_cast<f32x4u*>(R4 + px * 4) = (f32x4u){o0, o1, o2, o3};
+                    R1[px] = (float)(b6 * pc.ig55);
                 }
-                g_prev = g_row;
-                par ^= 1;   // the next row writes the other buffers: its barrier orders these reads / writes before their reuse
+                par ^= 1;   // the next row writes the other buffer: its barrier orders these reads before the buffer's reuse
             }
         }
-    }
-    if (g_prev >= 0) {                                      // the last row of the segment
-        RELAX_LDS_BARRIER();
-        flush(st[par ^ 1], g_prev);
     }
 }
 
@@ -532,9 +513,9 @@ struct MatrixPix {
     float dx, dy;         // the flow at the pixel
     bool inb;             // displaced position inside the image (else the frame-1 terms are dropped)
 };
-// Loads go through a buffer resource over the pair's two coefficient images ([2][h][w][5]): one 32-bit byte offset per pixel in a VGPR,
-// the frame offset in an SGPR - no 64-bit address arithmetic per load (17 VALU instructions per pixel with flat pointers); the 5 / 10
-// contiguous floats of a pixel / a pixel pair arrive as 16- + 4-byte and 16- + 16- + 8-byte loads.
+// Loads go through a buffer resource over the pair's coefficients ([2][h][w][4] + [2][h][w], 40 bytes per pixel): one 32-bit byte offset
+// per pixel in a VGPR, the frame / plane offset in an SGPR - no 64-bit address arithmetic per load (17 VALU instructions per pixel with
+// flat pointers); a pixel arrives as a 16- and a 4-byte load, a pixel pair of the displaced frame as 16 + 16 + 8 bytes.
 __device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 }
@@ -544,13 +525,14 @@ __device__ __forceinline__ float2 buf_f32x2(__amdgpu_buffer_rsrc_t rs, int voff,
 __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
-__device__ __forceinline__ void matrix_request(MatrixPix& p, __amdgpu_buffer_rsrc_t rs, int frame_bytes, int x, int y, float dx, float dy, int h,
+__device__ __forceinline__ void matrix_request(MatrixPix& p, __amdgpu_buffer_rsrc_t rs, int hw_px, int x, int y, float dx, float dy, int h,
                                                int w) {
-    const int v0 = (y * w + x) * 20;
+    // a pair's coefficients: [frame][h][w][4] (c0..c3, 16 bytes per pixel) followed by [frame][h][w] (c4) - see poly_expansion
+    const int px0 = y * w + x;
     {
-        const f32x4 a = buf_f32x4(rs, v0, 0);
+        const f32x4 a = buf_f32x4(rs, px0 * 16, 0);
         p.r0[0] = a.x; p.r0[1] = a.y; p.r0[2] = a.z; p.r0[3] = a.w;
-        p.r0[4] = buf_f32(rs, v0 + 16, 0);
+        p.r0[4] = buf_f32(rs, px0 * 4, hw_px * 32);
     }
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
@@ -559,17 +541,17 @@ __device__ __forceinline__ void matrix_request(MatrixPix& p, __amdgpu_buffer_rsr
     p.fx = fx; p.fy = fy; p.dx = dx; p.dy = dy;
     p.inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
     // outside the image the values are not used: the loads go to a clamped (valid) address instead of sitting in a divergent branch
-    const int v1 = (clampi(y1, 0, h - 2) * w + clampi(x1, 0, w - 2)) * 20, v2 = v1 + w * 20;
+    const int p1 = clampi(y1, 0, h - 2) * w + clampi(x1, 0, w - 2), p2 = p1 + w;
     {
-        const int f1 = frame_bytes;          // frame 1
-        const f32x4 a = buf_f32x4(rs, v1, f1), b = buf_f32x4(rs, v1 + 16, f1);
-        const float2 c2 = buf_f32x2(rs, v1 + 32, f1);
-        p.top[0] = a.x; p.top[1] = a.y; p.top[2] = a.z; p.top[3] = a.w; p.top[4] = b.x;
-        p.top[5] = b.y; p.top[6] = b.z; p.top[7] = b.w; p.top[8] = c2.x; p.top[9] = c2.y;
-        const f32x4 d = buf_f32x4(rs, v2, f1), e = buf_f32x4(rs, v2 + 16, f1);
-        const float2 f2 = buf_f32x2(rs, v2 + 32, f1);
-        p.bot[0] = d.x; p.bot[1] = d.y; p.bot[2] = d.z; p.bot[3] = d.w; p.bot[4] = e.x;
-        p.bot[5] = e.y; p.bot[6] = e.z; p.bot[7] = e.w; p.bot[8] = f2.x; p.bot[9] = f2.y;
+        const int f4 = hw_px * 16, f1 = hw_px * 36;          // frame 1: its 4-vectors, its fifth coefficients
+        const f32x4 a = buf_f32x4(rs, p1 * 16, f4), b = buf_f32x4(rs, p1 * 16 + 16, f4);
+        const float2 c2 = buf_f32x2(rs, p1 * 4, f1);
+        p.top[0] = a.x; p.top[1] = a.y; p.top[2] = a.z; p.top[3] = a.w; p.top[4] = c2.x;
+        p.top[5] = b.x; p.top[6] = b.y; p.top[7] = b.z; p.top[8] = b.w; p.top[9] = c2.y;
+        const f32x4 d = buf_f32x4(rs, p2 * 16, f4), e = buf_f32x4(rs, p2 * 16 + 16, f4);
+        const float2 f2 = buf_f32x2(rs, p2 * 4, f1);
+        p.bot[0] = d.x; p.bot[1] = d.y; p.bot[2] = d.z; p.bot[3] = d.w; p.bot[4] = f2.x;
+        p.bot[5] = e.x; p.bot[6] = e.y; p.bot[7] = e.z; p.bot[8] = e.w; p.bot[9] = f2.y;
     }
 }
 // Every product / sum below names its rounding (__fmul_rn / __fadd_rn / __fmaf_rn): left to itself the compiler contracts these
@@ -631,9 +613,9 @@ __device__ __forceinline__ float2 solve_flow(double A0, double A1, double A2, do
     const double ny = __fma_rn(A2, A3, -__dmul_rn(A1, A4));
     return make_float2((float)__dmul_rn(nx, r), (float)__dmul_rn(ny, r));
 }
-__device__ inline void matrix_entries(__amdgpu_buffer_rsrc_t rs, int frame_bytes, int x, int y, float dx, float dy, int h, int w, float out[5]) {
+__device__ inline void matrix_entries(__amdgpu_buffer_rsrc_t rs, int hw_px, int x, int y, float dx, float dy, int h, int w, float out[5]) {
     MatrixPix p;
-    matrix_request(p, rs, frame_bytes, x, y, dx, dy, h, w);
+    matrix_request(p, rs, hw_px, x, y, dx, dy, h, w);
     matrix_compute(p, x, y, h, w, out);
 }
 
@@ -709,7 +691,7 @@ __global__ __launch_bounds__(256) void update_matrices_k(const float* __restrict
         fy0 = flow[i * 2 + 1];
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (pair * 2) * hw * 5), 0, (int)(hw * 40), 0x00020000);
-    matrix_entries(rs, (int)(hw * 20), x, y, fx0, fy0, h, w, e);
+    matrix_entries(rs, (int)hw, x, y, fx0, fy0, h, w, e);
     float* o = M + pair * 5 * hw + ((int64_t)y * w + x);
 #pragma unroll
     for (int c = 0; c < 5; ++c) o[c * hw] = e[c];
@@ -928,7 +910,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
 
     if (producer) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (pair * 2) * hw * 5), 0, (int)(hw * 40), 0x00020000);
-        const int frame_bytes = (int)(hw * 20);
+        const int hw_px = (int)hw;
         const float* fin = UP ? up.src + pair * ((int64_t)up.H * up.W * 2) : flow_in + pair * hw * 2;
         [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fin), 0, UP ? 0 : (int)(hw * 8), 0x00020000);
         // One step of operands in flight: while the entries of step t are computed row by row from the registers the previous step
@@ -961,7 +943,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
         } else {                                                                                             \
             dx_ = FX_[r_]; dy_ = FY_[r_];                                                                    \
         }                                                                                                    \
-        matrix_request(px[r_], rs, frame_bytes, xc, IT_ROW(t_, r_), dx_, dy_, h, w);                         \
+        matrix_request(px[r_], rs, hw_px, xc, IT_ROW(t_, r_), dx_, dy_, h, w);                               \
     } while (0)
         // one step: FUC_ / FXC_ / FYC_ = the flow set of step t_ + 1 (consumed), FUN_ / .. = that of step t_ + 2 (requested)
 #define IT_STEP(t_, FUC_, FXC_, FYC_, FUN_, FXN_, FYN_, OPS_, FLOW_)                                         \
