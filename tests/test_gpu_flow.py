@@ -111,6 +111,27 @@ def test_batch_of_pairs_and_chunking():
     assert torch.equal(flow[1], one[0])          # a pair's flow does not depend on its batch
 
 
+@pytest.mark.parametrize("h,w", [(97, 131), (35, 49)])
+def test_odd_pixel_counts_with_several_pairs(h, w):
+    """h * w odd: the coefficient block of every second pair ([2][h][w][4] + [2][h][w] floats, 40 bytes per pixel) starts 8 bytes off a
+    16-byte line, so its 16-byte stores (poly_expansion) and loads (the iteration kernels) are misaligned.  Every pair of a batch must
+    still get the flow it gets alone, on both iteration paths."""
+    frames = torch.from_numpy(np.stack([np.stack(_smooth_pair(h, w, 70 + i)) for i in range(3)])).cuda()
+    eng = engine()
+    for fused in (1, 0):
+        eng.set_option("flow_fused", fused)
+        try:
+            flow, img = eng.optical_flow(frames, want_flow=True, want_image=True)
+            for i in range(3):
+                one, one_img = eng.optical_flow(frames[i:i + 1], want_flow=True, want_image=True)
+                assert torch.equal(flow[i], one[0]) and torch.equal(img[i], one_img[0]), (fused, i)
+        finally:
+            eng.set_option("flow_fused", 1)
+    want = flow_ref.farneback(flow_ref.bgr2gray(frames[1, 0].cpu().numpy()), flow_ref.bgr2gray(frames[1, 1].cpu().numpy()))
+    err = np.abs(flow[1].cpu().numpy() - want)
+    assert err.max() < 1e-3 and err.mean() < 1e-5, (err.max(), err.mean())
+
+
 def test_full_relax_clip_with_flow():
     from tests.gpu_common import rn50_weights, vit_weights
     rn50_weights(), vit_weights("vit_base")
