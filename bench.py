@@ -616,6 +616,7 @@ def dataset_pass(eng, workload, n, B, rank, world, split_k, host_clips=False, pr
         # what the copies would cost alone: one batch of this rank's clips, pinned -> device, timed on an idle GPU
         pin = [torch.from_numpy(host[j % n_resident]).pin_memory() for j in range(min(B, 8))]
         dst = [torch.empty_like(p, device="cuda") for p in pin]
+        dst[0].copy_(pin[0], non_blocking=True)          # untimed: the first copy from freshly pinned pages was seen 10 x slower on one box
         torch.cuda.synchronize()
         tc = time.perf_counter()
         for p, d in zip(pin, dst):
