@@ -105,34 +105,56 @@ class ClipStager:
                     self._pooled_bytes += b.numel()
 
     # ---- driver-thread side --------------------------------------------------------------------------------
-    def upload(self, clips):
-        """clips: device tensors and / or (pinned) host tensors -> (device tensors, token).  Host clips are copied on the side
-        stream into this turn's device slot; the current stream is made to wait for the copies in `wait(token)`."""
-        if not self.on_gpu or all(c.is_cuda for c in clips):
-            return list(clips), None
+    def begin(self):
+        """Start a batch: take this turn's device slot, make the side stream wait until the batch that used it two turns ago is
+        through.  Then `add(clip)` per clip as its loader finishes (the copy starts at once, under the loading of the batch's other
+        clips), `end()` -> token."""
         slot = self._turn
         self._turn ^= 1
+        self._cur = {"slot": slot, "at": 0, "any": False}
+        self.copy_stream.wait_event(self._free[slot])
+        return self._cur
+
+    def add(self, c):
+        """One clip of the batch begun: device tensors pass through; a (pinned) host tensor is copied on the side stream into the slot
+        (a slot that turns out too small is replaced by a larger block: the views handed out keep the old one alive)."""
+        if not self.on_gpu or c.is_cuda:
+            return c
+        st = self._cur
+        slot, sz = st["slot"], -(-c.numel() // 256) * 256
         cur = torch.cuda.current_stream(self.device)
-        sizes = [0 if c.is_cuda else -(-c.numel() // 256) * 256 for c in clips]
-        need = sum(sizes)
         with torch.cuda.stream(self.copy_stream):
-            if self._slots[slot] is None or self._slots[slot].numel() < need:
-                self._slots[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)   # block of the copy stream's pool ...
-                self._slots[slot].record_stream(cur)                                           # ... that the compute stream reads
-            self.copy_stream.wait_event(self._free[slot])        # the batch that used this slot two turns ago is through
-            out, at = [], 0
-            for c, sz in zip(clips, sizes):
-                if c.is_cuda:
-                    out.append(c)
-                    continue
-                d = self._slots[slot][at:at + c.numel()].view(c.shape)
-                d.copy_(c, non_blocking=True)
-                out.append(d)
-                at += sz
-                self.bytes_copied += c.numel()
-            ready = torch.cuda.Event()
-            ready.record(self.copy_stream)
-        return out, (slot, ready)
+            buf = self._slots[slot]
+            if buf is None or st["at"] + sz > buf.numel():
+                grow = max(2 * (buf.numel() if buf is not None else 0), st["at"] + 8 * sz)
+                buf = torch.empty(grow, dtype=torch.uint8, device=self.device)          # block of the copy stream's pool ...
+                buf.record_stream(cur)                                                    # ... that the compute stream reads
+                if st["at"] > 0:
+                    st["at"] = 0                                                          # (the clips copied so far stay in the old block)
+                self._slots[slot] = buf
+            d = buf[st["at"]:st["at"] + c.numel()].view(c.shape)
+            d.copy_(c, non_blocking=True)
+        st["at"] += sz
+        st["any"] = True
+        self.bytes_copied += c.numel()
+        return d
+
+    def end(self):
+        st, self._cur = self._cur, None
+        if not st["any"]:
+            self._turn ^= 1                                   # nothing was copied: the slot was not used, give the turn back
+            return None
+        ready = torch.cuda.Event()
+        ready.record(self.copy_stream)
+        return (st["slot"], ready)
+
+    def upload(self, clips):
+        """clips: device tensors and / or (pinned) host tensors -> (device tensors, token): begin / add / end in one call."""
+        if not self.on_gpu or all(c.is_cuda for c in clips):
+            return list(clips), None
+        self.begin()
+        out = [self.add(c) for c in clips]
+        return out, self.end()
 
     def wait(self, token):
         if token is not None:
@@ -169,8 +191,8 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
 
     prefetch = 0: no loader threads, no side stream - clips(i) is called in the driver thread as the batch is assembled (the
              round-3 behaviour; same rows bit for bit).
-    ramp (default, with prefetch > 0 and clips_per_step >= 16): the pass opens with batches of B/8, B/4, B/2 clips before the
-             full ones, so that the loading of the first batch - which nothing hides - is short.
+    ramp (default, with prefetch > 0 and clips_per_step >= 16): the pass opens with batches of B/8, 3B/8, B/2 clips (together one
+             full batch) before the full ones, so that the loading of the first batch - which nothing hides - is short.
     batch_invariant (default): the pass runs with the engine's tail split-K off, so a clip's row does not depend on which clips
              share its batch - i.e. not on the number of ranks (engine.clip_vectors); the option is restored afterwards.
     out_dir: write each clip's per-frame rows [T, F] as `video_{i+1}_{network_name}_feature_map_original.npy`
@@ -253,11 +275,11 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         except Exception as e:                          # noqa: BLE001 - the contract: the clip fails, the run goes on
             return ("err", f"{type(e).__name__}: {e}")
 
-    # ramp: the first batch has nothing to hide its loading under, so the pass opens with short batches (B/8, B/4, B/2) - the
+    # ramp: the first batch has nothing to hide its loading under, so the pass opens with short batches (B/8, 3B/8, B/2) - the
     # engine starts after an eighth of a batch has been loaded and every next batch loads under the previous one's compute
     sizes = []
     if ramp and prefetch > 0 and B >= 16 and len(mine) >= 2 * B:
-        sizes = [B // 8, B // 4, B // 2]
+        sizes = [B // 8, B - B // 8 - B // 2, B // 2]       # together one full batch: the rest of the pass splits as it would without them
     starts, at = [], 0
     while at < len(mine):
         starts.append(at)
@@ -273,11 +295,15 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
     def stage(b):
         """Collect batch b from the loaders and start its host-to-device copies -> (slots, idxs, device clips, token, pinned)."""
         nonlocal loader_wait
-        t_w = time.perf_counter()
-        results = [f.result() for f in futures.pop(b)] if pool is not None else [load(i) for i in batches[b]]
-        loader_wait += time.perf_counter() - t_w
-        slots, idxs, host, pinned = [], [], [], []
-        for slot, (i, r) in enumerate(zip(batches[b], results), start=starts[b]):
+        futs = futures.pop(b) if pool is not None else None
+        slots, idxs, devs, pinned = [], [], [], []
+        staging = stager is not None and stager.on_gpu
+        if staging:
+            stager.begin()
+        for k, (slot, i) in enumerate(zip(range(starts[b], starts[b] + len(batches[b])), batches[b])):
+            t_w = time.perf_counter()
+            r = futs[k].result() if futs is not None else load(i)
+            loader_wait += time.perf_counter() - t_w
             if r[0] == "err":
                 errors.append((i, r[1]))
             elif r[0] == "row":
@@ -285,14 +311,9 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
             else:
                 slots.append(slot)
                 idxs.append(i)
-                host.append(r[1])
+                devs.append(stager.add(r[1]) if staging else r[1])    # the copy of this clip starts while the others still load
                 pinned.append(r[2])
-        if not host:
-            return slots, idxs, [], None, pinned
-        if stager is not None:
-            devs, token = stager.upload(host)
-        else:
-            devs, token = host, None
+        token = stager.end() if staging else None
         return slots, idxs, devs, token, pinned
 
     try:

@@ -137,14 +137,14 @@ def test_slow_and_failing_loaders_do_not_deadlock_the_pass():
 
 
 def test_the_pass_opens_with_short_batches_and_returns_the_same_rows():
-    """ramp: B/8, B/4, B/2, then full batches (the loading of the first batch has nothing to hide under); rows and error list as
+    """ramp: B/8, 3B/8, B/2 (together one full batch), then full batches (the loading of the first batch has nothing to hide under); rows and error list as
     without it."""
     _patched()
     src = lambda i: _clip(8 + (i % 3) * 4)                      # noqa: E731  (healthy clips only)
     e1, e2 = FakeEngine(), FakeEngine()
     a, ea = dataset.extract_dataset_clips(src, 70, e1, clips_per_step=16, rank=0, world=1)
     b, eb = dataset.extract_dataset_clips(src, 70, e2, clips_per_step=16, rank=0, world=1, ramp=False)
-    assert e1.batches == [2, 4, 8, 16, 16, 16, 8] and e2.batches == [16, 16, 16, 16, 6]
+    assert e1.batches == [2, 6, 8, 16, 16, 16, 6] and e2.batches == [16, 16, 16, 16, 6]     # the same tail with and without the ramp
     assert np.array_equal(a.numpy(), b.numpy()) and not ea and not eb
 
 
