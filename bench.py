@@ -434,7 +434,7 @@ def main():
             others[name] = rec
             del step_o, clips_o, out_o
         torch.cuda.empty_cache()
-        others["config4_dataset"] = dataset_pass(eng, "config4", 256, 64, 0, 1, args.gemm_split_k, host_clips=True, prefetch=args.prefetch,
+        others["config4_dataset"] = dataset_pass(eng, "config4", 512, 64, 0, 1, args.gemm_split_k, host_clips=True, prefetch=args.prefetch,
                                                  workers=args.loader_workers, n_resident=4, warmup=1)
 
     if world > 1:
