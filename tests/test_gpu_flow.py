@@ -132,6 +132,36 @@ def test_odd_pixel_counts_with_several_pairs(h, w):
     assert err.max() < 1e-3 and err.mean() < 1e-5, (err.max(), err.mean())
 
 
+def test_degenerate_pairs_identical_constant_and_black_frames():
+    """A frozen frame (identical pair: OpenCV's border rule still yields a small flow near the right / bottom edge), two flat frames of
+    different brightness (no gradients: the flow is exactly zero, the magnitude range is empty - cv2.normalize's scale falls back to 0 -
+    and the image is black) and a frame against black: against the oracle as every other pair, nothing may turn into NaN, and the
+    fragment stage must order an image whose patch scores are all equal by the reference's tie rule."""
+    h, w = 200, 264
+    a, _ = _smooth_pair(h, w, 11)
+    flat_lo = np.full((h, w, 3), 50, np.uint8)
+    flat_hi = np.full((h, w, 3), 200, np.uint8)
+    black = np.zeros((h, w, 3), np.uint8)
+    pairs = [np.stack([a, a]), np.stack([flat_lo, flat_hi]), np.stack([a, black])]
+    frames = torch.from_numpy(np.stack(pairs)).cuda()
+    eng = engine()
+    flow, img = eng.optical_flow(frames, want_flow=True, want_image=True)
+    assert bool(torch.isfinite(flow).all())
+    for i, (p0, p1) in enumerate(pairs):
+        want = flow_ref.farneback(flow_ref.bgr2gray(p0), flow_ref.bgr2gray(p1))
+        want_img = flow_ref.flow_to_rgb(want)
+        err = np.abs(flow[i].cpu().numpy() - want)
+        assert err.max() < 1e-3, (i, err.max())
+        d = np.abs(img[i].cpu().numpy().astype(np.int32) - want_img.astype(np.int32))
+        assert (d == 0).mean() > 0.99, (i, (d == 0).mean(), d.max())
+    assert float(flow[1].abs().max()) == 0.0 and int(img[1].max()) == 0          # flat frames: exactly zero flow, black image
+    flat_img = img[1].cpu().numpy()
+    fo = eng.fragment_image(img[1:2])
+    _, wp = fragment_ref.extract_important_patches(flat_img, fragment_ref.get_patch_diff(flat_img))
+    n = int(fo["counts"][0])
+    assert n == len(wp) and fo["positions"][0, :n].cpu().numpy().tolist() == wp.tolist()     # all scores equal: the reference's tie order
+
+
 def test_full_relax_clip_with_flow():
     from tests.gpu_common import rn50_weights, vit_weights
     rn50_weights(), vit_weights("vit_base")
