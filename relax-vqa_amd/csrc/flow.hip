@@ -563,7 +563,8 @@ __device__ __forceinline__ float dot4_rn(float a0, float b0, float a1, float b1,
 __device__ __forceinline__ void matrix_compute(const MatrixPix& p, int x, int y, int h, int w, float out[5]) {
     const float fx = p.fx, fy = p.fy, dx = p.dx, dy = p.dy;
     float r2, r3, r4, r5, r6;
-    if (p.inb) {
+    {   // the in-bounds case is always evaluated (the loads went to clamped addresses anyway) and the other one selected: no divergent
+        // branch in the producers' instruction stream (-0.6 % of the stage against the branch; same values)
         const float gx = __fsub_rn(1.f, fx), gy = __fsub_rn(1.f, fy);
         const float a00 = __fmul_rn(gx, gy), a01 = __fmul_rn(fx, gy), a10 = __fmul_rn(gx, fy), a11 = __fmul_rn(fx, fy);
         r2 = dot4_rn(a00, p.top[0], a01, p.top[5], a10, p.bot[0], a11, p.bot[5]);
@@ -574,11 +575,11 @@ __device__ __forceinline__ void matrix_compute(const MatrixPix& p, int x, int y,
         r4 = __fmul_rn(__fadd_rn(p.r0[2], r4), 0.5f);
         r5 = __fmul_rn(__fadd_rn(p.r0[3], r5), 0.5f);
         r6 = __fmul_rn(__fadd_rn(p.r0[4], r6), 0.25f);
-    } else {
-        r2 = r3 = 0.f;
-        r4 = p.r0[2];
-        r5 = p.r0[3];
-        r6 = __fmul_rn(p.r0[4], 0.5f);
+        r2 = p.inb ? r2 : 0.f;
+        r3 = p.inb ? r3 : 0.f;
+        r4 = p.inb ? r4 : p.r0[2];
+        r5 = p.inb ? r5 : p.r0[3];
+        r6 = p.inb ? r6 : __fmul_rn(p.r0[4], 0.5f);
     }
     r2 = __fmul_rn(__fsub_rn(p.r0[0], r2), 0.5f);
     r3 = __fmul_rn(__fsub_rn(p.r0[1], r3), 0.5f);
