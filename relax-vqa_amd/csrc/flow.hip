@@ -270,6 +270,11 @@ struct PyramidTaps {
 };
 constexpr int PYR_HALO = 8;
 constexpr int PYR_G = 256 + 2 * PYR_HALO;     // gray values per row and band
+// the value of the next lane of the wave (lane 63 keeps its own: only even lanes use the result) as a DPP wave shift - a vector
+// instruction, where __shfl_down goes through the LDS crossbar (ds_bpermute_b32) of a kernel that is short of LDS cycles
+__device__ __forceinline__ float next_lane(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
 __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__ orig, const uint8_t* __restrict__ next, int64_t pair_stride,
                                                      int H, int W, float* __restrict__ I0, float* __restrict__ I1, float* __restrict__ I2,
                                                      float* __restrict__ I3, int seg, const PyramidTaps tp) {
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__
             const bool in_rows = r >= y0 && r < y1;
             if (in_rows && c < W) o0[(int64_t)r * W + c] = v0;
             // level 1: rows 2 d, 2 d + 1 and columns 2 d, 2 d + 1 of the blurred frame, weights 1/2 (all lanes take part in the exchange)
-            const float a01 = __shfl_down(b1prev, 1), a11 = __shfl_down(b1, 1);
+            const float a01 = next_lane(b1prev), a11 = next_lane(b1);
             if (in_rows && (r & 1) && !(x & 1) && c < W)
                 o1[(int64_t)(r >> 1) * (W / 2) + (c >> 1)] = lerp_rn(lerp_rn(b1prev, a01, 0.5f), lerp_rn(b1, a11, 0.5f), 0.5f);
             h0m2 = h0m1; h0m1 = h0c;
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__
                         a0 = fmaf(tp.k2[t], ring2[(4 * d + 1 + t - 4) & 15][x], a0);
                         a1 = fmaf(tp.k2[t], ring2[(4 * d + 2 + t - 4) & 15][x], a1);
                     }
-                    const float a01 = __shfl_down(a0, 1), a11 = __shfl_down(a1, 1);
+                    const float a01 = next_lane(a0), a11 = next_lane(a1);
                     const int dx = (c0 >> 2) + (x >> 1);
                     if (!(x & 1) && dx < (W >> 2)) o2[(int64_t)d * (W >> 2) + dx] = lerp_rn(lerp_rn(a0, a01, 0.5f), lerp_rn(a1, a11, 0.5f), 0.5f);
                 }
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(256) void pyramid_fused(const uint8_t* __restrict__
                         a0 = fmaf(tp.k3[t], ring3[(8 * d + 3 + t - 9) & 31][e], a0);
                         a1 = fmaf(tp.k3[t], ring3[(8 * d + 4 + t - 9) & 31][e], a1);
                     }
-                    const float a01 = __shfl_down(a0, 1), a11 = __shfl_down(a1, 1);
+                    const float a01 = next_lane(a0), a11 = next_lane(a1);
                     const int dx = (c0 >> 3) + (e >> 1);
                     if (!(e & 1) && dx < (W >> 3)) o3[(int64_t)d * (W >> 3) + dx] = lerp_rn(lerp_rn(a0, a01, 0.5f), lerp_rn(a1, a11, 0.5f), 0.5f);
                 }
