@@ -23,5 +23,7 @@ Parity pinning status (see DESIGN.md "Oracle"):
   and is cross-checked against HuggingFace ``transformers`` ResNetModel (an
   independent implementation of the same architecture).  Against the reference
   itself: PARITY UNPINNED.
-* Farneback optical flow: out of scope this round.
+* Farneback optical flow + ``flow_to_rgb`` (``oracle/flow_ref.py``): OpenCV 4.9's algorithm restated (cv2 is absent from
+  the image).  Pinned by TOLERANCE only - the reference's own ``*_residual_of*.png`` sets: >= 99.8 % of the flow image's
+  bytes equal, >= 195 / 196 fragment positions (``tests/test_oracle_flow.py``, ``tests/test_gpu_reference_png_sets.py``).
 """

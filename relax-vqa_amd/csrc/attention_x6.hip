@@ -17,6 +17,15 @@
 #include "relax_internal.h"
 #include "sp3.h"
 
+// Phase-stamp hooks of the diagnostic build: empty in the product.  tools/abl/attention_x6_stamps.hip defines them and #includes this
+// file (its flush overwrites the first floats of the fp32 output with the averages: a diagnostic library, never the product).
+#ifndef A6_STAMP
+#define A6_STAMP_DECL
+#define A6_STAMP(i_)
+#define A6_STAMP_ITEM()
+#define A6_STAMP_FLUSH()
+#endif
+
 namespace relax {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -143,21 +152,7 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
     A6_STORE_K();
     __syncthreads();
 
-#ifdef RELAX_A6_STAMPS   // diagnostic build (tools/build_ablations.sh a6stamps): ticks per phase of an item, waves 0 and 6 of workgroup 3
-    unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long t_ = __builtin_amdgcn_s_memtime();
-    int items_done = 0;
-#define A6_STAMP(i_)                                                                                                 \
-    {                                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        const unsigned long long n_ = __builtin_amdgcn_s_memtime();                                                  \
-        ph[i_] += n_ - t_;                                                                                           \
-        t_ = n_;                                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-    }
-#else
-#define A6_STAMP(i_)
-#endif
+    A6_STAMP_DECL;
     while (true) {
         A6_DMA(item, 2);   // V rows: in flight during the score phase
         // ---- scores: S^T tile kt = K[kt] Q^T, 4 d-steps x 6 partial products (smallest first) -------------------------
@@ -308,9 +303,7 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
             }
         }
         A6_STAMP(5);   // epilogue
-#ifdef RELAX_A6_STAMPS
-        ++items_done;
-#endif
+        A6_STAMP_ITEM();
         if (next >= total_items) break;
         A6_SPLIT_Q();
         A6_STAMP(6);   // split of the next Q
@@ -322,12 +315,7 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
         A6_STAMP(8);   // K rows -> plane image + barrier
         item = next;
     }
-#ifdef RELAX_A6_STAMPS
-    if (OUT_F32 && blockIdx.x == 3 && (tid == 0 || tid == 6 * 64)) {   // (the fp32-output form only: the averages go out in the first floats of `out`)
-        for (int i = 0; i < 9; ++i) out[(tid ? 16 : 0) + i] = (float)(ph[i] / items_done);
-    }
-#endif
-#undef A6_STAMP
+    A6_STAMP_FLUSH();
 #undef A6_DMA
 #undef A6_WAIT_DMA
 #undef A6_STORE_K

@@ -26,9 +26,6 @@
 // them.  Where a fused multiply-add is wanted it is written: fmaf / fma / __fmaf_rn / __fma_rn.
 namespace relax {
 
-#ifndef RELAX_FLOW_ABLATE
-#define RELAX_FLOW_ABLATE 0     // diagnostic builds (tools/build_ablations.sh flow:<mask>, WRONG results, timing only):
-#endif                          // 2 no matrix arithmetic, 4 no strips (window slide + solve), 8 no column sums, 16 no flow loads
 // Workgroup barrier for data that goes through LDS only: waits for this wave's LDS operations, not for its global loads and
 // stores (__syncthreads() also waits vmcnt(0): in a row-walking kernel that drains the rows requested ahead and the stores of the
 // row just written at every row).
@@ -865,26 +862,14 @@ __global__ __launch_bounds__(256) void box_solve_fused(const float* __restrict__
 // The ring starts as zeros and the first 5 steps (15 rows) fill it - `s += row - 0` - so the loop has no special first window:
 // entering rows y0 - 8 + 3t + r (the very first, y0 - 8, lies outside the window of y0 and enters as zeros).  Same additions in the
 // same order as box_solve_fused, same matrix entries as update_matrices_k (shared source above): the flow is bit-identical.
-#ifdef RELAX_FLOW_STAMPS   // diagnostic build (tools/build_ablations.sh flowstamps): ticks per phase of a step, one producer and one box wave of one block per launch
-__device__ unsigned long long g_flow_stamps[16];
-#define IT_STAMP_DECL unsigned long long st_t_ = __builtin_amdgcn_s_memtime(), st_[6] = {0, 0, 0, 0, 0, 0}
-#define IT_STAMP(i_)                                                         \
-    {                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                   \
-        const unsigned long long n_ = __builtin_amdgcn_s_memtime();          \
-        st_[i_] += n_ - st_t_;                                               \
-        st_t_ = n_;                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                   \
-    }
-#define IT_STAMP_WAIT_LOADS   /* everything this step consumes has landed: the wait as one number (the product waits row by row) */ \
-    {                                                                        \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
-        IT_STAMP(5);                                                         \
-    }
-#else
+// Phase-stamp hooks of the diagnostic build: empty in the product.  tools/abl/flow_stamps.hip defines them (and the reader
+// relax_debug_flow_stamps) and #includes this file; nothing in this translation unit can record or print a stamp.
+#ifndef IT_STAMP
 #define IT_STAMP_DECL
 #define IT_STAMP(i_)
 #define IT_STAMP_WAIT_LOADS
+#define IT_STAMP_FLUSH_PRODUCER
+#define IT_STAMP_FLUSH_BOX
 #endif
 constexpr int IT_ROWS = 3;
 constexpr int IT_OUT = FUSE_OUT;                 // 240 output columns per band
@@ -936,8 +921,8 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
         if constexpr (UP) flow_up_request(FU_[r_], up, fin, xc, y_);                                         \
         else {                                                                                               \
             const float2 q_ = buf_f32x2(rsf, (y_ * w + xc) * 8, 0);                                          \
-            FX_[r_] = (RELAX_FLOW_ABLATE & 16) ? 0.25f : q_.x;                                               \
-            FY_[r_] = (RELAX_FLOW_ABLATE & 16) ? 0.5f : q_.y;                                                \
+            FX_[r_] = q_.x;                                                                                  \
+            FY_[r_] = q_.y;                                                                                  \
         }                                                                                                    \
     } while (0)
 #define IT_REQUEST_OPERANDS(t_, r_, FU_, FX_, FY_)                                                           \
@@ -961,10 +946,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
         }                                                                                                    \
         _Pragma("unroll") for (int r = 0; r < IT_ROWS; ++r) {                                                \
             float e[5];                                                                                      \
-            if (RELAX_FLOW_ABLATE & 2) {                                                                     \
-                _Pragma("unroll") for (int c = 0; c < 5; ++c) e[c] = px[r].r0[c] + px[r].top[c] + px[r].bot[c] + px[r].top[5 + c] + px[r].bot[5 + c]; \
-            } else                                                                                           \
-                matrix_compute(px[r], xc, IT_ROW(t_, r), h, w, e);                                           \
+            matrix_compute(px[r], xc, IT_ROW(t_, r), h, w, e);                                               \
             const bool skip = (t_) == 0 && r == 0;   /* row y0 - 8 is outside the window of y0 */            \
             _Pragma("unroll") for (int c = 0; c < 5; ++c) Mb[(t_) & 1][r][c][tid] = skip ? 0.f : e[c];      \
             if constexpr (UP) {                                                                              \
@@ -1000,14 +982,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
             else IT_STEP_EVEN(t, ops, flo);
         }
         RELAX_LDS_BARRIER();                                   // the barrier of step Q (the box waves' last column sums)
-#ifdef RELAX_FLOW_STAMPS
-        if (threadIdx.x == 256 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && (g_flow_stamps[15] == 0 || g_flow_stamps[15] == (unsigned long long)w)) {
-            atomicAdd(&g_flow_stamps[0], st_[0]);
-            atomicAdd(&g_flow_stamps[1], st_[1]);
-            atomicAdd(&g_flow_stamps[3], st_[5]);
-            atomicAdd(&g_flow_stamps[2], (unsigned long long)Q);
-        }
-#endif
+        IT_STAMP_FLUSH_PRODUCER;
 #undef IT_STEP_EVEN
 #undef IT_STEP_ODD
 #undef IT_STEP
@@ -1038,7 +1013,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
             const int t = tb + j;                             // this step: V(t - 1), then H(t - 2)
             if (t <= Q + 1) {                                 // uniform over the block
                 IT_STAMP(5);
-                if (t >= 1 && t <= Q && !(RELAX_FLOW_ABLATE & 8)) {
+                if (t >= 1 && t <= Q) {
                     const int par = (t - 1) & 1;
 #pragma unroll
                     for (int r = 0; r < IT_ROWS; ++r) {
@@ -1056,7 +1031,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
                 if (t >= IT_FILL + 2) {                       // (t <= Q + 1 holds)
                     const int q = t - 2, par = q & 1;
                     const int y = y0 + IT_ROWS * (q - IT_FILL) + sr;
-                    if (strip && y < y1 && !(RELAX_FLOW_ABLATE & 4)) {
+                    if (strip && y < y1) {
                         double acc[5][4];
 #pragma unroll
                         for (int c = 0; c < 5; ++c) {
@@ -1113,14 +1088,7 @@ __global__ __launch_bounds__(512) void flow_iteration(const float* __restrict__ 
             }
         }
     }
-#ifdef RELAX_FLOW_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && (g_flow_stamps[15] == 0 || g_flow_stamps[15] == (unsigned long long)w)) {
-        atomicAdd(&g_flow_stamps[4], st_[2]);
-        atomicAdd(&g_flow_stamps[5], st_[3]);
-        atomicAdd(&g_flow_stamps[6], st_[4]);
-        atomicAdd(&g_flow_stamps[7], (unsigned long long)(Q + 2));
-    }
-#endif
+    IT_STAMP_FLUSH_BOX;
     if constexpr (MINMAX) {   // wave minimum / maximum, one atomic pair per wave
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
@@ -1595,19 +1563,6 @@ int relax_optical_flow(relax_handle* h, const uint8_t* orig, const uint8_t* next
     }
     return RELAX_OK;
 }
-
-
-#ifdef RELAX_FLOW_STAMPS
-int relax_debug_flow_stamps(unsigned long long* out16, int reset, int only_width) {   // diagnostic builds only (tools/flow_stamps.py)
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(relax::g_flow_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {};
-        z[15] = (unsigned long long)only_width;   // 0: launches of every level
-        if (hipMemcpyToSymbol(HIP_SYMBOL(relax::g_flow_stamps), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 int relax_flow_to_rgb(relax_handle* h, const float* flow, int T, int H, int W, uint8_t* flow_bgr, relax_stream stream) {
     if (!h) return RELAX_ERR_INVALID;

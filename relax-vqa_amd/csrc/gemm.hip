@@ -19,19 +19,6 @@
 #include "host_logic.h"
 #include "gelu.h"
 
-#ifndef RELAX_F32_ABLATE
-#define RELAX_F32_ABLATE 0  // build-time timing experiments on the fp32 loop (WRONG results): 1 no barrier, 2 no global loads,
-#endif                      // 4 no LDS stores.  Never set in the product build (tools/build_ablations.sh f32:<n>)
-#ifndef RELAX_X3_ABLATE
-#define RELAX_X3_ABLATE 0   // build-time timing experiments on the bf16x3 loop (WRONG results): 1 no barrier, 2 no global loads,
-#endif                      // 4 no LDS stores, 8 no split, 16 half the fragment reads (tools/build_ablations.sh)
-
-#ifdef RELAX_GEMM_STAMPS   // diagnostic build (tools/build_ablations.sh stamps): wave 0 records 100 MHz timestamps per phase
-#define RELAX_STAMP(i_) if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i_)] = wall_clock64()
-#else
-#define RELAX_STAMP(i_)
-#endif
-
 namespace relax {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -53,7 +40,6 @@ struct GemmParams {
     int tiles_m, tiles_n, ntiles, group_m;
     int full_tiles;  // tiles [0, full_tiles) run the whole K loop and the epilogue in-kernel
     int nsplit;      // tiles [full_tiles, ntiles) are cut into nsplit K slices (raw partial sums)
-    unsigned long long* stamps;   // RELAX_GEMM_STAMPS builds only: per-workgroup phase timestamps
 };
 
 __device__ inline int xcd_remap(int b, int nwg) {
@@ -140,7 +126,6 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_gemm_f32(const GemmPar
     }
     const int m0 = tm * BM;
     const int n0 = tn * BN;
-    RELAX_STAMP(0);
 
     // per-thread row descriptors of the A operand (fixed for the whole K loop)
     int64_t a_base[A_LOADS];
@@ -304,13 +289,11 @@ _Pragma("unroll")  \
 _Pragma("unroll")  \
             for (int i = 0; i < TM; ++i) {  \
                 ah[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + ks * 32);  \
-                if (RELAX_X3_ABLATE & 16) al[i] = ah[i]; else  \
                 al[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDK * 4 + BK * 2 + ks * 32);  \
             }  \
 _Pragma("unroll")  \
             for (int j = 0; j < TN; ++j) {  \
                 bh[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + ks * 32);  \
-                if (RELAX_X3_ABLATE & 16) bl[j] = bh[j]; else  \
                 bl[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDK * 4 + BK * 2 + ks * 32);  \
             }  \
             /* product type outermost: 8 independent accumulators between two MFMAs on the same one; per accumulator the  \
@@ -328,19 +311,10 @@ _Pragma("unroll")  \
                         if (pc * BLOCKS >= g_ * PIECES && pc * BLOCKS < (g_ + 1) * PIECES) {  \
                             uint2 hi_, lo_;  \
                             const f32x4 src_ = pc < A_LOADS ? ra[pc < A_LOADS ? pc : 0] : rb[pc >= A_LOADS ? pc - A_LOADS : 0];  \
-                            if (RELAX_X3_ABLATE & 8) {  \
-                                hi_.x = __float_as_uint(src_.x); hi_.y = __float_as_uint(src_.y);  \
-                                lo_.x = __float_as_uint(src_.z); lo_.y = __float_as_uint(src_.w);  \
-                            } else {  \
-                                split_bf16x4(src_, &hi_, &lo_);  \
-                            }  \
+                            split_bf16x4(src_, &hi_, &lo_);  \
                             uint2* dst_ = pc < A_LOADS ? A8_ + pc * PASS * (LDK / 2) : B8_ + (pc - A_LOADS) * PASS * (LDK / 2);  \
-                            if (RELAX_X3_ABLATE & 4) {  \
-                                asm volatile("" ::"v"(hi_.x), "v"(hi_.y), "v"(lo_.x), "v"(lo_.y));  \
-                            } else {  \
-                                dst_[0] = hi_;  \
-                                dst_[BK / 4] = lo_;  \
-                            }  \
+                            dst_[0] = hi_;  \
+                            dst_[BK / 4] = lo_;  \
                         }  \
                 }  \
         }  \
@@ -350,13 +324,12 @@ _Pragma("unroll")  \
         RELAX_LOAD_TILE(kt_begin * BK);
         RELAX_STORE_TILE(0);
         __syncthreads();
-        RELAX_STAMP(1);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int cur = (kt - kt_begin) & 1;
-            if (kt + 1 < kt_end && !(RELAX_F32_ABLATE & 2)) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
+            if (kt + 1 < kt_end) RELAX_LOAD_TILE((kt + 1) * BK);  // global loads in flight under the MFMAs below
             RELAX_COMPUTE(cur);
-            if (kt + 1 < kt_end && !(RELAX_F32_ABLATE & 4)) RELAX_STORE_TILE(cur ^ 1);
-            if (!(RELAX_F32_ABLATE & 1)) __syncthreads();
+            if (kt + 1 < kt_end) RELAX_STORE_TILE(cur ^ 1);
+            __syncthreads();
         }
     } else {
         // bf16x3: a K step is only 24 MFMAs (768 cycles) per wave, too short to cover a global load, so the register
@@ -366,17 +339,16 @@ _Pragma("unroll")  \
         RELAX_STORE_TILE_R(0, ra0, rb0);
         if (kt_begin + 1 < kt_end) RELAX_LOAD_TILE_R((kt_begin + 1) * BK, ra1, rb1);
         __syncthreads();
-        RELAX_STAMP(1);
         int kt = kt_begin;
         // steady state, branch-free: the split + LDS stores of tile k+1 are emitted between the MFMA blocks of tile k
         // so that one basic block holds both and the VALU work runs under the matrix pipe
         for (; kt + 3 < kt_end; kt += 2) {
-            if (!(RELAX_X3_ABLATE & 2)) RELAX_LOAD_TILE_R((kt + 2) * BK, ra0, rb0);
+            RELAX_LOAD_TILE_R((kt + 2) * BK, ra0, rb0);
             RELAX_COMPUTE_STORE_X3(0, 1, ra1, rb1);
-            if (!(RELAX_X3_ABLATE & 1)) __syncthreads();
-            if (!(RELAX_X3_ABLATE & 2)) RELAX_LOAD_TILE_R((kt + 3) * BK, ra1, rb1);
+            __syncthreads();
+            RELAX_LOAD_TILE_R((kt + 3) * BK, ra1, rb1);
             RELAX_COMPUTE_STORE_X3(1, 0, ra0, rb0);
-            if (!(RELAX_X3_ABLATE & 1)) __syncthreads();
+            __syncthreads();
         }
         for (; kt < kt_end; kt += 2) {
             if (kt + 2 < kt_end) RELAX_LOAD_TILE_R((kt + 2) * BK, ra0, rb0);
@@ -391,7 +363,6 @@ _Pragma("unroll")  \
             }
         }
     }
-    RELAX_STAMP(2);
 #undef RELAX_COMPUTE
 #undef RELAX_COMPUTE_STORE_X3
 
@@ -428,10 +399,8 @@ _Pragma("unroll")  \
     const bool interior = m0 + BM <= p.M;  // workgroup-uniform: interior tiles skip the per-row guards
 #pragma unroll
     for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
-        if (pass == 1) { RELAX_STAMP(4); }
-        if (pass > 0) __syncthreads();
-        if (pass == 1) { RELAX_STAMP(5); }
-        f32x4 rv[EP_ITERS];
+                if (pass > 0) __syncthreads();
+                f32x4 rv[EP_ITERS];
         if (slice < 0 && interior) {
 #pragma unroll
             for (int it = 0; it < EP_ITERS; ++it)   // residual rows of this pass: in flight under the LDS staging below
@@ -451,8 +420,7 @@ _Pragma("unroll")  \
             }
         }
         __syncthreads();
-        if (pass == 0) { RELAX_STAMP(3); }
-        if (slice >= 0) {
+                if (slice >= 0) {
 #pragma unroll
             for (int it = 0; it < EP_ITERS; ++it) {
                 const int lr = it * EP_STEP + lr0;
@@ -496,7 +464,6 @@ _Pragma("unroll")  \
             }
         }
     }
-    RELAX_STAMP(7);
 }
 
 #undef RELAX_LOAD_TILE
@@ -565,32 +532,7 @@ static int launch_variant(relax_handle* h, GemmParams& p, int blocks_per_cu, hip
         attr_set[h->device] = true;
     }
     const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
-#ifdef RELAX_GEMM_STAMPS
-    RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * 8 * (size_t)units));
-    p.stamps = static_cast<unsigned long long*>(h->scratch.p);
-#endif
     hipLaunchKernelGGL((conv_gemm_f32<BM, BN, WM, WN, BK, OCC, TAPS, PREC>), dim3(units), dim3(NT), lds, s, p);
-#ifdef RELAX_GEMM_STAMPS
-    {
-        RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
-        std::vector<unsigned long long> hs(8 * (size_t)units);
-        RELAX_HIP_CHECK(h, hipMemcpy(hs.data(), p.stamps, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
-        double d[6] = {0, 0, 0, 0, 0, 0};
-        for (int u = 0; u < p.full_tiles; ++u) {
-            const unsigned long long* t = &hs[8 * (size_t)u];
-            d[0] += (double)(t[1] - t[0]);   // prologue
-            d[1] += (double)(t[2] - t[1]);   // K loop
-            d[2] += (double)(t[3] - t[2]);   // accumulators of pass 0 -> LDS + barrier
-            d[3] += (double)(t[4] - t[3]);   // pass 0: LDS -> bias/residual/act -> global stores issued
-            d[4] += (double)(t[5] - t[4]);   // barrier before pass 1
-            d[5] += (double)(t[7] - t[5]);   // remaining passes
-        }
-        const double n = (p.full_tiles > 0 ? p.full_tiles : 1) * 100.0;
-        fprintf(stderr, "gemm %dx%dx%d tile %dx%d act %d res %d: per tile (us) prologue %.2f loop %.2f (%d steps) | epilogue: acc->LDS %.2f, "
-                "pass-0 out %.2f, barrier %.2f, other passes %.2f\n", p.M, p.N, p.Kpad, BM, BN, p.act, p.residual != nullptr,
-                d[0] / n, d[1] / n, p.Kpad / BK, d[2] / n, d[3] / n, d[4] / n, d[5] / n);
-    }
-#endif
     if (p.nsplit > 1)
         hipLaunchKernelGGL((splitk_finish<BM, BN>), dim3(BM * BN / 4 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
     RELAX_HIP_CHECK(h, hipGetLastError());

@@ -48,10 +48,13 @@
 #include "sp3.h"
 #include "gelu.h"
 
-#ifdef RELAX_X6_STAMPS   // diagnostic build (tools/build_ablations.sh x6stamps): thread 0 of every workgroup records cycle stamps
-#define X6_STAMP(i_) if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime()
-#else
+// Phase-stamp hooks of the diagnostic build: empty in the product.  tools/abl/gemm_x6_stamps.hip defines them (and the report) and
+// #includes this file; nothing in this translation unit records or prints a stamp.
+#ifndef X6_STAMP
 #define X6_STAMP(i_)
+#define X6_STAMP_IDS()
+#define X6_STAMPS_BEFORE_LAUNCH(h_, p_, units_)
+#define X6_STAMPS_AFTER_LAUNCH(BM_, BN_, h_, p_, units_, s_)
 #endif
 
 namespace relax {
@@ -107,7 +110,7 @@ struct X6Params {
     int act;
     int tiles_m, tiles_n, ntiles, group_m;
     int full_tiles, nsplit;
-    unsigned long long* stamps;   // RELAX_X6_STAMPS builds only
+    unsigned long long* stamps;   // diagnostic builds only (tools/abl/gemm_x6_stamps.hip); null in the product
 };
 
 __device__ inline int xcd_remap6(int b, int nwg) {
@@ -199,12 +202,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     const int m0 = tm * BM;
     const int n0 = tn * BN;
     X6_STAMP(0);
-#ifdef RELAX_X6_STAMPS
-    if (p.stamps && threadIdx.x == 0) {
-        p.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
-        p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
-    }
-#endif
+    X6_STAMP_IDS();
 
     // ---- DMA descriptors.  Piece j of this wave (global piece wave + NW*j) covers LDS bytes [piece*1024, +1024) of a
     // stage; lane l fills unit u = piece*64 + l = (tile row u/6, physical unit u%6); physical unit (plane q, half h')
@@ -809,36 +807,6 @@ __global__ __launch_bounds__(256) void splitk_finish_x6(const X6Params p) {
     if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lc, va, vb);
 }
 
-#ifdef RELAX_X6_STAMPS
-// diagnostic build only: per-tile cycle stamps of the launch that just ran (prologue / K loop / epilogue)
-template <int BM, int BN>
-static int x6_report_stamps(relax_handle* h, const X6Params& p, int units, hipStream_t s) {
-    RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
-    std::vector<unsigned long long> hs(8 * (size_t)units);
-    RELAX_HIP_CHECK(h, hipMemcpy(hs.data(), p.stamps, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
-    double d[3] = {0, 0, 0};
-    for (int u = 0; u < p.full_tiles; ++u) {
-        const unsigned long long* t = &hs[8 * (size_t)u];
-        d[0] += (double)(t[1] - t[0]);
-        d[1] += (double)(t[2] - t[1]);
-        d[2] += (double)(t[3] - t[2]);
-    }
-    if (const char* dump = getenv("RELAX_X6_STAMP_DUMP")) {   // raw records of every launch, appended
-        if (FILE* f = fopen(dump, "ab")) {
-            const int hdr[8] = {p.M, p.N, p.K, BM, BN, units, p.full_tiles, 0};
-            fwrite(hdr, sizeof(hdr), 1, f);
-            fwrite(hs.data(), sizeof(hs[0]), hs.size(), f);
-            fclose(f);
-        }
-    }
-    const double n = p.full_tiles > 0 ? p.full_tiles : 1;
-    fprintf(stderr, "x6 %dx%dx%d tile %dx%d act %d res %d sp3out %d: cycles per tile: prologue %.0f, K loop %.0f (%d steps, %.0f per step), "
-            "epilogue %.0f\n", p.M, p.N, p.K, BM, BN, p.act, p.residual != nullptr, p.out_sp3 != nullptr, d[0] / n, d[1] / n,
-            p.K / 16, d[1] / n / (p.K / 16), d[2] / n);
-    return RELAX_OK;
-}
-#endif
-
 template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false>
 static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
@@ -867,14 +835,9 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
         attr_set[h->device] = true;
     }
     const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
-#ifdef RELAX_X6_STAMPS
-    RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * 8 * (size_t)units));
-    p.stamps = static_cast<unsigned long long*>(h->scratch.p);
-#endif
+    X6_STAMPS_BEFORE_LAUNCH(h, p, units);
     hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32>), dim3(units), dim3(NT), lds, s, p);
-#ifdef RELAX_X6_STAMPS
-    RELAX_TRY((x6_report_stamps<BM, BN>(h, p, units, s)));
-#endif
+    X6_STAMPS_AFTER_LAUNCH(BM, BN, h, p, units, s);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((splitk_finish_x6<BM, BN>), dim3(BM * BN / 8 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
     RELAX_HIP_CHECK(h, hipGetLastError());

@@ -117,10 +117,8 @@ static_assert(KPAD * 16 % ATT_THREADS == 0, "K/V staging must divide evenly over
 
 typedef float att_f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool STAMPS>   // STAMPS: diagnostic instantiation (per-wave phase shares); the product kernel carries none of it
 __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                 int heads, int total_items, int ablate,
-                                                                 unsigned long long* __restrict__ stamps) {
+                                                                 int heads, int total_items) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* KV = smem;
     float* rowsum = smem + KPAD * KV_LD;
@@ -158,20 +156,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
             qf[q8] = *reinterpret_cast<const att_f32x4*>(q_ + 8 * q8) * (0.125f * 1.44269504088896341f);         \
     }
 
-    // diagnostic instantiation only (-DRELAX_ATT_STAMPS): per-wave cycle shares of the phases of one item
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long t_prev = 0;
-#define ATT_STAMP(i_)                                                  \
-    if (STAMPS) {                                                      \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
-        seg[i_] += t_ - t_prev;                                        \
-        t_prev = t_;                                                   \
-    }
     ATT_LOAD_KV(item, dim);
     ATT_LOAD_Q(item);
     ATT_STORE_KV();
     __syncthreads();
-    if (STAMPS) t_prev = __builtin_amdgcn_s_memtime();
 
     while (true) {
         ATT_LOAD_KV(item, 2 * dim);   // V of this item: in flight during the score phase
@@ -182,7 +170,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
             for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
             const float* kp = KV + (kt * 32 + li) * KV_LD + 4 * half;
 #pragma unroll
-            for (int q8 = 0; q8 < ((STAMPS && (ablate & 32)) ? 1 : 8); ++q8) {
+            for (int q8 = 0; q8 < 8; ++q8) {
                 const att_f32x4 kf = *reinterpret_cast<const att_f32x4*>(kp + 8 * q8);
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[q8].x, sacc[kt], 0, 0, 0);
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[q8].y, sacc[kt], 0, 0, 0);
@@ -190,7 +178,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[q8].w, sacc[kt], 0, 0, 0);
             }
         }
-        ATT_STAMP(0);   // score MFMAs
         // sacc[kt][r] = score(query li, key kt*32 + (r&3) + 8*(r>>2) + 4*half)
         float mx = -INFINITY;
 #pragma unroll
@@ -214,19 +201,17 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
             }
         sum += __shfl_xor(sum, 32);
         if (half == 0) rowsum[wave * 32 + li] = sum;
-        ATT_STAMP(1);   // softmax
         __syncthreads();          // every wave is done with K
         ATT_STORE_KV();           // V takes its place
         __syncthreads();
         const int next = item + gridDim.x;
         if (next < total_items) ATT_LOAD_KV(next, dim);   // K of the next item: in flight during the P V phase
-        ATT_STAMP(2);   // barrier + V store + barrier + issue K loads
 
         floatx16 oacc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
 #pragma unroll
-        for (int kt = 0; kt < ((STAMPS && (ablate & 16)) ? 1 : KTILES); ++kt)
+        for (int kt = 0; kt < KTILES; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -235,7 +220,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
                 oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r], v0, oacc[0], 0, 0, 0);
                 oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r], v1, oacc[1], 0, 0, 0);
             }
-        ATT_STAMP(3);   // P V MFMAs
         // oacc[dt][r] = O(query wave*32 + (r&3)+8*(r>>2)+4*half, d = dt*32 + li)
         float* ob = out + (int64_t)(item / heads) * NTOK * dim + (item % heads) * 64 + li;
 #pragma unroll
@@ -248,19 +232,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_197x64(const float* __r
                 ob[(int64_t)q * dim + 32] = oacc[1][r] * inv;
             }
         }
-        ATT_STAMP(4);   // output stores
         if (next >= total_items) break;
         ATT_LOAD_Q(next);
         __syncthreads();          // every wave is done with V (and with rowsum)
         ATT_STORE_KV();           // next item's K
         __syncthreads();
         item = next;
-        ATT_STAMP(5);   // Q loads + barrier + K store + barrier
     }
-    if (STAMPS && lane == 0) {
-        for (int i = 0; i < 6; ++i) stamps[((size_t)blockIdx.x * KTILES + wave) * 6 + i] = seg[i];
-    }
-#undef ATT_STAMP
 #undef ATT_LOAD_KV
 #undef ATT_STORE_KV
 #undef ATT_LOAD_Q
@@ -270,37 +248,15 @@ int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, in
     RELAX_REQUIRE(h, Nimg > 0 && heads > 0, "attention: Nimg=%d heads=%d", Nimg, heads);
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_197x64<false>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_197x64),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_LDS));
-#ifdef RELAX_ATT_STAMPS
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_197x64<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_LDS));
-#endif
         attr_set[h->device] = true;
     }
     const int total = Nimg * heads;
     // one persistent workgroup (7 waves, ~250 VGPRs) per CU
     const int grid = total < 256 ? total : 256;
-#ifdef RELAX_ATT_STAMPS   // diagnostic build only (tools/build_ablations.sh att_stamps[:mask]): per-wave phase shares, printed after a sync
-    {
-        RELAX_TRY(ensure_buf(h, h->scratch, sizeof(unsigned long long) * (size_t)grid * KTILES * 6));
-        unsigned long long* stamps = static_cast<unsigned long long*>(h->scratch.p);
-        hipLaunchKernelGGL(attention_197x64<true>, dim3(grid), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, total,
-                           RELAX_ATT_STAMPS & 56, stamps);
-        RELAX_HIP_CHECK(h, hipGetLastError());
-        RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
-        std::vector<unsigned long long> hs((size_t)grid * KTILES * 6);
-        RELAX_HIP_CHECK(h, hipMemcpy(hs.data(), stamps, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
-        double tot[6] = {0, 0, 0, 0, 0, 0};
-        for (size_t i = 0; i < hs.size(); ++i) tot[i % 6] += (double)hs[i];
-        const double n = (double)grid * KTILES * ((total + grid - 1) / grid);
-        fprintf(stderr, "attention phase cycles per wave per item: S %.0f softmax %.0f sync+Vstore %.0f PV %.0f stores %.0f Q+sync+Kstore %.0f\n",
-                tot[0] / n, tot[1] / n, tot[2] / n, tot[3] / n, tot[4] / n, tot[5] / n);
-    }
-#else
-    hipLaunchKernelGGL(attention_197x64<false>, dim3(grid), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, total, 0, nullptr);
+    hipLaunchKernelGGL(attention_197x64, dim3(grid), dim3(ATT_THREADS), ATT_LDS, s, qkv, out, heads, total);
     RELAX_HIP_CHECK(h, hipGetLastError());
-#endif
     return RELAX_OK;
 }
 

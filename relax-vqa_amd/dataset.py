@@ -245,15 +245,20 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         else:
             local[torch.as_tensor(slots, device=dev)] = vecs
         if frames is not None:
+            # a per-frame file that cannot be written (disk full, permissions) costs its own clip an entry in the error list, like
+            # any other per-clip failure: the row stays (it was computed), the run goes on and every rank still reaches the all-gather
             for i, rows in zip(idxs, frames):
                 arr = rows.cpu().numpy()
                 if pool is not None:
-                    writes.append(pool.submit(sampling.save_clip_features, out_dir, i, network_name, arr))
+                    writes.append((i, pool.submit(sampling.save_clip_features, out_dir, i, network_name, arr)))
                 else:
-                    sampling.save_clip_features(out_dir, i, network_name, arr)
+                    try:
+                        sampling.save_clip_features(out_dir, i, network_name, arr)
+                    except Exception as e:              # noqa: BLE001
+                        errors.append((i, f"per-frame file not written: {type(e).__name__}: {e}"))
 
     def load(i):
-        """One clip, in a loader thread (or inline when prefetch = 0) -> ("row", mean vector) | ("clip", tensor, pinned buffer) |
+        """One clip, in a loader thread (or inline when prefetch = 0) -> ("rows", the stored per-frame rows of a finished clip) | ("clip", tensor, pinned buffer) |
         ("err", message).  Never raises."""
         try:
             if out_dir is not None and skip_existing:
@@ -261,8 +266,8 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
                 if os.path.exists(path):
                     try:
                         rows = np.load(path)
-                        if rows.ndim == 2 and rows.shape[1] == F and rows.shape[0] > 0:
-                            return ("row", rows.mean(axis=0).astype(np.float32))
+                        if rows.ndim == 2 and rows.shape[1] == F and rows.shape[0] > 0 and rows.dtype == np.float32:
+                            return ("rows", np.ascontiguousarray(rows))
                     except Exception:                   # noqa: BLE001 - truncated / foreign file: recompute and overwrite it
                         pass
             clip = get(i)
@@ -306,8 +311,11 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
             loader_wait += time.perf_counter() - t_w
             if r[0] == "err":
                 errors.append((i, r[1]))
-            elif r[0] == "row":
-                local[slot] = torch.from_numpy(r[1]).to(dev)
+            elif r[0] == "rows":
+                # resume: the stored per-frame rows go through the SAME reduction as freshly computed ones (relax_segment_mean on
+                # the device), so a resumed row is the bits of the row the first run produced (extract_npy2mat.py:121-126 is the
+                # reference's host-side mean of the same files)
+                local[slot] = engine.rows_mean(torch.from_numpy(r[1]).to(dev))
             else:
                 slots.append(slot)
                 idxs.append(i)
@@ -352,8 +360,11 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
                     stager.done_with(token)
                     stager.copies_landed(token)
                     stager.give_back(pinned)
-        for w in writes:
-            w.result()
+        for i, w in writes:
+            try:
+                w.result()
+            except Exception as e:                          # noqa: BLE001
+                errors.append((i, f"per-frame file not written: {type(e).__name__}: {e}"))
         torch.cuda.synchronize(dev) if on_gpu else None
         t1 = time.perf_counter()
     finally:

@@ -388,6 +388,14 @@ class RelaxEngine:
             return out
         return out, self._per_frame_rows(blocks, counts)
 
+    def rows_mean(self, rows):
+        """fp32 [T, F] device tensor of per-frame rows -> their mean [F], by the same kernel (relax_segment_mean: the rows of a
+        column added in order, one division) that reduces freshly computed rows: the dataset driver's resume path uses it so that
+        a row rebuilt from the per-frame files is bit-identical to the one the first run returned."""
+        rows = rows.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty((1, rows.shape[1]), dtype=torch.float32, device=self.device)
+        return self._segment_means(out, [(rows, 0, 0)], [int(rows.shape[0])])[0]
+
     @staticmethod
     def _per_frame_rows(blocks, counts):
         """blocks as for _segment_means -> per clip the [T, F] matrix of its frames (file output only: aten copies)."""
@@ -422,8 +430,9 @@ class RelaxEngine:
         whole_frames: optional list of uint8 [Ts,H,W,3] per clip - ALL sampled frames (src/demo_test.py:76-87 averages the
         whole-frame features over every sampled frame, including a last one that has no `next` partner and therefore no
         pair); default: the first frame of every pair.
-        = full_features(full_prepare(...)): the two halves can run on different streams (full_prepare is byte / HBM work -
-        fragments, Farneback flow, resizes -, full_features the contractions), see FullPipeline."""
+        = full_features(full_prepare(...)): full_prepare is the byte / HBM work (fragments, Farneback flow, resizes), full_features
+        the contractions.  Running the two halves of consecutive batches on two streams was measured at 1.01 x
+        (tools/flow_overlap_try.py) and is not done in the product; the split stays because the dataset driver stages on it."""
         return self.full_features(self.full_prepare(clips, flow=flow, flow_images=flow_images, whole_frames=whole_frames))
 
     def full_prepare(self, clips, flow=True, flow_images=None, whole_frames=None):

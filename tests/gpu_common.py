@@ -6,9 +6,10 @@ import relax_vqa_amd  # noqa: F401
 from relax_vqa_amd import synth
 from relax_vqa_amd.engine import RelaxEngine
 
-# north_star tolerance: features within 1e-3 relative fp32.  The engine computes in exact fp32 (fp32 MFMA), so
-# the element-wise check below uses rtol 1e-3 with an absolute floor of 1e-4 x the block's mean magnitude
-# (features that are exactly ~0 after ReLU have no meaningful relative error).
+# north_star tolerance: features within 1e-3 relative fp32.  The engine's contractions run in one of its fp32-grade arithmetics
+# (`each_precision` in conftest.py runs a test under each: split operands on the 16-bit matrix cores with fp32 accumulation - the
+# default -, or the exact fp32 MFMA); the element-wise check below uses rtol 1e-3 with an absolute floor of 1e-4 x the block's mean
+# magnitude (features that are exactly ~0 after ReLU have no meaningful relative error).
 RTOL = 1e-3
 ATOL_FRAC = 1e-4
 

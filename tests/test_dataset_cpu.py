@@ -31,6 +31,9 @@ class FakeEngine:
         base = c.reshape(c.shape[0], -1).mean(dim=1, keepdim=True)
         return (base * torch.arange(1, F + 1, dtype=torch.float64)).to(torch.float32)
 
+    def rows_mean(self, rows):
+        return rows.mean(dim=0)   # the reduction clip_vectors below applies to fresh rows
+
     def clip_vectors(self, clips, resnet=True, vit=True, per_frame=False):
         self.batches.append(len(clips))
         for c in clips:
@@ -95,7 +98,29 @@ def test_single_rank_ragged_clips_failures_files_and_resume(tmp_path):
     again, errors2 = dataset.extract_dataset_clips(_clip, n, eng2, clips_per_step=4, out_dir=out_dir, skip_existing=True,
                                                    rank=0, world=1)
     assert sum(eng2.batches) == 1 and [i for i, _ in errors2] == [3, 5, 6]      # only clip 5 reaches the engine (and fails)
-    assert np.allclose(again.numpy(), want, equal_nan=True)
+    assert np.array_equal(again.numpy(), matrix.numpy(), equal_nan=True)   # resumed rows: the bits of the first run's rows
+
+
+@pytest.mark.parametrize("prefetch", [0, 2])
+def test_a_per_frame_file_that_cannot_be_written_costs_only_its_clip(tmp_path, monkeypatch, prefetch):
+    """A failing save_clip_features (disk full, permissions) becomes that clip's error entry - inline and from the writer pool - and the
+    pass still returns every row and reaches the collective (a raise here would leave the other ranks waiting in the all-gather)."""
+    _patched()
+    real = sampling.save_clip_features
+
+    def flaky(out_dir, i, network_name, arr):
+        if i == 2:
+            raise OSError(28, "No space left on device")
+        return real(out_dir, i, network_name, arr)
+
+    monkeypatch.setattr(sampling, "save_clip_features", flaky)
+    healthy = lambda i: _clip([0, 1, 2, 4, 7, 8][i])            # noqa: E731 - none of the poisoned clips
+    matrix, errors = dataset.extract_dataset_clips(healthy, 6, FakeEngine(), clips_per_step=4, out_dir=str(tmp_path / "f"),
+                                                   network_name="resnet50", rank=0, world=1, prefetch=prefetch)
+    assert [i for i, _ in errors] == [2] and "per-frame file not written" in errors[0][1] and "No space left" in errors[0][1]
+    assert not torch.isnan(matrix).any()                        # the row itself was computed
+    assert not os.path.exists(os.path.join(str(tmp_path / "f"), sampling.feature_file_name(2, "resnet50")))
+    assert os.path.exists(os.path.join(str(tmp_path / "f"), sampling.feature_file_name(3, "resnet50")))
 
 
 def test_sequence_input_and_empty_shards():

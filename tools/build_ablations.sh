@@ -1,16 +1,16 @@
 #!/bin/bash
-# Builds diagnostic copies of the library into tools/abl/ (never the product build):
-#   tools/build_ablations.sh <n> ...        bf16x3 loop ablations (-DRELAX_X3_ABLATE=n, WRONG results)
-#   tools/build_ablations.sh f32:<n>        fp32 loop ablations (-DRELAX_F32_ABLATE=n, WRONG results)
-#   tools/build_ablations.sh stamps         fp32 / bf16x3 kernel with per-phase timestamps
+# Builds diagnostic copies of the library into tools/abl/ (never the product build).  The product sources carry only empty stamp hooks
+# and no ablation switches: a diagnostic kernel exists in the variant translation units tools/abl/*_stamps.hip alone (each defines the
+# hooks and #includes the product file), so no -D on the product build can make librelax_hip.so record stamps or return wrong numbers.
 #   tools/build_ablations.sh x6stamps       bf16x6 kernel with per-phase cycle stamps (prints per launch, syncs)
-#   (the bf16x6 loop ablations of round 2 - RELAX_X6_ABLATE - were deleted from gemm_x6.hip in round 3 together with the other
-#    experiment branches; their measurements are in DESIGN.md section 3.2 and the code is in the history: commit a51794b)
-#   tools/build_ablations.sh att_stamps     fp32 attention kernel with per-phase cycle shares
 #   tools/build_ablations.sh flowstamps     fused Farneback iteration with tick stamps per phase of a step (tools/flow_stamps.py prints them)
-#   tools/build_ablations.sh flow:<mask>    fused Farneback iteration without parts of its work (-DRELAX_FLOW_ABLATE=mask, WRONG results, timing only)
-#   tools/build_ablations.sh a6stamps       bf16x6 attention kernel with ticks per phase of an item (tools/attn_stamps.py prints them)
-# use: RELAX_HIP_LIB=tools/abl/librelax_<name>.so python tools/gemm_bench.py ...
+#   tools/build_ablations.sh a6stamps       bf16x6 attention kernel with ticks per phase of an item (tools/attn_stamps.py prints them;
+#                                           overwrites the first floats of the fp32 output: timing only)
+# The loop ablations of rounds 1 - 4 (RELAX_X3_ABLATE, RELAX_F32_ABLATE, RELAX_X6_ABLATE, RELAX_FLOW_ABLATE: WRONG results, timing only)
+# and the stamps of the fp32-option kernels were deleted from the sources in rounds 3 and 5; their measurements are in LAB_NOTES.md and
+# profiles/, the code in the history (commits a51794b, d58970c).
+# use: RELAX_HIP_LIB=tools/abl/librelax_<name>.so python tools/gemm_bench.py ...   (tools/abl/*.so is not shipped to the GPU box by
+# gpurun - .gpurunignore - build it there: tools/build_ablations.sh <name> as the first step of the command)
 set -e
 cd "$(dirname "$0")/../relax-vqa_amd/csrc"
 make -s
@@ -23,13 +23,9 @@ link() {  # link <replaced object> <new object> <output name>
 }
 for n in "$@"; do
   case "$n" in
-    stamps) $CC -DRELAX_GEMM_STAMPS -c gemm.hip -o /tmp/gemm_stamps.o; link gemm.o /tmp/gemm_stamps.o stamps ;;
-    x6stamps) $CC -DRELAX_X6_STAMPS -c gemm_x6.hip -o /tmp/gemm_x6_stamps.o; link gemm_x6.o /tmp/gemm_x6_stamps.o x6stamps ;;
-    f32:*) $CC -DRELAX_F32_ABLATE=${n#f32:} -c gemm.hip -o /tmp/gemm_f32abl.o; link gemm.o /tmp/gemm_f32abl.o f32abl${n#f32:} ;;
-    att_stamps) $CC -DRELAX_ATT_STAMPS=0 -c layers.hip -o /tmp/layers_stamps.o; link layers.o /tmp/layers_stamps.o att_stamps ;;
-    flowstamps) $FLOWCC -DRELAX_FLOW_STAMPS -c flow.hip -o /tmp/flow_stamps.o; link flow.o /tmp/flow_stamps.o flowstamps ;;
-    flow:*) $FLOWCC -DRELAX_FLOW_ABLATE=${n#flow:} -c flow.hip -o /tmp/flow_abl${n#flow:}.o; link flow.o /tmp/flow_abl${n#flow:}.o flowabl${n#flow:} ;;
-    a6stamps) $CC -DRELAX_A6_STAMPS -c attention_x6.hip -o /tmp/attention_x6_stamps.o; link attention_x6.o /tmp/attention_x6_stamps.o a6stamps ;;
-    *) $CC -DRELAX_X3_ABLATE=$n -c gemm.hip -o /tmp/gemm_abl$n.o; link gemm.o /tmp/gemm_abl$n.o abl$n ;;
+    x6stamps) $CC -I. -c ../../tools/abl/gemm_x6_stamps.hip -o /tmp/gemm_x6_stamps.o; link gemm_x6.o /tmp/gemm_x6_stamps.o x6stamps ;;
+    flowstamps) $FLOWCC -I. -c ../../tools/abl/flow_stamps.hip -o /tmp/flow_stamps.o; link flow.o /tmp/flow_stamps.o flowstamps ;;
+    a6stamps) $CC -I. -c ../../tools/abl/attention_x6_stamps.hip -o /tmp/attention_x6_stamps.o; link attention_x6.o /tmp/attention_x6_stamps.o a6stamps ;;
+    *) echo "unknown diagnostic build: $n" >&2; exit 2 ;;
   esac
 done
