@@ -157,7 +157,7 @@ int relax_create(int device, relax_handle** out) {
     relax_handle* h = new relax_handle();
     h->device = device;
     if (const char* e = getenv("RELAX_GEMM_SPLIT")) h->gemm.split_k = atoi(e);
-    if (const char* e = getenv("RELAX_GEMM_PRECISION")) h->gemm.precision = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;
+    if (const char* e = getenv("RELAX_GEMM_PRECISION")) h->gemm.precision = atoi(e) >= 0 && atoi(e) <= 3 ? atoi(e) : 0;
     if (const char* e = getenv("RELAX_GEMM_VARIANT")) h->gemm.variant = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_VARIANT_N64")) h->gemm.variant_n64 = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_GROUP_M")) h->gemm.group_m = atoi(e) > 0 ? atoi(e) : 1;
@@ -213,7 +213,7 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     const std::string k(key);
     if (k == "gemm_split_k") h->gemm.split_k = value;
     else if (k == "gemm_precision") {
-        RELAX_REQUIRE(h, value >= 0 && value <= 2, "relax_set_option: gemm_precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16x6)");
+        RELAX_REQUIRE(h, value >= 0 && value <= 3, "relax_set_option: gemm_precision must be 0 (fp32), 1 (bf16x3), 2 (bf16x6) or 3 (f16x2)");
         h->gemm.precision = value;
     }
     else if (k == "gemm_variant") h->gemm.variant = value;
@@ -224,6 +224,10 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     else if (k == "flow_seg_rows") h->gemm.flow_seg_rows = value > 0 ? value : 0;
     else if (k == "flow_pyramid_fused") h->gemm.flow_pyramid_fused = value != 0;
     else if (k == "x6_fp32_rows") h->gemm.fp32_rows = value != 0;
+    else if (k == "h2_stages") {
+        RELAX_REQUIRE(h, value == 3 || value == 4, "relax_set_option: h2_stages must be 3 or 4");
+        h->gemm.h2_stages = value;
+    }
     else if (k == "debug_poison") h->gemm.debug_poison = value != 0;
     else {
         set_error(h, "relax_set_option: unknown option '%s'", key);
@@ -255,6 +259,7 @@ int relax_get_option(relax_handle* h, const char* key, int* value) {
     else if (k == "flow_seg_rows") *value = h->gemm.flow_seg_rows;
     else if (k == "flow_pyramid_fused") *value = h->gemm.flow_pyramid_fused;
     else if (k == "x6_fp32_rows") *value = h->gemm.fp32_rows;
+    else if (k == "h2_stages") *value = h->gemm.h2_stages;
     else if (k == "debug_poison") *value = h->gemm.debug_poison;
     else {
         set_error(h, "relax_get_option: unknown option '%s'", key);
@@ -280,12 +285,12 @@ int relax_profile_enable(relax_handle* h, int on) {
 
 int relax_profile_read(relax_handle* h, int kind, double* total_ms, double* total_work, int64_t* launches) {
     if (!h) return RELAX_ERR_INVALID;
-    RELAX_REQUIRE(h, kind >= 0 && kind <= 6, "relax_profile_read: kind must be 0..6");
+    RELAX_REQUIRE(h, kind >= 0 && kind <= 8, "relax_profile_read: kind must be 0..8");
     RELAX_TRY(prof_drain(h));
     // read kind -> (span kind, which total): 2 and 4 return the algorithmic HBM bytes of the contraction launches
-    static const int span_of[7] = {0, 1, 0, 2, 2, 3, 4};
+    static const int span_of[9] = {0, 1, 0, 2, 2, 3, 4, 5, 5};
     const int k = span_of[kind];
-    const bool bytes = kind == 2 || kind == 4;
+    const bool bytes = kind == 2 || kind == 4 || kind == 8;
     if (total_ms) *total_ms = h->prof.total_ms[k];
     if (total_work) *total_work = bytes ? h->prof.total_bytes[k] : h->prof.total_work[k];
     if (launches) *launches = h->prof.launches[k];

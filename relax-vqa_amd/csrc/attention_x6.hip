@@ -16,6 +16,7 @@
 // every lane 8 consecutive d of its query, i.e. whole 16-byte units.
 #include "relax_internal.h"
 #include "sp3.h"
+#include "h2.h"
 
 // Phase-stamp hooks of the diagnostic build: empty in the product.  tools/abl/attention_x6_stamps.hip defines them and #includes this
 // file (its flush overwrites the first floats of the fp32 output with the averages: a diagnostic library, never the product).
@@ -53,9 +54,9 @@ constexpr int A6_DMA_PIECES = A6_STG_ROWS * 256 / 1024;   // 50 pieces of 4 rows
 
 __device__ inline a6_bf16x8 as_frag(const a6_u32x4 v) { return __builtin_bit_cast(a6_bf16x8, v); }
 
-template <bool OUT_SP3, bool OUT_F32>
+template <int OUT_PLANES, bool OUT_F32>   // OUT_PLANES: 0 none, 1 split planes (three bf16), 2 two fp16 planes of value * out_scale (csrc/h2.h)
 __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restrict__ qkv, float* __restrict__ out,
-                                                           char* __restrict__ out_sp3, int heads, int total_items) {
+                                                           char* __restrict__ out_sp3, int heads, int total_items, float out_scale) {
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (no __amdgpu_buffer_rsrc_t there)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
                         hi4 = (a6_f32x4){own[8 * u + 4], own[8 * u + 5], own[8 * u + 6], own[8 * u + 7]};
                     }
                     const int d0 = (item % heads) * 64 + dt * 32 + 16 * u + 8 * half;
-                    if (OUT_SP3) store_sp3_x8(out_sp3 + orow * ((int64_t)dim * 6), d0, lo4, hi4);
+                    if (OUT_PLANES == 1) store_sp3_x8(out_sp3 + orow * ((int64_t)dim * 6), d0, lo4, hi4);
+                    if (OUT_PLANES == 2) store_h2_x8(out_sp3 + orow * ((int64_t)dim * 4), d0, lo4, hi4, out_scale);
                     if (OUT_F32) {
                         *reinterpret_cast<a6_f32x4*>(out + orow * dim + d0) = lo4;
                         *reinterpret_cast<a6_f32x4*>(out + orow * dim + d0 + 4) = hi4;
@@ -325,27 +327,33 @@ __global__ __launch_bounds__(A6_THREADS) void attention_x6(const float* __restri
 #endif
 }
 
-int launch_attention_x6(relax_handle* h, const float* qkv, float* out, void* out_sp3, int Nimg, int heads, hipStream_t s) {
-    RELAX_REQUIRE(h, Nimg > 0 && heads > 0 && (out || out_sp3), "attention_x6: Nimg=%d heads=%d", Nimg, heads);
+int launch_attention_x6(relax_handle* h, const float* qkv, float* out, void* out_planes, int Nimg, int heads, hipStream_t s,
+                        float out_h2_scale) {
+    RELAX_REQUIRE(h, Nimg > 0 && heads > 0 && (out || out_planes), "attention_x6: Nimg=%d heads=%d", Nimg, heads);
+    RELAX_REQUIRE(h, !(out_h2_scale > 0.f) || (out_planes && !out), "attention_x6: the fp16-plane output goes alone");
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_x6<true, false>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_x6<1, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, A6_LDS_TOTAL));
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_x6<false, true>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_x6<0, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, A6_LDS_TOTAL));
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_x6<true, true>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_x6<1, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, A6_LDS_TOTAL));
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_x6<2, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, A6_LDS_TOTAL));
         attr_set[h->device] = true;
     }
     const int total = Nimg * heads;
     const int grid = total < 256 ? total : 256;   // one persistent workgroup (7 waves) per CU
-    char* o6 = static_cast<char*>(out_sp3);
-    if (out && o6)
-        hipLaunchKernelGGL((attention_x6<true, true>), dim3(grid), dim3(A6_THREADS), A6_LDS_TOTAL, s, qkv, out, o6, heads, total);
+    char* o6 = static_cast<char*>(out_planes);
+    if (out_h2_scale > 0.f)
+        hipLaunchKernelGGL((attention_x6<2, false>), dim3(grid), dim3(A6_THREADS), A6_LDS_TOTAL, s, qkv, out, o6, heads, total, out_h2_scale);
+    else if (out && o6)
+        hipLaunchKernelGGL((attention_x6<1, true>), dim3(grid), dim3(A6_THREADS), A6_LDS_TOTAL, s, qkv, out, o6, heads, total, 1.f);
     else if (o6)
-        hipLaunchKernelGGL((attention_x6<true, false>), dim3(grid), dim3(A6_THREADS), A6_LDS_TOTAL, s, qkv, out, o6, heads, total);
+        hipLaunchKernelGGL((attention_x6<1, false>), dim3(grid), dim3(A6_THREADS), A6_LDS_TOTAL, s, qkv, out, o6, heads, total, 1.f);
     else
-        hipLaunchKernelGGL((attention_x6<false, true>), dim3(grid), dim3(A6_THREADS), A6_LDS_TOTAL, s, qkv, out, o6, heads, total);
+        hipLaunchKernelGGL((attention_x6<0, true>), dim3(grid), dim3(A6_THREADS), A6_LDS_TOTAL, s, qkv, out, o6, heads, total, 1.f);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }

@@ -632,7 +632,25 @@ int relax_op_gemm(relax_handle* h, const float* A, const float* W, const float* 
     RELAX_REQUIRE(h, act >= 0 && act <= 2, "relax_op_gemm: act=%d", act);
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (h->gemm.precision == 2) {
+    if (h->gemm.precision == 3 && N % 256 == 0 && K % 16 == 0) {
+        // operator-level entry under "f16x2": both operands are converted to two fp16 planes here, each ROW scaled by the power of two
+        // that puts its own maximum into [2^14, 2^15) (no static bound on an arbitrary A: csrc/h2.h); the inverse scales go to the
+        // epilogue as rowscale / colscale.  (The model drivers keep weights and activations in the format, with static scales.)
+        const size_t a_bytes = (size_t)M * K * 4, w_bytes = (size_t)N * K * 4;
+        const size_t a_al = (a_bytes + 255) & ~(size_t)255, w_al = (w_bytes + 255) & ~(size_t)255, m_al = ((size_t)M * 4 + 255) & ~(size_t)255;
+        RELAX_TRY(ensure_buf(h, h->sp3_ws, a_al + w_al + m_al + (size_t)N * 4 + 256));
+        char* As = static_cast<char*>(h->sp3_ws.p);
+        char* Ws = As + a_al;
+        float* rs = reinterpret_cast<float*>(Ws + w_al);
+        float* cs = reinterpret_cast<float*>(Ws + w_al + m_al);
+        RELAX_TRY(launch_to_h2_rows(h, A, K, As, M, K, rs, s));
+        RELAX_TRY(launch_to_h2_rows(h, W, K, Ws, N, K, cs, s));
+        GemmDescH2 d{};
+        d.a = As; d.w = Ws; d.colscale = cs; d.rowscale = rs; d.bias = bias; d.residual = residual; d.out = out;
+        d.M = M; d.N = N; d.K = K; d.act = act;
+        return launch_gemm_h2(h, d, s);
+    }
+    if (h->gemm.precision >= 2) {
         // operator-level entry under "bf16x6": both operands are converted to split planes here (the model drivers
         // keep weights and activations in that format instead)
         RELAX_REQUIRE(h, K % 16 == 0, "relax_op_gemm (bf16x6): K=%d must be a multiple of 16", K);
@@ -674,7 +692,7 @@ int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const
     hipStream_t s = static_cast<hipStream_t>(stream);
     // bf16x6 where the split-plane kernel takes the geometry (16-channel chunks, at most 32 taps, 64-column tiles); anything
     // else - e.g. a 7x7 filter, Cin = 8 - runs on the exact-fp32 kernel as it did before bf16x6 became the default
-    if (h->gemm.precision == 2 && Cin % 16 == 0 && d.Kpad == KH * KW * Cin && KH * KW <= 32 && Cout % 64 == 0 &&
+    if (h->gemm.precision >= 2 && Cin % 16 == 0 && d.Kpad == KH * KW * Cin && KH * KW <= 32 && Cout % 64 == 0 &&
         (KH * KW > 1 || pad == 0)) {
         // operator-level entry under "bf16x6": input and weights are converted to split planes here
         // (1x1 stride-1 convolutions onto 64 / 128 channels: the kernel splits the fp32 pixels in its K loop)

@@ -1,0 +1,537 @@
+// "f16x2": the fp32-grade contraction kernel on the fp16 matrix cores of gfx950 (gemm_precision 3; plain GEMMs with N % 256 == 0:
+// every GEMM of the ViT).
+//
+//   out[m, n] = act( (sum_k A'[m, k] * W'[n, k]) * colscale[n] * rowscale[m] + bias[n] + residual[m, n] )
+//
+// Every fp32 operand is held as TWO fp16 numbers of a power-of-two multiple of itself (csrc/h2.h): A'[m,k] = A[m,k] * sa = ah + al,
+// W'[n,k] = W[n,k] * t_n = bh + bl, 22 significant bits each.  v_mfma_f32_16x16x32_f16 contracts 32 deep; a chunk holds 16 k - so the
+// 32-deep K of ONE instruction takes BOTH planes of the chunk, and
+//        A[hi|lo] . B[lo|lo] = ah bl + al bl            A[hi|lo] . B[hi|hi] = ah bh + al bh              (smallest first)
+// are ALL FOUR partial products in two instructions per 16 x 16 outputs and 16 k (bf16x6: six products in three), every fp16 x fp16
+// product exact in the fp32 accumulator, which is rounded once per instruction.  The sum is multiplied by 2^-(t_n + e_a) in the epilogue
+// (a power of two: exact).  4 bytes per operand value instead of 6: a third fewer matrix-pipe cycles, DMA pieces, LDS bytes and
+// fragment reads per fp32 product than gemm_x6.hip.  Measured (tools/micro/mfma_f16x2.hip, profiles/r05_mfma_f16x2.txt): the error
+// against the exact product of the fp32 operands is BELOW the fp32 FMA chain's at every K (8.9e-8 / 2.8e-7 / 5.5e-7 at K = 32 / 768 /
+// 3072; chain 9.0e-8 / 4.4e-7 / 8.8e-7; bf16x6 6.7e-8 / 3.7e-7 / 7.6e-7), fp16 subnormal operands are kept by the instruction,
+// and the LDS-fed loop runs 1.46 x the algorithmic rate of the bf16x6 loop at the same executed PFLOP/s (the part is power-limited).
+//
+// Range.  fp16 has 5 exponent bits: a value is representable with its 22 bits for 2^-3 <= |x * s| < 65504, with an absolute error of
+// 2^-25 / s below that window - harmless, the errors of a dot product add absolutely and the row's large terms carry 2^-22 of their
+// own size - and NOT AT ALL above it.  So the scale of every tensor comes from a bound that holds for every input:
+//   * weights: per output row, from the row's own maximum, at load time (max |W'| in [2^14, 2^15));
+//   * ViT activations: one static power of two per tensor (host_logic.h: LayerNorm outputs are bounded by sqrt(dim - 1) |gamma| +
+//     |beta| whatever the input; the outputs of a Linear behind a LayerNorm by Cauchy-Schwarz; attention outputs are convex
+//     combinations of V rows; |GELU(x)| <= |x|; patch pixels are in [0, 1]).  The bounds are 5 - 8 binades above the typical value, the
+//     window is 19 binades wide.  No data-dependent scale: a row's bits do not depend on the batch, and nothing can overflow;
+//   * operator-level entry points (relax_op_gemm): per row of A from that row's maximum (to_h2_rows), again batch-invariant.
+// Non-finite inputs stay non-finite (inf - inf in the lo plane gives NaN), as on the other paths.
+//
+// Structure: the M16 loop of gemm_x6.hip on 64-byte rows.  256 x 256 tile on 8 waves (2 x 4, 128 x 64 per wave, one workgroup per CU),
+// BK = 16, NSTG LDS stages of 512 rows x 64 B = 32 KB filled by LDS-DMA (4 pieces of 1 KiB per wave and step, issued one per MFMA
+// group: the texture-address FIFO argument of gemm_x6.hip), counted s_waitcnt vmcnt, one raw s_barrier per step; B (2 forms x 4
+// fragments) double-buffered in registers across steps, A (ONE form) streamed one 16-row fragment at a time: 16 ds_read_b128 and 64
+// MFMAs per wave and step.  LDS image of a stage: the hi planes of the 512 rows as [row][32 B], then their lo planes the same way, 16 KB
+// further.  With 32-byte rows the 16-lane groups of a ds_read_b128 touch every bank once for all three read patterns with NO
+// permutation (8 rows span the 64 banks; a group holds rows {0-3, 12-15} at one 16-byte half and rows {4-11} at the other), the
+// lo fragment of a row is the hi fragment's address + 16384 (an immediate offset: one address register per operand), and a DMA
+// piece is 32 rows of one plane: the hi and the lo piece of the same rows share their per-lane source offset (the plane is +32 B in
+// the scalar offset).
+// Epilogue, tail split-K, XCD remap and tile grouping as gemm_x6.hip.
+#include "relax_internal.h"
+#include "host_logic.h"
+#include "h2.h"
+#include "gelu.h"
+
+// Phase-stamp hooks of the diagnostic build: empty in the product (tools/abl/gemm_h2_stamps.hip defines them and #includes this file).
+#ifndef H2_STAMP
+#define H2_STAMP(i_)
+#define H2_STAMPS_BEFORE_LAUNCH(h_, p_, units_)
+#define H2_STAMPS_AFTER_LAUNCH(h_, p_, units_, s_)
+#endif
+
+namespace relax {
+
+typedef float h2k_f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2k_f16x8 __attribute__((ext_vector_type(8)));
+
+// ---- conversions ---------------------------------------------------------------------------------------------------------
+// fp32 [rows][K] (row stride ld floats) -> h2 [rows][K*4 B] with value * scale * row_scale[row] (either factor optional); one
+// thread per 8 values
+__global__ __launch_bounds__(256) void to_h2_kernel(const float* __restrict__ x, int64_t ld, char* __restrict__ y, int K, int64_t total8,
+                                                    float scale, const float* __restrict__ row_scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int k8 = K >> 3;
+    const int64_t row = i / k8;
+    const int k = (int)(i - row * k8) * 8;
+    const float* s = x + row * ld + k;
+    const float f = row_scale ? scale * row_scale[row] : scale;
+    store_h2_x8(y + row * (int64_t)K * 4, k, *reinterpret_cast<const h2k_f32x4*>(s), *reinterpret_cast<const h2k_f32x4*>(s + 4), f);
+}
+
+// the same with the scale taken from the row itself: one wave per row, scale = the power of two that puts the row's maximum into
+// [2^14, 2^15); inv_scale[row] = 1 / scale goes to the GEMM epilogue (operator-level entry points: no static bound on A there)
+__global__ __launch_bounds__(256) void to_h2_rows_kernel(const float* __restrict__ x, int64_t ld, char* __restrict__ y, int K, int rows,
+                                                         float* __restrict__ inv_scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;   // wave-uniform
+    const float* s = x + (int64_t)row * ld;
+    float m = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const h2k_f32x4 a = *reinterpret_cast<const h2k_f32x4*>(s + k), b = *reinterpret_cast<const h2k_f32x4*>(s + k + 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float sc = h2_scale_for(m);
+    if (lane == 0) inv_scale[row] = 1.f / sc;
+    char* d = y + (int64_t)row * K * 4;
+    for (int k = lane * 8; k < K; k += 512)
+        store_h2_x8(d, k, *reinterpret_cast<const h2k_f32x4*>(s + k), *reinterpret_cast<const h2k_f32x4*>(s + k + 4), sc);
+}
+
+int launch_to_h2(relax_handle* h, const float* x, int64_t ld, void* y, int64_t rows, int K, float scale, const float* row_scale,
+                 hipStream_t s) {
+    RELAX_REQUIRE(h, K % 16 == 0 && ld % 4 == 0 && rows > 0, "to_h2: K=%d must be a multiple of 16 (ld %lld)", K, (long long)ld);
+    const int64_t total8 = rows * (K / 8);
+    hipLaunchKernelGGL(to_h2_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, x, ld, static_cast<char*>(y), K, total8,
+                       scale, row_scale);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+int launch_to_h2_rows(relax_handle* h, const float* x, int64_t ld, void* y, int rows, int K, float* inv_scale, hipStream_t s) {
+    RELAX_REQUIRE(h, K % 16 == 0 && ld % 4 == 0 && rows > 0, "to_h2_rows: K=%d must be a multiple of 16 (ld %lld)", K, (long long)ld);
+    hipLaunchKernelGGL(to_h2_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ld, static_cast<char*>(y), K, rows, inv_scale);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------------------------
+struct H2Params {
+    const char* a;           // h2 activations [M][K*4 B]
+    const char* w;           // h2 weights [N][K*4 B]
+    const float* colscale;   // [N]: 2^-(t_n + e_a), the inverse of (weight row scale x static activation scale)
+    const float* rowscale;   // [M]: the inverse of a per-row activation scale (operator level), or null
+    const float* bias;
+    const float* residual;   // fp32 [M][N] or null
+    float* out;              // fp32 [M][N] or null
+    char* out_h2;            // h2 [M][N*4 B] or null, values scaled by out_scale
+    float out_scale;
+    float* partial;          // split-K partial tiles
+    int M, N, K;
+    int act;
+    int no_split;
+    int tiles_m, tiles_n, ntiles, group_m;
+    int full_tiles, nsplit;
+    unsigned long long* stamps;   // diagnostic builds only; null in the product
+};
+
+__device__ inline int xcd_remap_h2(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+#define H2_DMA(rsrc_, lds_off_, voff_, soff_)                                                                             \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_, (__attribute__((address_space(3))) void*)(smem + (lds_off_)), 16,     \
+                                             voff_, soff_, 0, 0)
+[[maybe_unused]] constexpr unsigned kH2OutOfRange = 0x80000000u;   // > every num_records below: the DMA writes zeros for that lane
+constexpr int64_t kH2MaxRecords = 0x7ffffff0;
+
+constexpr int H2_BM = 256, H2_BN = 256;
+constexpr int H2_STAGE = (H2_BM + H2_BN) * kH2ChunkBytes;   // 32 KB
+constexpr int H2_PIECES = H2_STAGE / 1024;                  // 32
+[[maybe_unused]] constexpr int H2_PPW = H2_PIECES / 8;                       // 4 per wave: 2 activation pieces, 2 weight pieces
+
+template <int NSTG>
+__global__ __launch_bounds__(512, 2) void gemm_h2(const H2Params p) {
+#if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (no __amdgpu_buffer_rsrc_t there)
+    constexpr int BM = H2_BM, BN = H2_BN, STAGE = H2_STAGE, PPW = H2_PPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // work unit -> (tile, K slice)
+    int tile, kt_begin, kt_end, slice = -1, split_tile = 0;
+    {
+        const int nk_all = p.K >> 4;
+        const int b = blockIdx.x;
+        if (b < p.full_tiles) {
+            tile = xcd_remap_h2(b, p.full_tiles);
+            kt_begin = 0;
+            kt_end = nk_all;
+        } else {
+            const int u = b - p.full_tiles;
+            split_tile = u / p.nsplit;
+            slice = u - split_tile * p.nsplit;
+            tile = p.full_tiles + split_tile;
+            kt_begin = (int)((int64_t)nk_all * slice / p.nsplit);
+            kt_end = (int)((int64_t)nk_all * (slice + 1) / p.nsplit);
+        }
+    }
+    int tm, tn;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = tile / per_group;
+        const int first = g * p.group_m;
+        const int gsz = p.tiles_m - first < p.group_m ? p.tiles_m - first : p.group_m;
+        const int w = tile - g * per_group;
+        tm = first + w % gsz;
+        tn = w / gsz;
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+    H2_STAMP(0);
+
+    // ---- DMA descriptors.  A stage = [hi image: 512 rows x 32 B][lo image: the same]; a piece = 1 KiB = 32 rows of one image; lane l
+    // fills half l & 1 of row 32 * (piece & 15) + (l >> 1).  This wave's four pieces: hi and lo of the activation rows 32 wave .. + 31
+    // (pieces wave, 16 + wave) and of the weight rows 32 wave .. + 31 (pieces 8 + wave, 24 + wave): two per-lane offsets.
+    const int64_t row_bytes = (int64_t)p.K * 4;
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
+    {
+        const int64_t left = (int64_t)(p.M - m0) * row_bytes;
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a + (int64_t)m0 * row_bytes), 0,
+                                                   (int)(left < kH2MaxRecords ? left : kH2MaxRecords), 0x00020000);
+        rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + (int64_t)n0 * row_bytes), 0, (int)(BN * row_bytes), 0x00020000);
+    }
+    unsigned voff_a, voff_w;
+    {
+        const int r = 32 * wave + (lane >> 1);
+        voff_a = m0 + r < p.M ? (unsigned)(r * (int)row_bytes + (lane & 1) * 16) : kH2OutOfRange;
+        voff_w = (unsigned)(r * (int)row_bytes + (lane & 1) * 16);
+    }
+    int d_kt = kt_begin;   // the next K step to issue (steps are issued in order)
+    // piece j of the wave: 0 = activations hi, 1 = weights hi, 2 = activations lo, 3 = weights lo
+#define H2_ISSUE_PIECE(st_, j_)                                                                                         \
+    {                                                                                                                   \
+        const int soff_ = d_kt * kH2ChunkBytes + ((j_) >> 1) * 32;                                                      \
+        const int dst_ = (st_) * STAGE + ((j_) >> 1) * (STAGE / 2) + ((j_) & 1) * (BM * 32) + wave * 1024;               \
+        if (((j_) & 1) == 0) { H2_DMA(rsrc_a, dst_, voff_a, soff_); }                                                    \
+        else { H2_DMA(rsrc_w, dst_, voff_w, soff_); }                                                                    \
+    }
+#define H2_ISSUE(st_)                                                                                                   \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j) H2_ISSUE_PIECE(st_, j);                                         \
+        ++d_kt;                                                                                                         \
+    }
+
+    floatx4 acc[8][4];   // 16-row A fragments x 16-column B fragments of the wave's 128 x 64
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets: lane (r, g), g = the 8-k group of the 32-deep instruction: A[hi|lo] takes half g & 1 of the hi (g < 2) or
+    // the lo (g >= 2) plane, B[hi|hi] / B[lo|lo] half g & 1 of the hi / lo plane
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const int a_hl = (g16 >> 1) * (STAGE / 2) + (wm * 128 + r16) * 32 + ((g16 & 1) << 4);
+    const int b_hh = (BM + wn * 64 + r16) * 32 + ((g16 & 1) << 4);
+    h2k_f16x8 xb[2][4][2], ya[2];
+#define H2_READ_XB(set_, sp_)                                                                                           \
+    _Pragma("unroll") for (int y = 0; y < 4; ++y) {                                                                     \
+        xb[set_][y][0] = *reinterpret_cast<const h2k_f16x8*>((sp_) + b_hh + y * 16 * 32);                               \
+        xb[set_][y][1] = *reinterpret_cast<const h2k_f16x8*>((sp_) + b_hh + y * 16 * 32 + STAGE / 2);                   \
+    }
+#define H2_READ_A(buf_, e_, sp_)                                                                                        \
+    {                                                                                                                   \
+        ya[buf_] = *reinterpret_cast<const h2k_f16x8*>((sp_) + a_hl + (e_) * 16 * 32);                                  \
+        __builtin_amdgcn_sched_barrier(0);   /* issued HERE, a whole MFMA group ahead of its use */                     \
+    }
+#define H2_MFMAS(set_, buf_, e_)                                                                                        \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                                   \
+            acc[e_][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ya[buf_], xb[set_][y][1], acc[e_][y], 0, 0, 0);         \
+        _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                                   \
+            acc[e_][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ya[buf_], xb[set_][y][0], acc[e_][y], 0, 0, 0);         \
+        __builtin_amdgcn_sched_barrier(0);   /* nothing moves across: the software pipeline below is the schedule */     \
+    }
+    // region k: [wait for step k+1, barrier, B forms and A fragment 0 of step k+1, MFMAs of fragment 7 of step k, then fragments 0..6
+    // of step k+1 each behind the read of the next one]; xs_ = k & 1 (register set of B), st_ = k % NSTG (LDS stage of step k, which
+    // every wave has left at the barrier: the pieces of step k + NSTG go into it, one per MFMA group).  In flight at the wait: the
+    // steps k+1 .. k+NSTG-1; the newest (NSTG - 2) * PPW pieces of this wave may stay in flight.
+#define H2_REGION(xs_, st_, has_next_, has_d_)                                                                          \
+    {                                                                                                                   \
+        const char* sn_ = smem + (((st_) + 1) % NSTG) * STAGE;                                                          \
+        if (has_next_) {                                                                                                \
+            if (has_d_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTG - 2) * PPW) : "memory");              \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+            __builtin_amdgcn_s_barrier();                                                                               \
+            H2_READ_XB((xs_) ^ 1, sn_);                                                                                 \
+            H2_READ_A(0, 0, sn_);                                                                                       \
+        }                                                                                                               \
+        H2_MFMAS(xs_, 1, 7);                                                                                            \
+        if (has_next_) {                                                                                                \
+            _Pragma("unroll") for (int e = 0; e < 7; ++e) {                                                             \
+                H2_READ_A((e + 1) & 1, e + 1, sn_);                                                                     \
+                if ((has_d_) && e < PPW) H2_ISSUE_PIECE(st_, e);                                                        \
+                H2_MFMAS((xs_) ^ 1, e & 1, e);                                                                          \
+            }                                                                                                           \
+            if (has_d_) ++d_kt;                                                                                         \
+        }                                                                                                               \
+    }
+
+    const int nk = kt_end - kt_begin;
+    // prologue: the first NSTG steps (as many as exist) are requested; step 0 has to have landed, the younger ones stay in flight
+    {
+        const int pre = nk < NSTG ? nk : NSTG;
+        for (int i = 0; i < pre; ++i) H2_ISSUE(i);
+        if (pre >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else if (pre == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (pre == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    H2_READ_XB(0, smem);
+    H2_READ_A(0, 0, smem);
+    H2_STAMP(1);
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+        H2_READ_A((e + 1) & 1, e + 1, smem);
+        H2_MFMAS(0, e & 1, e);
+    }
+    {
+        // has_next = step k+1 exists; has_d = step k + NSTG exists (its DMA is issued in region k); literal `true` in the steady state.
+        // One period of (register set, stage) = lcm(2, NSTG) regions, spelled out so that every index is a constant.
+        constexpr int PERIOD = (NSTG % 2 == 0) ? NSTG : 2 * NSTG;
+        int k = 0;
+        for (; k + PERIOD + NSTG <= nk; k += PERIOD) {
+#pragma unroll
+            for (int i = 0; i < PERIOD; ++i) H2_REGION(i & 1, i % NSTG, true, true);
+        }
+        for (; k < nk; k += PERIOD) {
+#pragma unroll
+            for (int i = 0; i < PERIOD; ++i)
+                if (k + i < nk) H2_REGION(i & 1, i % NSTG, k + i + 1 < nk, k + i + NSTG < nk);
+        }
+    }
+#undef H2_REGION
+#undef H2_MFMAS
+#undef H2_READ_A
+#undef H2_READ_XB
+#undef H2_ISSUE
+#undef H2_ISSUE_PIECE
+    H2_STAMP(2);
+    __syncthreads();   // no DMA is in flight and every fragment is in registers: the stages become the epilogue staging
+
+    // ---- epilogue, staged through LDS in 64-row passes (C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r); a
+    // thread owns two groups of 4 columns: adjacent (8 consecutive columns = whole 16-byte plane units) when planes leave, half a
+    // tile row apart for plain fp32 traffic (every store / load instruction then covers contiguous 512-byte row segments)
+    float* stg = reinterpret_cast<float*>(smem);
+    constexpr int LDC = BN + 4;
+    constexpr int EP_ROWS = 64;
+    constexpr int C8 = BN / 8;
+    constexpr int NT = 512;
+    static_assert(EP_ROWS * LDC * 4 <= NSTG * STAGE, "epilogue pass must fit the staging LDS");
+    constexpr int EP_STEP = NT / C8;
+    constexpr int EP_ITERS = EP_ROWS / EP_STEP;
+    const bool planes = p.out_h2 != nullptr;   // workgroup-uniform
+    const int lcA = planes ? (tid % C8) * 8 : (tid % C8) * 4;
+    const int lcB = planes ? lcA + 4 : lcA + BN / 2;
+    const int lr0 = tid / C8;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bias_a = zero4, bias_b = zero4, cs_a = zero4, cs_b = zero4;
+    if (slice < 0) {
+        cs_a = *reinterpret_cast<const f32x4*>(p.colscale + n0 + lcA);
+        cs_b = *reinterpret_cast<const f32x4*>(p.colscale + n0 + lcB);
+        if (p.bias) {
+            bias_a = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcA);
+            bias_b = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcB);
+        }
+    }
+    const bool interior = m0 + BM <= p.M;   // workgroup-uniform
+#pragma unroll
+    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
+        if (pass > 0) __syncthreads();
+        f32x4 ra[EP_ITERS], rb[EP_ITERS];
+        float rs[EP_ITERS];
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) {
+            const int m = m0 + pass * EP_ROWS + it * EP_STEP + lr0;
+            ra[it] = zero4;
+            rb[it] = zero4;
+            rs[it] = 1.f;
+            if (slice < 0 && (interior || m < p.M)) {
+                if (p.residual) {
+                    const float* r = p.residual + (int64_t)m * p.N + n0;
+                    ra[it] = *reinterpret_cast<const f32x4*>(r + lcA);
+                    rb[it] = *reinterpret_cast<const f32x4*>(r + lcB);
+                }
+                if (p.rowscale) rs[it] = p.rowscale[m];
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int rb0 = wm * 128 + x * 16;
+            if (rb0 / EP_ROWS == pass) {
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stg[(rb0 % EP_ROWS + 4 * g16 + r) * LDC + wn * 64 + y * 16 + r16] = acc[x][y][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) {
+            const int lr = it * EP_STEP + lr0;
+            const int trow = pass * EP_ROWS + lr;
+            const int m = m0 + trow;
+            if (!interior && m >= p.M) continue;
+            f32x4 va = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lcA);
+            f32x4 vb = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lcB);
+            if (slice >= 0) {   // K slice of a split tile: raw partial sums, the epilogue runs in splitk_finish_h2
+                float* o = p.partial + ((int64_t)split_tile * p.nsplit + slice) * (BM * BN) + (int64_t)trow * BN;
+                *reinterpret_cast<f32x4*>(o + lcA) = va;
+                *reinterpret_cast<f32x4*>(o + lcB) = vb;
+                continue;
+            }
+            // powers of two: exact.  Then (acc + bias) + residual, the same order on every path
+            va = va * (cs_a * rs[it]) + bias_a;
+            vb = vb * (cs_b * rs[it]) + bias_b;
+            if (p.residual) {
+                va += ra[it];
+                vb += rb[it];
+            }
+            if (p.act == 1) {
+                va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};
+                vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};
+            } else if (p.act == 2) {
+                va = gelu_erf4(va);
+                vb = gelu_erf4(vb);
+            }
+            const int64_t o = (int64_t)m * p.N + n0;
+            if (p.out) {
+                *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
+                *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
+            }
+            if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, p.out_scale);   // (planes: lcB = lcA + 4)
+        }
+    }
+    H2_STAMP(3);
+#endif
+}
+
+// Sums the K slices of the split tiles in slice order (deterministic) and applies the epilogue.
+__global__ __launch_bounds__(256) void splitk_finish_h2(const H2Params p) {
+    constexpr int BM = H2_BM, BN = H2_BN;
+    const int split_tile = blockIdx.y;
+    const int tile = p.full_tiles + split_tile;
+    int tm, tn;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = tile / per_group;
+        const int first = g * p.group_m;
+        const int gsz = p.tiles_m - first < p.group_m ? p.tiles_m - first : p.group_m;
+        const int w = tile - g * per_group;
+        tm = first + w % gsz;
+        tn = w / gsz;
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+    const int e8 = blockIdx.x * 256 + threadIdx.x;  // 8-column group index inside the tile
+    if (e8 >= BM * BN / 8) return;
+    const int lr = e8 / (BN / 8), lc = (e8 % (BN / 8)) * 8;
+    const int m = m0 + lr;
+    if (m >= p.M) return;
+    const float* pt = p.partial + (int64_t)split_tile * p.nsplit * (BM * BN) + lr * BN + lc;
+    f32x4 va = *reinterpret_cast<const f32x4*>(pt), vb = *reinterpret_cast<const f32x4*>(pt + 4);
+    for (int k = 1; k < p.nsplit; ++k) {
+        va += *reinterpret_cast<const f32x4*>(pt + (int64_t)k * (BM * BN));
+        vb += *reinterpret_cast<const f32x4*>(pt + (int64_t)k * (BM * BN) + 4);
+    }
+    const int64_t o = (int64_t)m * p.N + n0 + lc;
+    const float rs = p.rowscale ? p.rowscale[m] : 1.f;
+    va = va * (*reinterpret_cast<const f32x4*>(p.colscale + n0 + lc) * rs);
+    vb = vb * (*reinterpret_cast<const f32x4*>(p.colscale + n0 + lc + 4) * rs);
+    if (p.bias) {
+        va += *reinterpret_cast<const f32x4*>(p.bias + n0 + lc);
+        vb += *reinterpret_cast<const f32x4*>(p.bias + n0 + lc + 4);
+    }
+    if (p.residual) {
+        va += *reinterpret_cast<const f32x4*>(p.residual + o);
+        vb += *reinterpret_cast<const f32x4*>(p.residual + o + 4);
+    }
+    if (p.act == 1) {
+        va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};
+        vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};
+    } else if (p.act == 2) {
+        va = gelu_erf4(va);
+        vb = gelu_erf4(vb);
+    }
+    if (p.out) {
+        *reinterpret_cast<f32x4*>(p.out + o) = va;
+        *reinterpret_cast<f32x4*>(p.out + o + 4) = vb;
+    }
+    if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lc, va, vb, p.out_scale);
+}
+
+template <int NSTG>
+static int launch_h2_variant(relax_handle* h, H2Params& p, hipStream_t s) {
+    constexpr int BM = H2_BM, BN = H2_BN;
+    p.tiles_n = p.N / BN;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.ntiles = p.tiles_m * p.tiles_n;
+    p.group_m = h->gemm.group_m;
+    p.partial = nullptr;
+    // Tail split-K: the last, partial round of tiles is cut along K (cost model: host_logic.cpp, shared with the other kernels)
+    const host::TailSplit ts = host::choose_tail_split(p.ntiles, 256, p.K / 16, 8, h->gemm.split_k && !p.no_split);
+    p.full_tiles = ts.full_tiles;
+    p.nsplit = ts.nsplit;
+    if (p.nsplit > 1) {
+        const size_t need = sizeof(float) * (size_t)(p.ntiles - p.full_tiles) * p.nsplit * BM * BN;
+        RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
+        p.partial = static_cast<float*>(h->splitk_ws.p);
+    }
+    constexpr size_t lds = (size_t)NSTG * H2_STAGE;
+    static bool attr_set[kMaxDevices] = {};
+    if (!attr_set[h->device]) {
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2<NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[h->device] = true;
+    }
+    const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
+    H2_STAMPS_BEFORE_LAUNCH(h, p, units);
+    hipLaunchKernelGGL((gemm_h2<NSTG>), dim3(units), dim3(512), lds, s, p);
+    H2_STAMPS_AFTER_LAUNCH(h, p, units, s);
+    if (p.nsplit > 1)
+        hipLaunchKernelGGL(splitk_finish_h2, dim3(BM * BN / 8 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+int launch_gemm_h2(relax_handle* h, const GemmDescH2& d, hipStream_t s) {
+    H2Params p{};
+    p.a = static_cast<const char*>(d.a);
+    p.w = static_cast<const char*>(d.w);
+    p.colscale = d.colscale; p.rowscale = d.rowscale;
+    p.bias = d.bias; p.residual = d.residual; p.out = d.out; p.out_h2 = static_cast<char*>(d.out_h2); p.out_scale = d.out_scale;
+    p.M = d.M; p.N = d.N; p.K = d.K; p.act = d.act; p.no_split = d.no_split;
+    RELAX_REQUIRE(h, p.M > 0 && p.N > 0 && p.K > 0, "f16x2 gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+    RELAX_REQUIRE(h, p.K % 16 == 0 && p.N % 256 == 0, "f16x2 gemm: K=%d must be a multiple of 16 and N=%d of 256", p.K, p.N);
+    RELAX_REQUIRE(h, (int64_t)p.K * 4 * 256 < kH2MaxRecords, "f16x2 gemm: K=%d too large", p.K);
+    RELAX_REQUIRE(h, d.a && d.w && d.colscale && (d.out || d.out_h2), "f16x2 gemm: missing operand / no output requested");
+    RELAX_REQUIRE(h, !d.out_h2 || (d.out_scale > 0.f && d.out_scale < 3.0e38f), "f16x2 gemm: the plane output needs its scale");
+    auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    RELAX_REQUIRE(h, aligned16(d.a) && aligned16(d.w) && aligned16(d.colscale) && aligned16(d.bias) && aligned16(d.residual) && aligned16(d.out) &&
+                         aligned16(d.out_h2),
+                  "f16x2 gemm: every operand pointer must be 16-byte aligned");
+    const double flops = 2.0 * p.M * (double)p.N * (double)p.K;
+    // algorithmic HBM bytes: operands as planes (4 B per value), outputs (+ residual), each touched once
+    const double bytes = 4.0 * ((double)p.M * p.K + (double)p.N * p.K) +
+                         (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_h2 ? 4.0 : 0.0) + (d.residual ? 4.0 : 0.0));
+    int span;
+    RELAX_TRY(prof_begin(h, s, 5, flops, &span, bytes));
+    const int rc = h->gemm.h2_stages == 4 ? launch_h2_variant<4>(h, p, s) : launch_h2_variant<3>(h, p, s);
+    if (rc != RELAX_OK) { prof_abort(h, span); return rc; }
+    RELAX_TRY(prof_end(h, s, span));
+    return RELAX_OK;
+}
+
+}  // namespace relax

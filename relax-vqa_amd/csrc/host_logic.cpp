@@ -94,6 +94,54 @@ TailSplit choose_tail_split(int ntiles, int slots, int nk, int min_steps, bool c
     return r;
 }
 
+float h2_scale_for_bound(double amax) {
+    if (!(amax > 0.0) || !(amax < 3.0e38)) return 1.f;
+    int e;
+    (void)std::frexp(amax, &e);   // amax in [2^(e-1), 2^e)
+    int sh = 15 - e;
+    sh = sh > 120 ? 120 : (sh < -120 ? -120 : sh);
+    return std::ldexp(1.f, sh);
+}
+
+void h2_weight_row_scales(const float* W, int rows, int K, float* scale) {
+    for (int n = 0; n < rows; ++n) {
+        float m = 0.f;
+        const float* r = W + (size_t)n * K;
+        for (int k = 0; k < K; ++k) {
+            const float a = std::fabs(r[k]);
+            if (a > m) m = a;     // (a NaN never wins the comparison: such a row keeps the scale of its finite values)
+        }
+        scale[n] = h2_scale_for_bound((double)m);
+    }
+}
+
+double layernorm_out_bound(const float* gamma, const float* beta, int dim) {
+    const double zmax = std::sqrt((double)(dim > 1 ? dim - 1 : 1));
+    double m = 0.0;
+    for (int i = 0; i < dim; ++i) {
+        const double v = std::fabs((double)gamma[i]) * zmax + std::fabs((double)beta[i]);
+        if (v > m) m = v;
+    }
+    return m;
+}
+
+double linear_of_layernorm_bound(const float* W, const float* b, const float* gamma, const float* beta, int dim, int n0, int n1) {
+    const double zn = std::sqrt((double)dim);
+    double m = 0.0;
+    for (int n = n0; n < n1; ++n) {
+        const float* r = W + (size_t)n * dim;
+        double q = 0.0, c = b ? (double)b[n] : 0.0;
+        for (int i = 0; i < dim; ++i) {
+            const double gw = (double)gamma[i] * (double)r[i];
+            q += gw * gw;
+            c += (double)beta[i] * (double)r[i];
+        }
+        const double v = zn * std::sqrt(q) + std::fabs(c);
+        if (v > m) m = v;
+    }
+    return m;
+}
+
 }  // namespace host
 }  // namespace relax
 

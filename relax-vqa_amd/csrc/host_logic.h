@@ -47,5 +47,19 @@ struct TailSplit {
 };
 TailSplit choose_tail_split(int ntiles, int slots, int nk, int min_steps, bool can_split);
 
+// ---- scales of the two-plane fp16 format (csrc/h2.h): powers of two from RIGOROUS bounds, so no value can leave the fp16 range --------
+// The power of two that puts `amax` into [2^14, 2^15) (so twice the bound still fits below 65504); 1 for zero / non-finite.
+float h2_scale_for_bound(double amax);
+// Per-row weight scales: scale[n] = h2_scale_for_bound(max_k |W[n, k]|), W [rows][K] row-major.
+void h2_weight_row_scales(const float* W, int rows, int K, float* scale);
+// LayerNorm output bound: y_i = gamma_i z_i + beta_i with |z_i| <= sqrt(dim - 1) for EVERY input row (z has mean 0 and
+// sum z^2 <= dim)  ->  max_i (|gamma_i| sqrt(dim - 1) + |beta_i|).
+double layernorm_out_bound(const float* gamma, const float* beta, int dim);
+// Bound of the outputs n in [n0, n1) of Linear(LayerNorm(x)):  |sum_i z_i gamma_i W[n,i] + (beta . W[n,:] + b[n])| <=
+// sqrt(dim) * ||gamma * W[n,:]||_2 + |beta . W[n,:] + b[n]|   (Cauchy-Schwarz with ||z||_2 <= sqrt(dim)); the maximum over the range.
+// Everything that is a convex combination or a contraction of such outputs (attention output: rows of V; GELU: |GELU(x)| <= |x|)
+// inherits the bound.  W [N][dim] row-major, b may be null.
+double linear_of_layernorm_bound(const float* W, const float* b, const float* gamma, const float* beta, int dim, int n0, int n1);
+
 }  // namespace host
 }  // namespace relax

@@ -3,6 +3,7 @@
 // BN+ReLU+max-pool, deterministic global-average-pool, NHWC->NCHW tap export.
 #include "relax_internal.h"
 #include "sp3.h"
+#include "h2.h"
 
 namespace relax {
 
@@ -17,10 +18,12 @@ __device__ inline float wave_sum(float v) {
 // ---- LayerNorm: one 64-lane wave per row, row held in registers (dim <= 768) ---------------------------
 // SP3: the normalised row leaves as split planes (bf16 hi + mid + lo, gemm_x6.hip) for the bf16x6 contraction that
 // consumes it; the arithmetic before the store is the same, so the fp32 value that is split is the one the fp32 path stores.
-template <bool SP3>
+// MODE 2: as two fp16 planes of value * h2_scale (csrc/h2.h; h2_scale = the static power of two of this tensor) for the f16x2 contraction.
+template <int MODE>   // 0: fp32, 1: split planes, 2: two fp16 planes
 __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ x, const float* __restrict__ g,
                                                       const float* __restrict__ b, void* __restrict__ yv, int rows,
-                                                      int dim, float eps) {
+                                                      int dim, float eps, float h2_scale) {
+    constexpr bool SP3 = MODE == 1;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;  // wave-uniform
@@ -74,6 +77,16 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float* __restrict__ 
                 } else {
                     *reinterpret_cast<sp3_u32x4*>(d + 32) = (sp3_u32x4){s0, s1, mid.x, mid.y};     // mid: partner's 4 values, own 4
                 }
+            } else if (MODE == 2) {
+                // values k = 4i .. 4i+3 = 8 bytes of each plane of chunk k / 16: lanes 2j and 2j+1 hold the two halves of a 16-byte unit;
+                // after one exchange the even lane stores the hi unit, the odd lane the lo unit (16-byte stores, as above)
+                h2_u32x2 hi, lo;
+                split2_x4((h2_f32x4){o.x, o.y, o.z, o.w} * h2_scale, hi, lo);
+                const bool odd = lane & 1;
+                const unsigned s0 = __shfl_xor(odd ? hi.x : lo.x, 1), s1 = __shfl_xor(odd ? hi.y : lo.y, 1);
+                char* d = static_cast<char*>(yv) + (int64_t)row * dim * 4 + (i >> 2) * kH2ChunkBytes + ((i >> 1) & 1) * 16;
+                if (!odd) *reinterpret_cast<h2_u32x4*>(d) = (h2_u32x4){hi.x, hi.y, s0, s1};            // hi: own 4 values, partner's 4
+                else *reinterpret_cast<h2_u32x4*>(d + 32) = (h2_u32x4){s0, s1, lo.x, lo.y};            // lo: partner's 4 values, own 4
             } else {
                 reinterpret_cast<float4*>(static_cast<float*>(yv) + (int64_t)row * dim)[i] = o;
             }
@@ -85,7 +98,7 @@ int launch_layernorm(relax_handle* h, const float* x, const float* g, const floa
                      float eps, hipStream_t s) {
     RELAX_REQUIRE(h, dim % 4 == 0 && dim > 0 && dim <= 768, "layernorm: dim=%d must be a multiple of 4, <= 768", dim);
     RELAX_REQUIRE(h, rows > 0, "layernorm: rows=%d", rows);
-    hipLaunchKernelGGL(layernorm_rows<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, dim, eps);
+    hipLaunchKernelGGL(layernorm_rows<0>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y, rows, dim, eps, 1.f);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }
@@ -94,7 +107,16 @@ int launch_layernorm_sp3(relax_handle* h, const float* x, const float* g, const 
                          float eps, hipStream_t s) {
     RELAX_REQUIRE(h, dim % 16 == 0 && dim > 0 && dim <= 768, "layernorm_sp3: dim=%d must be a multiple of 16, <= 768", dim);
     RELAX_REQUIRE(h, rows > 0, "layernorm: rows=%d", rows);
-    hipLaunchKernelGGL(layernorm_rows<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y_sp3, rows, dim, eps);
+    hipLaunchKernelGGL(layernorm_rows<1>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y_sp3, rows, dim, eps, 1.f);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+int launch_layernorm_h2(relax_handle* h, const float* x, const float* g, const float* b, void* y_h2, float scale, int rows, int dim,
+                        float eps, hipStream_t s) {
+    RELAX_REQUIRE(h, dim % 16 == 0 && dim > 0 && dim <= 768, "layernorm_h2: dim=%d must be a multiple of 16, <= 768", dim);
+    RELAX_REQUIRE(h, rows > 0 && scale > 0.f, "layernorm_h2: rows=%d scale=%g", rows, (double)scale);
+    hipLaunchKernelGGL(layernorm_rows<2>, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, y_h2, rows, dim, eps, scale);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }
@@ -500,7 +522,7 @@ int relax_op_attention(relax_handle* h, const float* qkv, float* out, int Nimg, 
     if (!h) return RELAX_ERR_INVALID;
     RELAX_REQUIRE(h, qkv && out, "relax_op_attention: NULL operand");
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
-    if (h->gemm.precision == 2) return launch_attention_x6(h, qkv, out, nullptr, Nimg, heads, static_cast<hipStream_t>(stream));
+    if (h->gemm.precision >= 2) return launch_attention_x6(h, qkv, out, nullptr, Nimg, heads, static_cast<hipStream_t>(stream));
     return launch_attention(h, qkv, out, Nimg, heads, static_cast<hipStream_t>(stream));
 }
 

@@ -90,6 +90,22 @@ struct ConvDescX6 {
     double flops;           // algorithmic FLOPs for the profiler (0 = 2*M*N*K)
 };
 
+// h2 ("two fp16 planes", csrc/h2.h) operands of the f16x2 kernel (gemm_h2.hip): plain GEMM, N % 256 == 0
+struct GemmDescH2 {
+    const void* a;          // h2 activations [M][K*4 B], values scaled by a power of two
+    const void* w;          // h2 weights [N][K*4 B], row n scaled by 2^t_n
+    const float* colscale;  // [N]: the inverse of (weight row scale x static activation scale)
+    const float* rowscale;  // [M]: the inverse of a per-row activation scale, or null
+    const float* bias;      // [N] or null
+    const float* residual;  // fp32 [M][N] or null
+    float* out;             // fp32 [M][N] or null
+    void* out_h2;           // h2 [M][N*4 B] or null (at least one output), values scaled by out_scale (a power of two from a bound)
+    float out_scale;
+    int M, N, K;
+    int act;                // 0 none, 1 relu, 2 gelu(erf)
+    bool no_split;
+};
+
 // ---- model weights ------------------------------------------------------------------------------
 struct ConvW {          // one folded conv (+BN) of ResNet-50
     float* w = nullptr;     // device [Cout][Kpad]
@@ -120,6 +136,8 @@ struct ResNet50W {
 struct LinearW {
     float* w = nullptr;  // device [out][in]
     void* w_sp3 = nullptr;  // the same matrix as split planes (bf16 hi + mid + lo, gemm_x6.hip), made once at load time
+    void* w_h2 = nullptr;   // the same matrix as two fp16 planes, row n scaled by 2^t_n (gemm_h2.hip), made once at load time
+    float* colscale = nullptr;   // [out]: 2^-t_n / (static scale of the activation tensor this layer reads)
     float* b = nullptr;  // device [out]
     int in = 0, out = 0;
 };
@@ -127,6 +145,9 @@ struct LinearW {
 struct VitBlockW {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     LinearW qkv, proj, fc1, fc2;
+    // f16x2: static power-of-two scales of the activation tensors that travel as fp16 planes (host_logic.h: from bounds that hold
+    // for every input): LayerNorm 1 output, attention output, LayerNorm 2 output, GELU(fc1) output
+    float s_ln1 = 1.f, s_att = 1.f, s_ln2 = 1.f, s_hid = 1.f;
 };
 
 struct VitW {
@@ -169,8 +190,9 @@ struct Profiler {
     bool on = false;
     std::vector<ProfSpan> spans;
     std::vector<hipEvent_t> pool;
-    // span kinds: 0 fp32 / bf16x3 contraction, 1 patch score, 2 bf16x6 contraction, 3 Farneback iteration kernel, 4 the whole Farneback stage
-    static constexpr int kKinds = 5;
+    // span kinds: 0 fp32 / bf16x3 contraction, 1 patch score, 2 bf16x6 contraction, 3 Farneback iteration kernel, 4 the whole Farneback stage,
+    // 5 f16x2 contraction (gemm_h2.hip)
+    static constexpr int kKinds = 6;
     double total_ms[kKinds] = {};
     double total_work[kKinds] = {};
     double total_bytes[kKinds] = {};
@@ -182,7 +204,10 @@ struct Profiler {
 namespace relax {
 // Tuning / reproducibility switches of the contraction kernel (relax_set_option; env defaults RELAX_GEMM_*).
 struct GemmOptions {
-    int precision = 2; // "gemm_precision": 2 = bf16x6 (default, fp32-grade), 0 = exact fp32 MFMA, 1 = bf16x3 split products (~1e-5 relative)
+    int precision = 2; // "gemm_precision": 3 = f16x2 ( fp32-grade: two fp16 planes, four products in two MFMAs - gemm_h2.hip - for the
+                       // plain GEMMs with N % 256 == 0, i.e. the whole ViT; everything else as under 2), 2 = bf16x6 (default, fp32-grade), 0 = exact fp32
+                       // MFMA, 1 = bf16x3 split products (~1e-5 relative)
+    int h2_stages = 3; // "h2_stages": LDS stages of the f16x2 kernel (3 or 4; same bits)
     int split_k = 1;   // "gemm_split_k": tail split-K on (1) / off (0: K sums are batch-invariant bit for bit)
     int variant = -1;  // "gemm_variant": exact-fp32 kernel only: pin the tile variant for N % 128 == 0 problems, -1 = automatic
     int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)
@@ -255,13 +280,22 @@ inline int launch_gemm_x6(relax_handle* h, const void* A_sp3, const void* W_sp3,
     return launch_conv_x6(h, d, s);
 }
 
+// f16x2 contraction kernel (gemm_h2.hip)
+int launch_gemm_h2(relax_handle* h, const GemmDescH2& d, hipStream_t s);
+int launch_to_h2(relax_handle* h, const float* x, int64_t ld, void* y, int64_t rows, int K, float scale, const float* row_scale, hipStream_t s);
+int launch_to_h2_rows(relax_handle* h, const float* x, int64_t ld, void* y, int rows, int K, float* inv_scale, hipStream_t s);
+
 // small kernels (layers.hip)
 int launch_layernorm(relax_handle* h, const float* x, const float* g, const float* b, float* y, int rows, int dim,
                      float eps, hipStream_t s);
 int launch_layernorm_sp3(relax_handle* h, const float* x, const float* g, const float* b, void* y_sp3, int rows, int dim,
                          float eps, hipStream_t s);
 int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s);
-int launch_attention_x6(relax_handle* h, const float* qkv, float* out, void* out_sp3, int Nimg, int heads, hipStream_t s);
+int launch_layernorm_h2(relax_handle* h, const float* x, const float* g, const float* b, void* y_h2, float scale, int rows, int dim,
+                        float eps, hipStream_t s);
+// out_planes: split planes (out_h2_scale == 0) or two fp16 planes scaled by out_h2_scale (> 0)
+int launch_attention_x6(relax_handle* h, const float* qkv, float* out, void* out_planes, int Nimg, int heads, hipStream_t s,
+                        float out_h2_scale = 0.f);
 int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
                            int Nimg, int H, int W, int C, hipStream_t s);
 int launch_bn_relu_maxpool_sp3(relax_handle* h, const float* x, const float* scale, const float* shift, void* y_sp3,

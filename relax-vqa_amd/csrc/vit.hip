@@ -10,6 +10,7 @@
 #include "relax_internal.h"
 #include "host_logic.h"
 #include "sp3.h"
+#include "h2.h"
 
 namespace relax {
 
@@ -17,6 +18,7 @@ constexpr int NTOK = 197;
 constexpr int NPATCH = 196;
 constexpr int PATCH_K = 3 * 16 * 16;
 constexpr float kLnEps = 1e-6f;
+constexpr float kPatchScale = 16384.f;   // patch values are value/255 in [0, 1]: as fp16 planes of value * 2^14 (csrc/h2.h)
 
 // uint8 BGR [N,224,224,3] -> fp32 [N*196, 768], k = c*256 + py*16 + px with c in RGB order, value/255
 __global__ __launch_bounds__(256) void vit_patchify(const uint8_t* __restrict__ frag, float* __restrict__ P,
@@ -47,6 +49,23 @@ __global__ __launch_bounds__(256) void vit_patchify_sp3(const uint8_t* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (float)src[3 * j] / 255.0f;
     store_sp3_x8(P + row * (PATCH_K * 6), k, (sp3_f32x4){v[0], v[1], v[2], v[3]}, (sp3_f32x4){v[4], v[5], v[6], v[7]});
+}
+
+// the same patches as two fp16 planes of value/255 * scale (csrc/h2.h; the values are in [0, 1]: scale 2^14)
+__global__ __launch_bounds__(256) void vit_patchify_h2(const uint8_t* __restrict__ frag, char* __restrict__ P, int64_t total8, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int k = (int)(i % (PATCH_K / 8)) * 8;
+    const int64_t row = i / (PATCH_K / 8);
+    const int p = (int)(row % NPATCH);
+    const int64_t n = row / NPATCH;
+    const int c = k >> 8, py = (k >> 4) & 15, px = k & 15;
+    const int y = (p / 14) * 16 + py, x = (p % 14) * 16 + px;
+    const uint8_t* src = frag + ((n * 224 + y) * 224 + x) * 3 + (2 - c);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)src[3 * j] / 255.0f;
+    store_h2_x8(P + row * (PATCH_K * 4), k, (h2_f32x4){v[0], v[1], v[2], v[3]}, (h2_f32x4){v[4], v[5], v[6], v[7]}, scale);
 }
 
 // X[n,0,:] = cls + pos[0];  X[n,1+p,:] = PE[n*196+p,:] + pos[1+p]
@@ -222,6 +241,55 @@ int relax_load_vit(relax_handle* h, const float* const* tensors, const char* con
         sp3(&b.fc1);
         sp3(&b.fc2);
     }
+    // two fp16 planes of every GEMM weight for the f16x2 kernel: row n scaled by 2^t_n (from the row's maximum); colscale[n] =
+    // 2^-t_n / (the static scale of the activation tensor the layer reads).  The activation scales come from bounds that hold for
+    // EVERY input (host_logic.h), evaluated here in double on the host copies of the weights.
+    auto host_of = [&](const std::string& key, int64_t numel) -> const float* {
+        std::string err;
+        return sd.get(key, numel, err, "vit state dict");   // (present: `up` has already checked every key)
+    };
+    std::vector<float> tmp_scale, tmp_col;
+    auto h2w = [&](LinearW* l, const std::string& p, float act_scale) {
+        if (rc != RELAX_OK) return;
+        const float* hw = host_of(p + ".weight", (int64_t)l->in * l->out);
+        tmp_scale.resize((size_t)l->out);
+        tmp_col.resize((size_t)l->out);
+        host::h2_weight_row_scales(hw, l->out, l->in, tmp_scale.data());
+        for (int n = 0; n < l->out; ++n) tmp_col[(size_t)n] = (1.f / tmp_scale[(size_t)n]) * (1.f / act_scale);   // powers of two: exact
+        float* d_scale = nullptr;
+        void* q = nullptr;
+        if (hipMalloc(&q, (size_t)l->in * l->out * 4) != hipSuccess) {
+            set_error(h, "vit: hipMalloc of fp16-plane weights failed");
+            rc = RELAX_ERR_NOMEM;
+            return;
+        }
+        v.allocs.push_back(q);
+        l->w_h2 = q;
+        rc = upload(h, tmp_scale.data(), (size_t)l->out, &d_scale, v.allocs);
+        if (rc == RELAX_OK) rc = upload(h, tmp_col.data(), (size_t)l->out, &l->colscale, v.allocs);
+        if (rc == RELAX_OK) rc = launch_to_h2(h, l->w, l->in, q, l->out, l->in, 1.f, d_scale, nullptr);
+    };
+    if (rc == RELAX_OK && dim % 256 == 0) {   // (the f16x2 tile takes N % 256 == 0: ViT-B; smaller models run bf16x6 under "gemm_precision" 3)
+        h2w(&v.patch, "patch_embed.proj", kPatchScale);
+        for (int i = 0; i < depth && rc == RELAX_OK; ++i) {
+            const std::string p = "blocks." + std::to_string(i) + ".";
+            VitBlockW& b = v.blocks[i];
+            const float *g1 = host_of(p + "norm1.weight", dim), *b1 = host_of(p + "norm1.bias", dim);
+            const float *g2 = host_of(p + "norm2.weight", dim), *b2 = host_of(p + "norm2.bias", dim);
+            b.s_ln1 = host::h2_scale_for_bound(host::layernorm_out_bound(g1, b1, dim));
+            b.s_ln2 = host::h2_scale_for_bound(host::layernorm_out_bound(g2, b2, dim));
+            // attention output = convex combinations of the V rows of qkv(LayerNorm1(x)): columns 2 dim .. 3 dim of the qkv Linear
+            b.s_att = host::h2_scale_for_bound(host::linear_of_layernorm_bound(host_of(p + "attn.qkv.weight", (int64_t)3 * dim * dim),
+                                                                               host_of(p + "attn.qkv.bias", 3 * dim), g1, b1, dim, 2 * dim, 3 * dim));
+            // |GELU(x)| <= |x|, x = fc1(LayerNorm2(.))
+            b.s_hid = host::h2_scale_for_bound(host::linear_of_layernorm_bound(host_of(p + "mlp.fc1.weight", (int64_t)4 * dim * dim),
+                                                                               host_of(p + "mlp.fc1.bias", 4 * dim), g2, b2, dim, 0, 4 * dim));
+            h2w(&b.qkv, p + "attn.qkv", b.s_ln1);
+            h2w(&b.proj, p + "attn.proj", b.s_att);
+            h2w(&b.fc1, p + "mlp.fc1", b.s_ln2);
+            h2w(&b.fc2, p + "mlp.fc2", b.s_hid);
+        }
+    }
     if (rc == RELAX_OK && hipDeviceSynchronize() != hipSuccess) {
         set_error(h, "vit: weight conversion failed");
         rc = RELAX_ERR_HIP;
@@ -253,7 +321,50 @@ int relax_vit_features(relax_handle* h, const uint8_t* frags, int N, float* toke
     float* Hid = QKV + n * NTOK * dim * 3;
     const int rows = N * NTOK;
 
-    if (h->gemm.precision == 2) {
+    if (h->gemm.precision == 3 && dim % 256 == 0) {
+        // f16x2: GEMM inputs travel as two fp16 planes of (value x a static power of two), written by the kernel that produces them;
+        // GEMM outputs that feed LayerNorm / attention / the residual stream stay fp32.  The buffers of the bf16x6 layout are reused
+        // (4-byte plane values fit its 6-byte slots).  Attention keeps its bf16x6 arithmetic inside (attention_x6.hip: 4 % of the FLOPs).
+        float* base = static_cast<float*>(h->arena.p);
+        char* Ps = reinterpret_cast<char*>(base);
+        float* PEx = base + n * NPATCH * PATCH_K * 3 / 2;
+        float* Xx = PEx + n * NPATCH * dim;
+        char* Ys = reinterpret_cast<char*>(Xx + n * NTOK * dim);
+        float* QKVx = reinterpret_cast<float*>(Ys) + n * NTOK * dim * 3 / 2;
+        float* ATT = QKVx + n * NTOK * dim * 3;
+        char* Hs = reinterpret_cast<char*>(ATT + n * NTOK * dim);
+        auto gemm = [&](const void* A, const LinearW& l, const float* residual, float* out, void* out_h2, float out_scale, int M, int act) {
+            GemmDescH2 d{};
+            d.a = A; d.w = l.w_h2; d.colscale = l.colscale; d.bias = l.b; d.residual = residual; d.out = out; d.out_h2 = out_h2;
+            d.out_scale = out_scale; d.M = M; d.N = l.out; d.K = l.in; d.act = act;
+            return launch_gemm_h2(h, d, s);
+        };
+        const int64_t p8 = (int64_t)N * NPATCH * (PATCH_K / 8);
+        hipLaunchKernelGGL(vit_patchify_h2, dim3((unsigned)((p8 + 255) / 256)), dim3(256), 0, s, frags, Ps, p8, kPatchScale);
+        RELAX_TRY(gemm(Ps, v.patch, nullptr, PEx, nullptr, 0.f, N * NPATCH, 0));
+        const int64_t at = (int64_t)rows * (dim / 4);
+        hipLaunchKernelGGL(vit_assemble, dim3((unsigned)((at + 255) / 256)), dim3(256), 0, s, PEx, v.cls, v.pos, Xx, dim / 4, at);
+        RELAX_HIP_CHECK(h, hipGetLastError());
+        for (const VitBlockW& b : v.blocks) {
+            RELAX_TRY(launch_layernorm_h2(h, Xx, b.ln1_g, b.ln1_b, Ys, b.s_ln1, rows, dim, kLnEps, s));
+            RELAX_TRY(gemm(Ys, b.qkv, nullptr, QKVx, nullptr, 0.f, rows, 0));
+            RELAX_TRY(launch_attention_x6(h, QKVx, nullptr, Ys, N, v.heads, s, b.s_att));   // output straight into fp16 planes
+            RELAX_TRY(gemm(Ys, b.proj, Xx, Xx, nullptr, 0.f, rows, 0));                     // x += proj(attn)
+            RELAX_TRY(launch_layernorm_h2(h, Xx, b.ln2_g, b.ln2_b, Ys, b.s_ln2, rows, dim, kLnEps, s));
+            RELAX_TRY(gemm(Ys, b.fc1, nullptr, nullptr, Hs, b.s_hid, rows, 2));              // GELU(erf) -> fp16 planes
+            RELAX_TRY(gemm(Hs, b.fc2, Xx, Xx, nullptr, 0.f, rows, 0));                      // x += mlp
+        }
+        RELAX_TRY(launch_layernorm(h, Xx, v.norm_g, v.norm_b, ATT, rows, dim, kLnEps, s));
+        if (tokens) {
+            const int64_t t = (int64_t)N * NPATCH * (dim / 4);
+            hipLaunchKernelGGL(vit_drop_cls, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, ATT, tokens, dim / 4, t);
+        }
+        if (pooled) hipLaunchKernelGGL(vit_token_stats, dim3(dim / 64, N), dim3(256), 0, s, ATT, pooled, dim, NTOK, 1, NPATCH);
+        RELAX_HIP_CHECK(h, hipGetLastError());
+        return RELAX_OK;
+    }
+
+    if (h->gemm.precision >= 2) {   // (3 with a dim the f16x2 tile does not take, e.g. vit_tiny's 192: bf16x6)
         // bf16x6: GEMM inputs travel as split planes (written by the kernel that produces them), GEMM outputs that feed
         // LayerNorm / attention / the residual stream stay fp32
         float* base = static_cast<float*>(h->arena.p);

@@ -121,13 +121,16 @@ class RelaxEngine:
         self._check(self.lib.relax_mlp_head(self.h, _ptr(features), features.shape[0], _ptr(out), _stream()), "relax_mlp_head")
         return out
 
-    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}
+    PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2, "f16x2": 3}
 
     def set_precision(self, mode):
         """'fp32': exact fp32 products on the fp32 MFMA.  'bf16x6' (fp32-grade): each fp32 operand is held as three bf16
         values (hi + mid + lo, exact) and a*b = the six partial products of weight >= 2^-16 on the bf16 MFMA with fp32
-        accumulation - as close to the exact result as the fp32 FMA chain at 6/16 of its matrix cycles.  'bf16x3'
-        (opt-in, lower precision): two bf16 values, three products, ~1e-5 norm-relative (the parity bar is 1e-3)."""
+        accumulation - as close to the exact result as the fp32 FMA chain at 6/16 of its matrix cycles.  'f16x2' (fp32-grade): each
+        fp32 operand as two fp16 values of a power-of-two multiple of itself (22 bits; scales from bounds that hold for every input,
+        csrc/h2.h) and all four partial products in two fp16 MFMAs - the plain GEMMs with N % 256 == 0 (the whole ViT-B); convolutions
+        and attention run bf16x6 under it.  'bf16x3' (opt-in, lower precision): two bf16 values, three products, ~1e-5 norm-relative
+        (the parity bar is 1e-3)."""
         self.set_option("gemm_precision", self.PRECISIONS[mode])
 
     def precision(self):

@@ -48,9 +48,9 @@ def _engine_precision_is_restored(request):
     eng.set_precision("bf16x6")
 
 
-@pytest.fixture(params=["bf16x6", "fp32"])
+@pytest.fixture(params=["bf16x6", "fp32", "f16x2"])
 def each_precision(request):
-    """Parity tests that must hold on both fp32-grade arithmetics of the contraction kernels."""
+    """Parity tests that must hold on every fp32-grade arithmetic of the contraction kernels."""
     from tests.gpu_common import engine
     engine().set_precision(request.param)
     return request.param

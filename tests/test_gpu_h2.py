@@ -1,0 +1,239 @@
+"""f16x2 (csrc/gemm_h2.hip, csrc/h2.h): fp32 operands as two fp16 planes of a power-of-two multiple of themselves, all four partial
+products in two v_mfma_f32_16x16x32_f16, fp32 accumulate.  The claim under test is fp32-GRADE accuracy: against an fp64 reference the
+error is no larger than the exact-fp32 path's (an fp32 FMA chain) - the gate of the round-4 review - and the scales can never
+overflow (they come from bounds, not from data)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fragment_ref, pooling_ref, vit_ref
+from tests.gpu_common import assert_close, engine, synth, vit_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+@pytest.fixture()
+def h2():
+    eng = engine()
+    eng.set_precision("f16x2")
+    assert eng.precision() == "f16x2"
+    yield eng            # (the autouse fixture restores the engine's precision)
+
+
+def _two_plane_value(A):
+    """numpy emulation of csrc/h2.h per ROW of A: scale = the power of two that puts the row maximum into [2^14, 2^15), hi = fp16(x s),
+    lo = fp16(x s - hi); returns (hi + lo) / s in double - what the planes hold."""
+    A = np.asarray(A, dtype=np.float32)
+    amax = np.abs(A).max(axis=1, keepdims=True)
+    _, e = np.frexp(amax)
+    s = np.where(amax > 0, np.exp2((15 - e).astype(np.float64)), 1.0).astype(np.float32)
+    v = (A * s).astype(np.float32)
+    hi = v.astype(np.float16)
+    lo = (v - hi.astype(np.float32)).astype(np.float16)
+    return (hi.astype(np.float64) + lo.astype(np.float64)) / s.astype(np.float64)
+
+
+def test_permutation_matrix_copies_the_two_plane_value_bit_for_bit(h2):
+    """W = a permutation matrix (its rows become 2^14 exactly): out[m, n] = the two-plane value of A[m, perm[n]] EXACTLY - hi x 2^14
+    + lo x 2^14 is exact in the fp32 accumulator and the scales are powers of two.  One equality checks the plane layout, the LDS
+    image, the DMA piece map, the per-row scales, fp16 subnormal lo planes and the C write; the asymmetric permutation catches any
+    transpose, M = 300 the zero-filled rows past M, the 2^-6 .. 2^6 spread inside a row the part of the window below 2^-3."""
+    M, K = 300, 512
+    A = (_rand(M, K, seed=1) * torch.logspace(-6, 6, K, base=2.0)[None, :]).float()
+    want = _two_plane_value(A.numpy())
+    assert np.abs(want - A.double().numpy()).max() > 0          # (the format does round: the test is not vacuous)
+    for N in (256, 512):
+        perm = torch.randperm(K, generator=torch.Generator().manual_seed(N))[:N]
+        W = torch.zeros(N, K)
+        W[torch.arange(N), perm] = 1.0
+        got = h2.op_gemm(A.cuda(), W.cuda()).cpu().double().numpy()
+        assert np.array_equal(got, want[:, perm.numpy()]), f"N={N}"
+    # and the relative error of what the planes hold: 2^-22 of each value that sits in the window of its row
+    big = np.abs(A.numpy()) * 2.0 ** 17 >= np.abs(A.numpy()).max(axis=1, keepdims=True)
+    rel = np.abs(want - A.double().numpy())[big] / np.abs(A.double().numpy())[big]
+    assert rel.max() <= 2.0 ** -22
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 256, 32), (1000, 256, 512), (197 * 3, 2304, 768), (777, 3072, 768), (12608, 768, 3072),
+                                   (2049, 512, 4608), (256 * 40, 768, 768)])
+def test_error_is_no_larger_than_the_fp32_paths(M, N, K):
+    eng = engine()
+    A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    ref = A.double() @ W.double().T
+    eng.set_precision("fp32")
+    e32 = (eng.op_gemm(A.cuda(), W.cuda()).cpu().double() - ref).abs()
+    eng.set_precision("bf16x6")
+    e6 = (eng.op_gemm(A.cuda(), W.cuda()).cpu().double() - ref).abs()
+    eng.set_precision("f16x2")
+    got = eng.op_gemm(A.cuda(), W.cuda())
+    again = eng.op_gemm(A.cuda(), W.cuda())
+    assert torch.equal(got, again)
+    e2 = (got.cpu().double() - ref).abs()
+    scale = ref.abs().mean().item()
+    print(f"\n{M}x{N}x{K}: mean |err| / mean |ref|: fp32 {e32.mean().item() / scale:.3e}  bf16x6 {e6.mean().item() / scale:.3e}  "
+          f"f16x2 {e2.mean().item() / scale:.3e};  max: fp32 {e32.max().item() / scale:.3e}  bf16x6 {e6.max().item() / scale:.3e}  "
+          f"f16x2 {e2.max().item() / scale:.3e}")
+    assert_close(got, ref.float().numpy(), f"f16x2 gemm {M}x{N}x{K}")
+    assert e2.mean().item() <= 1.05 * e32.mean().item() + 1e-12, "f16x2 mean error exceeds the fp32 FMA chain's"
+    assert e2.max().item() <= 1.5 * e32.max().item() + 1e-12, "f16x2 worst error exceeds the fp32 FMA chain's"
+
+
+def test_rows_of_very_different_size_and_sparse_rows(h2):
+    """Per-row scales (operator level): rows whose magnitudes differ by 2^60, an all-zero row, a row with a single nonzero, and values
+    spread over 2^-12 .. 2^0 inside a row.  Error measured against the sum of magnitudes, beside the fp32 FMA chain."""
+    eng = h2
+    M, N, K = 300, 256, 768
+    g = torch.Generator().manual_seed(5)
+    A = _rand(M, K, seed=3) * torch.exp2(torch.randint(-12, 1, (M, K), generator=g).float()) * torch.exp2(torch.randint(-30, 31, (M, 1), generator=g).float())
+    A[7] = 0
+    A[9] = 0
+    A[9, 100] = 3.0e-20
+    W = _rand(N, K, seed=4) * torch.exp2(torch.randint(-8, 1, (N, K), generator=g).float())
+    ref = A.double() @ W.double().T
+    mag = (A.double().abs() @ W.double().abs().T).clamp_min(1e-300)
+    got = eng.op_gemm(A.cuda(), W.cuda()).cpu().double()
+    eng.set_precision("fp32")
+    e32 = ((eng.op_gemm(A.cuda(), W.cuda()).cpu().double() - ref).abs() / mag)
+    e2 = ((got - ref).abs() / mag)
+    print(f"\nerr / sum|a||w|: fp32 mean {e32.mean().item():.3e} max {e32.max().item():.3e}; f16x2 mean {e2.mean().item():.3e} max {e2.max().item():.3e}")
+    assert torch.isfinite(got).all() and torch.all(got[7] == 0)
+    assert e2.max().item() < 1e-6 and e2.mean().item() <= 1.05 * e32.mean().item() + 1e-9
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_epilogue(h2, act):
+    M, N, K = 333, 256, 96
+    A, W, b, r = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=0.1), _rand(N, seed=5), _rand(M, N, seed=6)
+    y = A.double() @ W.double().T + b.double() + r.double()
+    want = [y, F.relu(y), F.gelu(y)][act].float().numpy()
+    assert_close(h2.op_gemm(A.cuda(), W.cuda(), b.cuda(), r.cuda(), act=act), want, f"f16x2 epilogue act={act}")
+    rr = r.cuda().clone()
+    h2.op_gemm(A.cuda(), W.cuda(), b.cuda(), rr, act=act, out=rr)
+    assert_close(rr, want, f"f16x2 in-place residual act={act}")
+
+
+def test_shapes_the_tile_does_not_take_run_bf16x6(h2):
+    """N % 256 != 0 (the 64 / 128-column tiles) stays on the split-plane kernel under "gemm_precision" 3: same bits as under 2."""
+    A, W = _rand(500, 256, seed=1).cuda(), _rand(192, 256, seed=2, scale=0.06).cuda()
+    got = h2.op_gemm(A, W)
+    h2.set_precision("bf16x6")
+    assert torch.equal(got, h2.op_gemm(A, W))
+
+
+def test_split_k_is_deterministic_and_optional_and_stages_agree(h2):
+    """300 tiles of 256x256: 44 tail tiles are cut along K.  Same bits run to run; with gemm_split_k = 0 the bits do not depend on how
+    many rows travel together; the 3- and 4-stage forms of the loop give the same bits (same products, same order)."""
+    M, N, K = 256 * 100, 768, 768
+    A, W = _rand(M, K, seed=8).cuda(), _rand(N, K, seed=9, scale=K ** -0.5).cuda()
+    a = h2.op_gemm(A, W)
+    assert torch.equal(a, h2.op_gemm(A, W))
+    h2.set_option("h2_stages", 4)
+    try:
+        assert torch.equal(a, h2.op_gemm(A, W))
+    finally:
+        h2.set_option("h2_stages", 3)
+    h2.set_option("gemm_split_k", 0)
+    try:
+        whole = h2.op_gemm(A, W)
+        part = h2.op_gemm(A[: 256 * 7], W)
+        odd = h2.op_gemm(A[5: 5 + 777].contiguous(), W)
+    finally:
+        h2.set_option("gemm_split_k", 1)
+    assert torch.equal(whole[: 256 * 7], part) and torch.equal(whole[5: 5 + 777], odd)
+    assert_close(a, whole.cpu().numpy(), "split-K vs whole-K", rtol=1e-4, atol_frac=1e-5)
+
+
+# ---- the ViT under f16x2 ------------------------------------------------------------------------------------------------
+def _fragments(n, seed=0):
+    frs = []
+    for i in range(n):
+        o, nx = synth.synthetic_pair(240, 320, 500 + seed * 64 + i)
+        f = fragment_ref.fragment_pair(o, nx)
+        frs.append(f["ori_frag"] if i % 2 == 0 else f["diff_frag"])
+    return np.stack(frs)
+
+
+@pytest.mark.parametrize("adv", [False, True], ids=["regular", "adversarial"])
+def test_vit_base_matches_reference_golden_tokens_under_f16x2(golden_dir, h2, adv):
+    """The reference's own VisionTransformer outputs (tests/golden/vit_base{,_adv}_tokens.npz), regular weights and the adversarial
+    set (logits of +-20, large LayerNorm gains: the static bounds are tight there)."""
+    vit_weights("vit_base", adversarial=adv)
+    z = np.load(os.path.join(golden_dir, f"vit_base{'_adv' if adv else ''}_tokens.npz"))
+    tokens, pooled = h2.vit_features(torch.from_numpy(z["frags"]).cuda(), tokens=True, pooled=True)
+    assert_close(tokens, z["tokens"], "vit_base tokens (f16x2) vs reference VisionTransformer")
+    want = np.stack([pooling_ref.vit_pool_vector(t) for t in z["tokens"]])
+    assert_close(pooled, want, "vit_base pooled (f16x2) vs reference process_video_feature")
+
+
+@pytest.mark.parametrize("adv", [False, True], ids=["regular", "adversarial"])
+def test_vit_base_error_against_fp64_is_no_larger_than_the_fp32_paths(adv):
+    """12 blocks deep: tokens of the exact-fp32 path, of bf16x6 and of f16x2 against an fp64 run of the oracle (same fp32 weights and
+    inputs, all arithmetic in double).  The gate: f16x2 no further from fp64 than the fp32 FMA chain."""
+    sd = vit_weights("vit_base", adversarial=adv)
+    eng = engine()
+    frags = _fragments(3, seed=2)
+    sd64 = {k: v.double() for k, v in vit_ref.to_torch_state_dict(sd).items()}
+    ref = vit_ref.forward_tokens(sd64, vit_ref.preprocess_bgr_u8(frags).double(), 12).numpy()
+    f = torch.from_numpy(frags).cuda()
+    out = {}
+    for prec in ("fp32", "bf16x6", "f16x2"):
+        eng.set_precision(prec)
+        t, _ = eng.vit_features(f, tokens=True, pooled=False)
+        t2, _ = eng.vit_features(f, tokens=True, pooled=False)
+        assert torch.equal(t, t2), f"{prec} is not deterministic"
+        e = np.abs(t.cpu().numpy().astype(np.float64) - ref)
+        out[prec] = (np.linalg.norm(e) / np.linalg.norm(ref), e.max())
+    print("\nvit_base tokens vs fp64 (norm-rel, max abs): " + "  ".join(f"{k} {v[0]:.3e} {v[1]:.3e}" for k, v in out.items()))
+    assert out["f16x2"][0] <= 1.1 * out["fp32"][0] and out["f16x2"][1] <= 1.5 * out["fp32"][1]
+
+
+def test_vit_rows_do_not_depend_on_the_batch_under_f16x2(h2):
+    """Static scales: with the tail split off an image's tokens are the same bits alone, first or last in a batch of 37."""
+    vit_weights("vit_base")
+    f = torch.from_numpy(_fragments(5, seed=3)).cuda()
+    big = f.repeat(8, 1, 1, 1)[:37]
+    h2.set_option("gemm_split_k", 0)
+    try:
+        _, alone = h2.vit_features(f[2:3], tokens=False, pooled=True)
+        _, five = h2.vit_features(f, tokens=False, pooled=True)
+        _, many = h2.vit_features(big, tokens=False, pooled=True)
+    finally:
+        h2.set_option("gemm_split_k", 1)
+    assert torch.equal(alone[0], five[2]) and torch.equal(five[2], many[2]) and torch.equal(many[2], many[32])
+
+
+def test_extreme_inputs_cannot_overflow_the_static_scales():
+    """All-white, all-black and a checkerboard of 0 / 255 (the largest patch-embedding outputs and the most uneven LayerNorm rows a
+    uint8 input can make), regular and adversarial weights: the tokens stay finite, and against an fp64 run of the oracle f16x2 is no
+    further away than the exact-fp32 path (the adversarial network on a checkerboard is ill-conditioned - its one-hot softmax rows
+    amplify any fp32 rounding to 1e-4 - which is why the comparison is against fp64 and beside the FMA chain, not against a bar)."""
+    eng = engine()
+    for adv in (False, True):
+        sd = vit_weights("vit_base", adversarial=adv)
+        frags = np.zeros((3, 224, 224, 3), dtype=np.uint8)
+        frags[0] = 255
+        yy, xx = np.mgrid[0:224, 0:224]
+        frags[2] = (((yy // 16 + xx // 16) % 2) * 255)[:, :, None]
+        sd64 = {k: v.double() for k, v in vit_ref.to_torch_state_dict(sd).items()}
+        ref = vit_ref.forward_tokens(sd64, vit_ref.preprocess_bgr_u8(frags).double(), 12).numpy()
+        f = torch.from_numpy(frags).cuda()
+        err = {}
+        for prec in ("fp32", "f16x2"):
+            eng.set_precision(prec)
+            tokens, _ = eng.vit_features(f, tokens=True, pooled=False)
+            assert torch.isfinite(tokens).all(), prec
+            e = np.abs(tokens.cpu().numpy().astype(np.float64) - ref)
+            err[prec] = (np.linalg.norm(e) / np.linalg.norm(ref), e.max())
+        print(f"\nextreme inputs, adversarial={adv}: vs fp64 (norm-rel, max abs): fp32 {err['fp32'][0]:.3e} {err['fp32'][1]:.3e}  "
+              f"f16x2 {err['f16x2'][0]:.3e} {err['f16x2'][1]:.3e}")
+        assert err["f16x2"][0] <= 1.25 * err["fp32"][0] and err["f16x2"][1] <= 2.0 * err["fp32"][1]
+        if not adv:
+            assert_close(tokens, ref.astype(np.float32), "extreme inputs, regular weights")
