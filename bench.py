@@ -111,7 +111,7 @@ def _cpu_model():
 
 def hbm_traffic_per_launch(workload, clips_per_step, precision):
     """PMC-measured HBM bytes per contraction launch, if a committed profile exists for this exact workload and precision."""
-    path = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -158,7 +158,7 @@ def measure_hbm_traffic(workload, clips_per_step, precision, split_k):
             for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
                 if r["Counter_Name"] != counter:
                     continue
-                if "relax::gemm_x6" in r["Kernel_Name"] or "relax::conv1_x6" in r["Kernel_Name"]:
+                if any(k in r["Kernel_Name"] for k in ("relax::gemm_x6", "relax::conv1_x6", "relax::gemm_h2", "relax::gemm_h3")):
                     total += float(r["Counter_Value"])
                     ids.add(r["Dispatch_Id"])
                 elif any(k in r["Kernel_Name"] for k in FLOW_KERNELS):
@@ -167,11 +167,11 @@ def measure_hbm_traffic(workload, clips_per_step, precision, split_k):
             flow_tot[counter] = flow_total * 1024.0
             launches = len(ids)
         if not launches:
-            return None, "no gemm_x6 dispatch in the PMC pass", None
+            return None, "no contraction dispatch in the PMC pass", None
         flow_per_clip = (2.0 * flow_tot["FETCH_SIZE"] + flow_tot["WRITE_SIZE"]) / (2 * clips_per_step) if flow_tot["WRITE_SIZE"] > 0 else None
         return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / launches, (
             f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, one child pass each (1 warm-up + 1 step), "
-            f"(2 x FETCH_SIZE + WRITE_SIZE) over the {launches} gemm_x6 / conv1_x6 dispatches of the pass"), flow_per_clip
+            f"(2 x FETCH_SIZE + WRITE_SIZE) over the {launches} gemm_x6 / conv1_x6 / gemm_h3 dispatches of the pass"), flow_per_clip
     except subprocess.TimeoutExpired:
         return None, "a rocprofv3 pass did not finish in 150 s", None
     finally:
@@ -238,10 +238,13 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=16)
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra measurement of the other precision (exact fp32)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra pinned-host-to-device measurement")
-    ap.add_argument("--precision", default="bf16x6", choices=["fp32", "bf16x3", "bf16x6"],
-                    help="arithmetic of the contraction kernels for the headline loop.  bf16x6 (default): fp32 operands as three bf16 "
-                         "planes, six partial products, fp32 accumulate - error against fp64 of the size of the fp32 path's "
-                         "(tests/test_gpu_x6.py); fp32: exact fp32 MFMA; bf16x3: lower precision, never the headline")
+    ap.add_argument("--precision", default="f16x2", choices=["fp32", "bf16x3", "bf16x6", "f16x2"],
+                    help="arithmetic of the contraction kernels for the headline loop.  f16x2 (default): the plain GEMMs with N %% 256 == 0 "
+                         "(the whole ViT) take fp32 operands as two fp16 planes of a power-of-two multiple of themselves, three (K >= 256) or "
+                         "four partial products on the fp16 MFMA, fp32 accumulate; the convolutions and attention run bf16x6: fp32 operands as "
+                         "three bf16 planes, six partial products.  Both fp32-grade: error against fp64 no larger than the fp32 FMA chain's "
+                         "(tests/test_gpu_h2.py, tests/test_gpu_x6.py).  bf16x6: that arithmetic everywhere; fp32: exact fp32 MFMA; bf16x3: "
+                         "lower precision, never the headline")
     ap.add_argument("--clips-per-step", type=int, default=0,
                     help="clips each rank pushes through the engine per step (one batched pass: B*2*T fragments); default: 2048 "
                          "fragments per pass for configs 2 / 3 / 4 (64 / 32 / 64 clips, dataset pass included), 16 clips for the full pipelines")
@@ -301,7 +304,10 @@ def main():
     eng.set_option("gemm_split_k", args.gemm_split_k)
     precision = eng.precision()          # what the ENGINE computes in (read back from the library, not the flag)
     assert precision == args.precision, (precision, args.precision)
-    x3, x6 = precision == "bf16x3", precision == "bf16x6"
+    x3, h2 = precision == "bf16x3", precision == "f16x2"
+    x6 = precision in ("bf16x6", "f16x2")      # the split-operand kernels (under f16x2 the convolutions and attention stay bf16x6)
+    if h2:
+        assert eng.get_option("h2_form") == 1  # (three products for K >= 256: every f16x2 launch of these workloads; H2_EXECUTED below)
 
     def barrier():
         if world > 1:
@@ -355,7 +361,8 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         prof = {"gemm": eng.profile_read(3 if x6 else 0), "frag": eng.profile_read(1), "gemm_bytes": eng.profile_read(4 if x6 else 2),
-                "flow": eng.profile_read(5), "flow_stage": eng.profile_read(6), "other": eng.profile_read(0 if x6 else 3)}
+                "flow": eng.profile_read(5), "flow_stage": eng.profile_read(6), "other": eng.profile_read(0 if x6 else 3),
+                "h2": eng.profile_read(7), "h2_bytes": eng.profile_read(8)}
         eng.profile_enable(False)
         return elapsed, out, prof
 
@@ -363,9 +370,11 @@ def main():
     step, feat_dim, clips = make_step(args.workload, B, n_resident)
     full = args.workload.startswith("full")
     elapsed, out, prof = timed(step, args.steps, args.warmup)
-    gemm_ms, gemm_flops, gemm_launches = prof["gemm"]
+    x6_ms, x6_flops, x6_launches = prof["gemm"]                 # bf16x6 launches (fp32 / bf16x3: the launches of that kernel)
+    h2_ms, h2_flops, h2_launches = prof["h2"]                   # f16x2 launches (none under the other precisions)
+    gemm_ms, gemm_flops, gemm_launches = x6_ms + h2_ms, x6_flops + h2_flops, x6_launches + h2_launches
     frag_ms, frag_bytes, frag_launches = prof["frag"]
-    _, gemm_alg_bytes, _ = prof["gemm_bytes"]
+    gemm_alg_bytes = prof["gemm_bytes"][1] + prof["h2_bytes"][1]
     flow_ms, flow_bytes, flow_launches = prof["flow"]
     other_ms, other_flops, other_launches = prof["other"]   # contraction launches on the other kernel family
     assert eng.precision() == precision
@@ -391,7 +400,7 @@ def main():
 
     # the other fp32-grade arithmetic, measured beside the headline on the same workload and step function
     fast = None
-    other = "fp32" if x6 else "bf16x6"
+    other = "bf16x6" if h2 else ("fp32" if x6 else "bf16x6")
     if world == 1 and not args.no_fast_mode and not x3:
         eng.set_precision(other)
         for i in range(2):
@@ -414,7 +423,7 @@ def main():
 
     # the other BASELINE configurations on this GPU, a few steps each (the headline stays config 3)
     others = None
-    if world == 1 and not args.no_other_workloads and args.workload == "config3" and x6:
+    if world == 1 and not args.no_other_workloads and args.workload == "config3" and x6:   # (bf16x6 or f16x2)
         del clips, step
         others = {}
         for name, b_o in (("config2", 64), ("config4", 64), ("full2160p", 8)):
@@ -423,11 +432,16 @@ def main():
             e_o, out_o, prof_o = timed(step_o, 3, 1)
             assert out_o.shape == (b_o, dim_o) and bool(torch.isfinite(out_o).all())
             g_ms, g_flops, g_n = prof_o["gemm"]
+            q_ms, q_flops, q_n = prof_o["h2"]
+            t_ms = g_ms + q_ms
             rec = {"value": 3 * b_o / e_o, "unit": "clips/s", "ms_per_step": e_o / 3 * 1e3, "clips_per_step": b_o, "steps": 3,
                    "feature_dim": dim_o,
-                   "roofline": {"bound": "mfma", "kernel": "gemm_x6 + conv1_x6", "unit": "TFLOP/s", "peak": BF16_MATRIX_PEAK_TFLOPS,
-                                "achieved": 6 * g_flops / (g_ms * 1e-3) / 1e12, "frac": 6 * g_flops / (g_ms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS,
-                                "kernel_time_share_of_step": g_ms * 1e-3 / e_o}}
+                   "roofline": {"bound": "mfma", "kernel": "gemm_x6 + conv1_x6" + (" + gemm_h3 (f16x2)" if q_n else ""), "unit": "TFLOP/s",
+                                "peak": BF16_MATRIX_PEAK_TFLOPS,
+                                "achieved": (6 * g_flops + H2_EXECUTED * q_flops) / (t_ms * 1e-3) / 1e12,
+                                "frac": (6 * g_flops + H2_EXECUTED * q_flops) / (t_ms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS,
+                                "algorithmic_tflops": (g_flops + q_flops) / (t_ms * 1e-3) / 1e12,
+                                "kernel_time_share_of_step": t_ms * 1e-3 / e_o}}
             fs = flow_stage_record(prof_o, e_o)
             if fs is not None:
                 rec["roofline_flow_stage"] = fs
@@ -442,7 +456,7 @@ def main():
 
     traffic, traffic_note = hbm_traffic_per_launch(args.workload, B, precision), (
         "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (own passes, FETCH doubled per the gfx950 guide), from the "
-        "committed profile of this workload, batch and precision: profiles/r04_hbm_traffic.json (null when none matches the run)")
+        "committed profile of this workload, batch and precision: profiles/r05_hbm_traffic.json (null when none matches the run)")
     flow_traffic = None
     if world == 1 and not args.no_measure_traffic and x6:
         torch.cuda.synchronize()
@@ -455,7 +469,8 @@ def main():
     if rank == 0:
         clips_total = args.steps * world * B
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        mult = {"fp32": 1.0, "bf16x3": 3.0, "bf16x6": 6.0}[precision]
+        mult = {"fp32": 1.0, "bf16x3": 3.0, "bf16x6": 6.0, "f16x2": 6.0}[precision]
+        executed = (mult * x6_flops + H2_EXECUTED * h2_flops) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0   # matrix-pipe FLOPs per second
         result = {
             "metric": "clips/sec (32 sampled frames, 1080p) feature extraction" if args.workload == "config3"
                       else f"clips/sec feature extraction ({args.workload})",
@@ -473,11 +488,22 @@ def main():
                 "kernel": {"fp32": "conv_gemm_f32 (fp32 implicit-GEMM conv / GEMM, v_mfma_f32_32x32x2_f32)",
                            "bf16x3": "conv_gemm_f32<..., bf16x3> (3 x v_mfma_f32_32x32x16_bf16 per fp32 product; achieved = EXECUTED flops = 3 x algorithmic)",
                            "bf16x6": "gemm_x6 + conv1_x6 (six bf16 partial products per fp32 product on v_mfma_f32_16x16x32_bf16 / 32x32x16; achieved = EXECUTED bf16 flops = 6 x algorithmic, "
-                                     "peak = dense bf16 MFMA)"}[precision],
-                "achieved": achieved * mult, "peak": FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS,
+                                     "peak = dense bf16 MFMA)",
+                           "f16x2": "gemm_h3 (f16x2: three fp16 partial products per fp32 product on v_mfma_f32_16x16x32_f16 - the ViT GEMMs) + gemm_x6 + conv1_x6 "
+                                    "(bf16x6: six bf16 partial products - the ResNet-50 convolutions); achieved = EXECUTED 16-bit MFMA flops of both "
+                                    "families (3 x / 6 x their algorithmic flops) over their summed launch time, peak = dense bf16 / fp16 MFMA (the same rate)"}[precision],
+                "achieved": executed, "peak": FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved * mult / (FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS),
+                "frac": executed / (FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS),
                 "algorithmic_tflops": achieved,
+                "algorithmic_frac": achieved / (FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS),
+                "frac_note": "frac = executed matrix-pipe FLOPs / the dense 16-bit MFMA peak (how busy the pipe is); algorithmic_frac = the fp32 "
+                             "FLOPs of the contractions (2 x MAC) / the same peak (what the arithmetic costs: 3 or 6 pipe products per fp32 product)",
+                "families": {"f16x2": {"launches": h2_launches, "ms_per_step": h2_ms / args.steps,
+                                       "algorithmic_tflops": h2_flops / (h2_ms * 1e-3) / 1e12 if h2_ms > 0 else None, "executed_per_algorithmic": H2_EXECUTED},
+                             "bf16x6" if x6 else precision: {"launches": x6_launches, "ms_per_step": x6_ms / args.steps,
+                                                             "algorithmic_tflops": x6_flops / (x6_ms * 1e-3) / 1e12 if x6_ms > 0 else None,
+                                                             "executed_per_algorithmic": mult}},
                 "traffic": traffic, "traffic_note": traffic_note,
                 "algorithmic_bytes_per_launch": gemm_alg_bytes / max(gemm_launches, 1),
                 "launches": gemm_launches, "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
@@ -540,7 +566,11 @@ def flow_stage_record(prof, elapsed_s, traffic_per_clip=None):
                                "algorithmic_bytes_per_pixel_level_iteration": 56, "launches": it_n,
                                "avg_launch_us": it_ms * 1e3 / max(it_n, 1), "time_share_of_step": it_ms * 1e-3 / elapsed_s}}
     return rec
-DTYPE_TEXT = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into two bf16 terms, fp32 accumulate; reduced precision)",
+H2_EXECUTED = 3.0   # fp16 MFMA products per fp32 product in gemm_h3 at K >= 256 ("h2_form" 1): A[lo] B[hi], A[hi] B[lo], A[hi] B[hi]
+DTYPE_TEXT = {"f16x2": "f32 (fp32-grade split-operand arithmetic, fp32 accumulate: ViT GEMMs on fp32 operands as 2 fp16 planes x a power-of-two "
+                       "scale, 3 partial products on the fp16 MFMA [f16x2]; ResNet-50 convolutions and attention on 3 bf16 planes, 6 partial "
+                       "products on the bf16 MFMA [bf16x6])",
+              "fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into two bf16 terms, fp32 accumulate; reduced precision)",
               "bf16x6": "f32 (fp32 operands as 3 bf16 planes, 6 partial products on the bf16 MFMA, fp32 accumulate: fp32-grade)"}
 
 

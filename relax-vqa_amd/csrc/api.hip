@@ -158,6 +158,7 @@ int relax_create(int device, relax_handle** out) {
     h->device = device;
     if (const char* e = getenv("RELAX_GEMM_SPLIT")) h->gemm.split_k = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_PRECISION")) h->gemm.precision = atoi(e) >= 0 && atoi(e) <= 3 ? atoi(e) : 0;
+    if (const char* e = getenv("RELAX_H2_FORM")) h->gemm.h2_form = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 1;
     if (const char* e = getenv("RELAX_GEMM_VARIANT")) h->gemm.variant = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_VARIANT_N64")) h->gemm.variant_n64 = atoi(e);
     if (const char* e = getenv("RELAX_GEMM_GROUP_M")) h->gemm.group_m = atoi(e) > 0 ? atoi(e) : 1;
@@ -224,6 +225,10 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     else if (k == "flow_seg_rows") h->gemm.flow_seg_rows = value > 0 ? value : 0;
     else if (k == "flow_pyramid_fused") h->gemm.flow_pyramid_fused = value != 0;
     else if (k == "x6_fp32_rows") h->gemm.fp32_rows = value != 0;
+    else if (k == "h2_form") {
+        RELAX_REQUIRE(h, value >= 0 && value <= 2, "relax_set_option: h2_form must be 0, 1 or 2");
+        h->gemm.h2_form = value;
+    }
     else if (k == "h2_stages") {
         RELAX_REQUIRE(h, value == 3 || value == 4, "relax_set_option: h2_stages must be 3 or 4");
         h->gemm.h2_stages = value;
@@ -260,6 +265,7 @@ int relax_get_option(relax_handle* h, const char* key, int* value) {
     else if (k == "flow_pyramid_fused") *value = h->gemm.flow_pyramid_fused;
     else if (k == "x6_fp32_rows") *value = h->gemm.fp32_rows;
     else if (k == "h2_stages") *value = h->gemm.h2_stages;
+    else if (k == "h2_form") *value = h->gemm.h2_form;
     else if (k == "debug_poison") *value = h->gemm.debug_poison;
     else {
         set_error(h, "relax_get_option: unknown option '%s'", key);

@@ -419,6 +419,299 @@ __global__ __launch_bounds__(512, 2) void gemm_h2(const H2Params p) {
 #endif
 }
 
+// ---- the same contraction with a 32-deep K step ("BK = 32"), and the form the product runs ----------------------------------
+// One instruction contracts the SAME plane of two consecutive 16-k chunks: lanes with k group g < 2 hold the halves of chunk 2j,
+// g >= 2 those of chunk 2j + 1, i.e. the fragment is 32 consecutive k of one plane.  Per 32 k and 16 x 16 outputs
+//        A[lo] . B[hi]      A[hi] . B[lo]      A[hi] . B[hi]                                    (smallest first)
+// THREE instructions: the product al bl (2^-22 of the full product, the size of the representation error itself) is dropped for
+// K >= 256, where the measured error against fp64 is the same with and without it (tools/micro/mfma_f16x2.hip part 1, (b) against (c):
+// 2.83e-7 / 2.84e-7 at K = 768, 5.47e-7 / 5.47e-7 at K = 3072 - the fp32 accumulator's own rounding is what is left - and both below the
+// fp32 FMA chain's 4.4e-7 / 8.8e-7); FOUR = true adds A[lo] . B[lo] in front (short K: at K = 32 the three-product error, 9.7e-8, would
+// sit above the chain's 9.0e-8).  48 MFMAs per wave and 16 k (v1 above: 64, bf16x6: 96), 12 ds_read_b128 (16, 32), half the barriers.
+// LDS: two stages of [hi image: 512 rows x 64 B][lo image: the same] = 64 KB; unit u (8 k) of row r sits in slot u ^ f((r >> 2) & 3),
+// f = {0, 3, 2, 1}: conflict-free ds_read_b128 (a 16-lane group holds rows {0-3, 12-15} at one parity of g and {4-11} at the other);
+// the permutation is applied on the SOURCE offset of the DMA.  The global format keeps its 16-k chunks ([16 hi][16 lo]): unit u of the
+// 32-k step = chunk u >> 1, half u & 1.  Eight DMA pieces per wave and step, one in front of each MFMA group of the region; the pieces of
+// step k+2 go into the stage step k has just left and have the rest of the region to land (two stages: nothing stays in flight across a
+// barrier).
+constexpr int H3_STAGE = (H2_BM + H2_BN) * 128;   // 64 KB
+constexpr int H3_NSTG = 2;
+
+template <bool FOUR>
+__global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
+#if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (no __amdgpu_buffer_rsrc_t there)
+    constexpr int BM = H2_BM, BN = H2_BN, STAGE = H3_STAGE, NSTG = H3_NSTG, IMG = STAGE / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // work unit -> (tile, K slice)
+    int tile, kt_begin, kt_end, slice = -1, split_tile = 0;
+    {
+        const int nk_all = p.K >> 5;   // 32-k steps
+        const int b = blockIdx.x;
+        if (b < p.full_tiles) {
+            tile = xcd_remap_h2(b, p.full_tiles);
+            kt_begin = 0;
+            kt_end = nk_all;
+        } else {
+            const int u = b - p.full_tiles;
+            split_tile = u / p.nsplit;
+            slice = u - split_tile * p.nsplit;
+            tile = p.full_tiles + split_tile;
+            kt_begin = (int)((int64_t)nk_all * slice / p.nsplit);
+            kt_end = (int)((int64_t)nk_all * (slice + 1) / p.nsplit);
+        }
+    }
+    int tm, tn;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int g = tile / per_group;
+        const int first = g * p.group_m;
+        const int gsz = p.tiles_m - first < p.group_m ? p.tiles_m - first : p.group_m;
+        const int w = tile - g * per_group;
+        tm = first + w % gsz;
+        tn = w / gsz;
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+    H2_STAMP(0);
+
+    // ---- DMA descriptors.  A piece = 1 KiB = 16 rows x 64 B of one image; the images hold 32 pieces each (activation rows: 0 .. 15,
+    // weight rows: 16 .. 31).  Piece j of this wave: image j >> 2 (hi, lo), piece wave + 8 (j & 3) of it; lane l fills slot l & 3 of row
+    // 16 * piece + (l >> 2), which holds unit slot ^ f(row) = chunk (unit >> 1), half (unit & 1) of the step.  The hi and the lo piece
+    // of the same rows share the per-lane offset (the plane is + 32 B in the scalar offset): four offsets.
+    const int64_t row_bytes = (int64_t)p.K * 4;
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
+    {
+        const int64_t left = (int64_t)(p.M - m0) * row_bytes;
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a + (int64_t)m0 * row_bytes), 0,
+                                                   (int)(left < kH2MaxRecords ? left : kH2MaxRecords), 0x00020000);
+        rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + (int64_t)n0 * row_bytes), 0, (int)(BN * row_bytes), 0x00020000);
+    }
+    unsigned voff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int trow = (wave + 8 * q) * 16 + (lane >> 2);           // 0 .. 511
+        const int unit = (lane & 3) ^ ((4 - ((trow >> 2) & 3)) & 3);
+        const int off = (unit >> 1) * kH2ChunkBytes + (unit & 1) * 16;
+        if (q < 2) voff[q] = m0 + trow < p.M ? (unsigned)(trow * (int)row_bytes + off) : kH2OutOfRange;
+        else voff[q] = (unsigned)((trow - BM) * (int)row_bytes + off);
+    }
+    int d_kt = kt_begin;   // the next 32-k step to issue (steps are issued in order)
+#define H3_ISSUE_PIECE(st_, j_)                                                                                         \
+    {                                                                                                                   \
+        const int soff_ = d_kt * (2 * kH2ChunkBytes) + ((j_) >> 2) * 32;                                                \
+        const int dst_ = (st_) * STAGE + ((j_) >> 2) * IMG + (wave + 8 * ((j_) & 3)) * 1024;                             \
+        if (((j_) & 3) < 2) { H2_DMA(rsrc_a, dst_, voff[(j_) & 3], soff_); }                                             \
+        else { H2_DMA(rsrc_w, dst_, voff[(j_) & 3], soff_); }                                                            \
+    }
+
+    floatx4 acc[8][4];   // 16-row A fragments x 16-column B fragments of the wave's 128 x 64
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets: lane (r, g) reads unit g (k = 8g .. 8g+7 of the 32-k step) of its row, hi image; lo image: + IMG
+    const int r16 = lane & 15, g16 = lane >> 4;
+    const int f16 = (4 - ((r16 >> 2) & 3)) & 3;
+    const int a_h = (wm * 128 + r16) * 64 + ((g16 ^ f16) << 4);
+    const int b_h = (BM + wn * 64 + r16) * 64 + ((g16 ^ f16) << 4);
+    h2k_f16x8 xb[2][4][2], ya[2][2];   // [set][fragment][hi, lo], [buffer][hi, lo]
+#define H3_READ_XB(set_, sp_)                                                                                           \
+    _Pragma("unroll") for (int y = 0; y < 4; ++y) {                                                                     \
+        xb[set_][y][0] = *reinterpret_cast<const h2k_f16x8*>((sp_) + b_h + y * 16 * 64);                                \
+        xb[set_][y][1] = *reinterpret_cast<const h2k_f16x8*>((sp_) + b_h + y * 16 * 64 + IMG);                          \
+    }
+#define H3_READ_A(buf_, e_, sp_)                                                                                        \
+    {                                                                                                                   \
+        ya[buf_][0] = *reinterpret_cast<const h2k_f16x8*>((sp_) + a_h + (e_) * 16 * 64);                                \
+        ya[buf_][1] = *reinterpret_cast<const h2k_f16x8*>((sp_) + a_h + (e_) * 16 * 64 + IMG);                          \
+        __builtin_amdgcn_sched_barrier(0);   /* issued HERE, a whole MFMA group ahead of their use */                   \
+    }
+#define H3_MFMAS(set_, buf_, e_)                                                                                        \
+    {                                                                                                                   \
+        if (FOUR) {                                                                                                     \
+            _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                               \
+                acc[e_][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ya[buf_][1], xb[set_][y][1], acc[e_][y], 0, 0, 0);  \
+        }                                                                                                               \
+        _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                                   \
+            acc[e_][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ya[buf_][1], xb[set_][y][0], acc[e_][y], 0, 0, 0);      \
+        _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                                   \
+            acc[e_][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ya[buf_][0], xb[set_][y][1], acc[e_][y], 0, 0, 0);      \
+        _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                                   \
+            acc[e_][y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ya[buf_][0], xb[set_][y][0], acc[e_][y], 0, 0, 0);      \
+        __builtin_amdgcn_sched_barrier(0);   /* nothing moves across: the software pipeline below is the schedule */     \
+    }
+    // region k: [wait for step k+1 (every piece of this wave: two stages), barrier, B forms and A fragment 0 of step k+1, piece 0 of step
+    // k+2 into the stage step k has left, MFMAs of fragment 7 of step k, then fragments 0..6 of step k+1 each behind the read of the next
+    // one and one more piece]; xs_ = k & 1 = the register set of B = the LDS stage of step k.
+#define H3_REGION(xs_, has_next_, has_d_)                                                                               \
+    {                                                                                                                   \
+        const char* sn_ = smem + ((xs_) ^ 1) * STAGE;                                                                   \
+        if (has_next_) {                                                                                                \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+            __builtin_amdgcn_s_barrier();                                                                               \
+            H3_READ_XB((xs_) ^ 1, sn_);                                                                                 \
+            H3_READ_A(0, 0, sn_);                                                                                       \
+            if (has_d_) H3_ISSUE_PIECE(xs_, 0);                                                                         \
+        }                                                                                                               \
+        H3_MFMAS(xs_, 1, 7);                                                                                            \
+        if (has_next_) {                                                                                                \
+            _Pragma("unroll") for (int e = 0; e < 7; ++e) {                                                             \
+                H3_READ_A((e + 1) & 1, e + 1, sn_);                                                                     \
+                if (has_d_) H3_ISSUE_PIECE(xs_, e + 1);                                                                 \
+                H3_MFMAS((xs_) ^ 1, e & 1, e);                                                                          \
+            }                                                                                                           \
+            if (has_d_) ++d_kt;                                                                                         \
+        }                                                                                                               \
+    }
+
+    const int nk = kt_end - kt_begin;
+    {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) H3_ISSUE_PIECE(0, j);
+        ++d_kt;
+        if (nk > 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) H3_ISSUE_PIECE(1, j);
+            ++d_kt;
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // step 0 has landed; step 1 stays in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    H3_READ_XB(0, smem);
+    H3_READ_A(0, 0, smem);
+    H2_STAMP(1);
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+        H3_READ_A((e + 1) & 1, e + 1, smem);
+        H3_MFMAS(0, e & 1, e);
+    }
+    {
+        // has_next = step k+1 exists; has_d = step k+2 exists (its DMA is issued in region k); literal `true` in the steady state
+        int k = 0;
+        for (; k + 3 < nk; k += 2) {
+            H3_REGION(0, true, true);
+            H3_REGION(1, true, true);
+        }
+        for (; k < nk; k += 2) {
+            H3_REGION(0, k + 1 < nk, k + 2 < nk);
+            if (k + 1 < nk) H3_REGION(1, k + 2 < nk, k + 3 < nk);
+        }
+    }
+#undef H3_REGION
+#undef H3_MFMAS
+#undef H3_READ_A
+#undef H3_READ_XB
+#undef H3_ISSUE_PIECE
+    H2_STAMP(2);
+    __syncthreads();   // no DMA is in flight and every fragment is in registers: the stages become the epilogue staging
+
+    // ---- epilogue, staged through LDS in 64-row passes (C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r); a
+    // thread owns two groups of 4 columns: adjacent (8 consecutive columns = whole 16-byte plane units) when planes leave, half a
+    // tile row apart for plain fp32 traffic (every store / load instruction then covers contiguous 512-byte row segments)
+    float* stg = reinterpret_cast<float*>(smem);
+    constexpr int LDC = BN + 4;
+    constexpr int EP_ROWS = 64;
+    constexpr int C8 = BN / 8;
+    constexpr int NT = 512;
+    static_assert(EP_ROWS * LDC * 4 <= NSTG * STAGE, "epilogue pass must fit the staging LDS");
+    constexpr int EP_STEP = NT / C8;
+    constexpr int EP_ITERS = EP_ROWS / EP_STEP;
+    const bool planes = p.out_h2 != nullptr;   // workgroup-uniform
+    const int lcA = planes ? (tid % C8) * 8 : (tid % C8) * 4;
+    const int lcB = planes ? lcA + 4 : lcA + BN / 2;
+    const int lr0 = tid / C8;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bias_a = zero4, bias_b = zero4, cs_a = zero4, cs_b = zero4;
+    if (slice < 0) {
+        cs_a = *reinterpret_cast<const f32x4*>(p.colscale + n0 + lcA);
+        cs_b = *reinterpret_cast<const f32x4*>(p.colscale + n0 + lcB);
+        if (p.bias) {
+            bias_a = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcA);
+            bias_b = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcB);
+        }
+    }
+    const bool interior = m0 + BM <= p.M;   // workgroup-uniform
+#pragma unroll
+    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
+        if (pass > 0) __syncthreads();
+        f32x4 ra[EP_ITERS], rb[EP_ITERS];
+        float rs[EP_ITERS];
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) {
+            const int m = m0 + pass * EP_ROWS + it * EP_STEP + lr0;
+            ra[it] = zero4;
+            rb[it] = zero4;
+            rs[it] = 1.f;
+            if (slice < 0 && (interior || m < p.M)) {
+                if (p.residual) {
+                    const float* r = p.residual + (int64_t)m * p.N + n0;
+                    ra[it] = *reinterpret_cast<const f32x4*>(r + lcA);
+                    rb[it] = *reinterpret_cast<const f32x4*>(r + lcB);
+                }
+                if (p.rowscale) rs[it] = p.rowscale[m];
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int rb0 = wm * 128 + x * 16;
+            if (rb0 / EP_ROWS == pass) {
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stg[(rb0 % EP_ROWS + 4 * g16 + r) * LDC + wn * 64 + y * 16 + r16] = acc[x][y][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) {
+            const int lr = it * EP_STEP + lr0;
+            const int trow = pass * EP_ROWS + lr;
+            const int m = m0 + trow;
+            if (!interior && m >= p.M) continue;
+            f32x4 va = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lcA);
+            f32x4 vb = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lcB);
+            if (slice >= 0) {   // K slice of a split tile: raw partial sums, the epilogue runs in splitk_finish_h2
+                float* o = p.partial + ((int64_t)split_tile * p.nsplit + slice) * (BM * BN) + (int64_t)trow * BN;
+                *reinterpret_cast<f32x4*>(o + lcA) = va;
+                *reinterpret_cast<f32x4*>(o + lcB) = vb;
+                continue;
+            }
+            // powers of two: exact.  Then (acc + bias) + residual, the same order on every path
+            va = va * (cs_a * rs[it]) + bias_a;
+            vb = vb * (cs_b * rs[it]) + bias_b;
+            if (p.residual) {
+                va += ra[it];
+                vb += rb[it];
+            }
+            if (p.act == 1) {
+                va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};
+                vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};
+            } else if (p.act == 2) {
+                va = gelu_erf4(va);
+                vb = gelu_erf4(vb);
+            }
+            const int64_t o = (int64_t)m * p.N + n0;
+            if (p.out) {
+                *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
+                *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
+            }
+            if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, p.out_scale);   // (planes: lcB = lcA + 4)
+        }
+    }
+    H2_STAMP(3);
+#endif
+}
+
 // Sums the K slices of the split tiles in slice order (deterministic) and applies the epilogue.
 __global__ __launch_bounds__(256) void splitk_finish_h2(const H2Params p) {
     constexpr int BM = H2_BM, BN = H2_BN;
@@ -473,16 +766,18 @@ __global__ __launch_bounds__(256) void splitk_finish_h2(const H2Params p) {
     if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lc, va, vb, p.out_scale);
 }
 
-template <int NSTG>
+// FORM 0: gemm_h2<3>, 1: gemm_h2<4> (16-k steps, four products), 2: gemm_h3<false> (32-k steps, three products), 3: gemm_h3<true> (four)
+template <int FORM>
 static int launch_h2_variant(relax_handle* h, H2Params& p, hipStream_t s) {
     constexpr int BM = H2_BM, BN = H2_BN;
+    constexpr bool BK32 = FORM >= 2;
     p.tiles_n = p.N / BN;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.ntiles = p.tiles_m * p.tiles_n;
     p.group_m = h->gemm.group_m;
     p.partial = nullptr;
     // Tail split-K: the last, partial round of tiles is cut along K (cost model: host_logic.cpp, shared with the other kernels)
-    const host::TailSplit ts = host::choose_tail_split(p.ntiles, 256, p.K / 16, 8, h->gemm.split_k && !p.no_split);
+    const host::TailSplit ts = host::choose_tail_split(p.ntiles, 256, BK32 ? p.K / 32 : p.K / 16, BK32 ? 4 : 8, h->gemm.split_k && !p.no_split);
     p.full_tiles = ts.full_tiles;
     p.nsplit = ts.nsplit;
     if (p.nsplit > 1) {
@@ -490,15 +785,21 @@ static int launch_h2_variant(relax_handle* h, H2Params& p, hipStream_t s) {
         RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
         p.partial = static_cast<float*>(h->splitk_ws.p);
     }
-    constexpr size_t lds = (size_t)NSTG * H2_STAGE;
+    constexpr size_t lds = BK32 ? (size_t)H3_NSTG * H3_STAGE : (size_t)(FORM == 1 ? 4 : 3) * H2_STAGE;
+    auto kernel = [] {
+        if constexpr (FORM == 0) return &gemm_h2<3>;
+        else if constexpr (FORM == 1) return &gemm_h2<4>;
+        else if constexpr (FORM == 2) return &gemm_h3<false>;
+        else return &gemm_h3<true>;
+    }();
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h2<NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[h->device] = true;
     }
     const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
     H2_STAMPS_BEFORE_LAUNCH(h, p, units);
-    hipLaunchKernelGGL((gemm_h2<NSTG>), dim3(units), dim3(512), lds, s, p);
+    hipLaunchKernelGGL(kernel, dim3(units), dim3(512), lds, s, p);
     H2_STAMPS_AFTER_LAUNCH(h, p, units, s);
     if (p.nsplit > 1)
         hipLaunchKernelGGL(splitk_finish_h2, dim3(BM * BN / 8 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
@@ -528,7 +829,12 @@ int launch_gemm_h2(relax_handle* h, const GemmDescH2& d, hipStream_t s) {
                          (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_h2 ? 4.0 : 0.0) + (d.residual ? 4.0 : 0.0));
     int span;
     RELAX_TRY(prof_begin(h, s, 5, flops, &span, bytes));
-    const int rc = h->gemm.h2_stages == 4 ? launch_h2_variant<4>(h, p, s) : launch_h2_variant<3>(h, p, s);
+    // "h2_form": 1 (default) = 32-k steps with three products for K >= 256 and four below (and 16-k steps for K % 32 != 0);
+    // 0 = 16-k steps, four products ("h2_stages" LDS stages); 2 = 32-k steps, four products at every K
+    int rc;
+    if (h->gemm.h2_form == 0 || p.K % 32 != 0) rc = h->gemm.h2_stages == 4 ? launch_h2_variant<1>(h, p, s) : launch_h2_variant<0>(h, p, s);
+    else if (h->gemm.h2_form == 2 || p.K < 256) rc = launch_h2_variant<3>(h, p, s);
+    else rc = launch_h2_variant<2>(h, p, s);
     if (rc != RELAX_OK) { prof_abort(h, span); return rc; }
     RELAX_TRY(prof_end(h, s, span));
     return RELAX_OK;

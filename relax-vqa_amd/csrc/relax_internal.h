@@ -204,10 +204,12 @@ struct Profiler {
 namespace relax {
 // Tuning / reproducibility switches of the contraction kernel (relax_set_option; env defaults RELAX_GEMM_*).
 struct GemmOptions {
-    int precision = 2; // "gemm_precision": 3 = f16x2 ( fp32-grade: two fp16 planes, four products in two MFMAs - gemm_h2.hip - for the
-                       // plain GEMMs with N % 256 == 0, i.e. the whole ViT; everything else as under 2), 2 = bf16x6 (default, fp32-grade), 0 = exact fp32
+    int precision = 3; // "gemm_precision": 3 = f16x2 (default,  fp32-grade: two fp16 planes, four products in two MFMAs - gemm_h2.hip - for the
+                       // plain GEMMs with N % 256 == 0, i.e. the whole ViT; everything else as under 2), 2 = bf16x6 (fp32-grade), 0 = exact fp32
                        // MFMA, 1 = bf16x3 split products (~1e-5 relative)
-    int h2_stages = 3; // "h2_stages": LDS stages of the f16x2 kernel (3 or 4; same bits)
+    int h2_stages = 3; // "h2_stages": LDS stages of the 16-k form of the f16x2 kernel (3 or 4; same bits)
+    int h2_form = 1;   // "h2_form": 1 = 32-k steps, three products (al bl dropped) for K >= 256, four below; 0 = 16-k steps, four products;
+                       // 2 = 32-k steps, four products
     int split_k = 1;   // "gemm_split_k": tail split-K on (1) / off (0: K sums are batch-invariant bit for bit)
     int variant = -1;  // "gemm_variant": exact-fp32 kernel only: pin the tile variant for N % 128 == 0 problems, -1 = automatic
     int variant_n64 = -1;  // "gemm_variant_n64": same for N % 128 != 0 (N = 64 layers)

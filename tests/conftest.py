@@ -43,9 +43,9 @@ def _engine_precision_is_restored(request):
         return
     from tests.gpu_common import engine
     eng = engine()
-    eng.set_precision("bf16x6")
+    eng.set_precision("f16x2")
     yield
-    eng.set_precision("bf16x6")
+    eng.set_precision("f16x2")
 
 
 @pytest.fixture(params=["bf16x6", "fp32", "f16x2"])

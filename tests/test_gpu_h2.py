@@ -63,9 +63,11 @@ def test_permutation_matrix_copies_the_two_plane_value_bit_for_bit(h2):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 256, 32), (1000, 256, 512), (197 * 3, 2304, 768), (777, 3072, 768), (12608, 768, 3072),
-                                   (2049, 512, 4608), (256 * 40, 768, 768)])
-def test_error_is_no_larger_than_the_fp32_paths(M, N, K):
+                                   (2049, 512, 4608), (256 * 40, 768, 768), (700, 256, 256), (300, 256, 64)])
+@pytest.mark.parametrize("form", [1, 0, 2], ids=["k32_three_products", "k16_four_products", "k32_four_products"])
+def test_error_is_no_larger_than_the_fp32_paths(M, N, K, form):
     eng = engine()
+    eng.set_option("h2_form", form)
     A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
     ref = A.double() @ W.double().T
     eng.set_precision("fp32")
@@ -82,6 +84,7 @@ def test_error_is_no_larger_than_the_fp32_paths(M, N, K):
           f"f16x2 {e2.mean().item() / scale:.3e};  max: fp32 {e32.max().item() / scale:.3e}  bf16x6 {e6.max().item() / scale:.3e}  "
           f"f16x2 {e2.max().item() / scale:.3e}")
     assert_close(got, ref.float().numpy(), f"f16x2 gemm {M}x{N}x{K}")
+    eng.set_option("h2_form", 1)
     assert e2.mean().item() <= 1.05 * e32.mean().item() + 1e-12, "f16x2 mean error exceeds the fp32 FMA chain's"
     assert e2.max().item() <= 1.5 * e32.max().item() + 1e-12, "f16x2 worst error exceeds the fp32 FMA chain's"
 
@@ -135,11 +138,15 @@ def test_split_k_is_deterministic_and_optional_and_stages_agree(h2):
     A, W = _rand(M, K, seed=8).cuda(), _rand(N, K, seed=9, scale=K ** -0.5).cuda()
     a = h2.op_gemm(A, W)
     assert torch.equal(a, h2.op_gemm(A, W))
-    h2.set_option("h2_stages", 4)
+    h2.set_option("h2_form", 0)          # the 16-k form of the loop: 3 or 4 LDS stages
     try:
-        assert torch.equal(a, h2.op_gemm(A, W))
+        b3 = h2.op_gemm(A, W)
+        h2.set_option("h2_stages", 4)
+        assert torch.equal(b3, h2.op_gemm(A, W))
     finally:
         h2.set_option("h2_stages", 3)
+        h2.set_option("h2_form", 1)
+    assert_close(b3, a.cpu().numpy(), "16-k four-product form vs 32-k three-product form", rtol=1e-4, atol_frac=1e-5)
     h2.set_option("gemm_split_k", 0)
     try:
         whole = h2.op_gemm(A, W)

@@ -26,10 +26,11 @@ def x6():
     eng.set_precision(prev)
 
 
-def test_bf16x6_is_the_default_arithmetic():
+def test_f16x2_is_the_default_arithmetic():
+    """(f16x2 = two fp16 planes for the plain GEMMs with N % 256 == 0 - the ViT -, bf16x6 for everything else: tests/test_gpu_h2.py)"""
     from relax_vqa_amd.engine import RelaxEngine
     eng = RelaxEngine(0)
-    assert eng.precision() == "bf16x6"
+    assert eng.precision() == "f16x2"
     eng.close()
 
 
@@ -280,7 +281,7 @@ def test_conv_geometries_outside_the_x6_kernel_fall_back_to_the_fp32_kernel(Nimg
     """Round-2 advice: under the default arithmetic relax_op_conv2d_nhwc must keep accepting what the fp32 kernel accepted
     (e.g. a 7x7 filter with Cin % 32 == 0) instead of failing with 'more than 32 taps'."""
     eng = engine()
-    assert eng.precision() == "bf16x6"
+    assert eng.precision() == "f16x2"      # (the default; convolutions run bf16x6 under it)
     x = _rand(Nimg, Cin, H, H, seed=17)
     w = _rand(Cout, Cin, k, k, seed=18, scale=(Cin * k * k) ** -0.5)
     ref = F.conv2d(x.double(), w.double(), None, stride=stride, padding=pad).float().numpy()

@@ -3,6 +3,7 @@
 # and no ablation switches: a diagnostic kernel exists in the variant translation units tools/abl/*_stamps.hip alone (each defines the
 # hooks and #includes the product file), so no -D on the product build can make librelax_hip.so record stamps or return wrong numbers.
 #   tools/build_ablations.sh x6stamps       bf16x6 kernel with per-phase cycle stamps (prints per launch, syncs)
+#   tools/build_ablations.sh h2stamps       f16x2 kernel with per-phase cycle stamps (prints per launch, syncs)
 #   tools/build_ablations.sh flowstamps     fused Farneback iteration with tick stamps per phase of a step (tools/flow_stamps.py prints them)
 #   tools/build_ablations.sh a6stamps       bf16x6 attention kernel with ticks per phase of an item (tools/attn_stamps.py prints them;
 #                                           overwrites the first floats of the fp32 output: timing only)
@@ -17,13 +18,14 @@ make -s
 mkdir -p ../../tools/abl
 CC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-function"
 FLOWCC="$CC -fno-slp-vectorize -ffp-contract=off"   # as the Makefile builds flow.hip
-OBJS="api.o fragment.o flow.o resize.o gemm.o gemm_x6.o conv1_x6.o attention_x6.o layers.o resnet50.o vit.o head.o host_logic.o"
+OBJS="api.o fragment.o flow.o resize.o gemm.o gemm_x6.o gemm_h2.o conv1_x6.o attention_x6.o layers.o resnet50.o vit.o head.o host_logic.o"
 link() {  # link <replaced object> <new object> <output name>
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 ${OBJS/$1/$2} -o ../../tools/abl/librelax_$3.so
 }
 for n in "$@"; do
   case "$n" in
     x6stamps) $CC -I. -c ../../tools/abl/gemm_x6_stamps.hip -o /tmp/gemm_x6_stamps.o; link gemm_x6.o /tmp/gemm_x6_stamps.o x6stamps ;;
+    h2stamps) $CC -I. -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_stamps.o; link gemm_h2.o /tmp/gemm_h2_stamps.o h2stamps ;;
     flowstamps) $FLOWCC -I. -c ../../tools/abl/flow_stamps.hip -o /tmp/flow_stamps.o; link flow.o /tmp/flow_stamps.o flowstamps ;;
     a6stamps) $CC -I. -c ../../tools/abl/attention_x6_stamps.hip -o /tmp/attention_x6_stamps.o; link attention_x6.o /tmp/attention_x6_stamps.o a6stamps ;;
     *) echo "unknown diagnostic build: $n" >&2; exit 2 ;;
