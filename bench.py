@@ -259,6 +259,19 @@ def main():
                     help="dataset mode: after the device-resident pass, the same pass with every clip living in (pageable) host memory - "
                          "loader threads stage it in pinned buffers, a side stream copies batch k+1 under the compute of batch k "
                          "(relax-vqa_amd/dataset.py); reported beside `value` as `host_fed` with `h2d_hidden_frac`")
+    ap.add_argument("--stub-compute-ms", type=float, default=0.0,
+                    help="dataset mode, host-feed REHEARSAL: the backbones are replaced by a device-side wait of this many milliseconds per "
+                         "batch (every clip of the batch is still read once on the device, so its copy must have landed).  With "
+                         "RELAX_DIST_BACKEND=gloo and --gpus 8 on a one-GPU box the loaders, pinned pools and copy streams of eight ranks run "
+                         "at once against one device: what is measured is the HOST side of an 8-rank pass (staging and H2D rates, pinned "
+                         "memory), never a feature-extraction rate; the record says so and carries no `value`")
+    ap.add_argument("--from-frame-files", default=None, metavar="DIR",
+                    help="dataset mode: the clips are read from sampled-frame PNG files under DIR ({video}_{n}.png / {video}_{n}_next.png, "
+                         "written there once from synthetic frames if absent) by sampling.load_clip_from_frames in the loader threads, "
+                         "decoded straight into pinned staging memory: the ingest rate of a from-files pass (PNG decode stays outside the "
+                         "metric: reported as `from_frame_files`, never as `value`)")
+    ap.add_argument("--loader-workers-sweep", default=None, metavar="N,N,...",
+                    help="with --from-frame-files: repeat the from-files pass for each of these loader-thread counts")
     ap.add_argument("--prefetch", type=int, default=2, help="dataset mode: batches the loader threads run ahead of the engine (0: inline, no threads)")
     ap.add_argument("--loader-workers", type=int, default=8, help="dataset mode: loader threads per rank")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short extra measurements of configs 2 / 4 / 5")
@@ -293,6 +306,15 @@ def main():
     H, W, T, use_vit = WORKLOADS[args.workload]
 
     torch.cuda.set_device(local_rank)
+    if args.dataset_clips and args.stub_compute_ms > 0:      # host-feed rehearsal: no engine (N ranks may share one GPU's memory)
+        rec = host_feed_rehearsal(torch.device("cuda", local_rank), 768, args.workload, args.dataset_clips, args.clips_per_step, rank, world,
+                                  args.stub_compute_ms, prefetch=args.prefetch, workers=args.loader_workers, n_resident=args.resident_clips or 4)
+        if rank == 0:
+            print(json.dumps(rec))
+        if world > 1:
+            rdist.barrier()
+            dist.destroy_process_group()
+        return
     eng = RelaxEngine(local_rank)
     rn_sd = synth.resnet50_state_dict()
     vit_sd = synth.vit_state_dict("vit_base")
@@ -581,7 +603,117 @@ def workload_text(name):
             + (" + whole-frame features + Farneback flow fragments (35203-d)" if name.startswith("full") else "") + ", random-init weights")
 
 
-def dataset_pass(eng, workload, n, B, rank, world, split_k, host_clips=False, prefetch=2, workers=8, n_resident=4, warmup=1, dump=None):
+class StubEngine:
+    """The engine of the host-feed rehearsal: clip_vectors reads one line of every clip on the device (so the clip's copy must have
+    landed) and then holds the stream for `ms` milliseconds; returns zeros.  Same call signature and device as RelaxEngine."""
+
+    def __init__(self, device, vit_dim, ms):
+        self.device, self.vit_dim, self.ms = device, vit_dim, ms
+        torch.cuda._sleep(1000)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        torch.cuda._sleep(20_000_000)
+        e.record()
+        torch.cuda.synchronize()
+        self.cycles_per_ms = 20_000_000 / s.elapsed_time(e)
+
+    def clip_vectors(self, clips, resnet=True, vit=True, per_frame=False):
+        acc = torch.zeros((), dtype=torch.int64, device=self.device)
+        for c in clips:                                                        # every clip is read on the device, in stream order
+            acc += c.reshape(-1)[:: max(c.numel() // 4096, 1)].sum()
+        torch.cuda._sleep(int(self.ms * self.cycles_per_ms))
+        F = (13120 + 2051 if resnet else 0) + (6 * self.vit_dim if vit else 0)
+        return torch.zeros((len(clips), F), dtype=torch.float32, device=self.device) + (acc * 0).float()
+
+
+def host_feed_rehearsal(device, vit_dim, workload, n, B, rank, world, stub_ms, prefetch=2, workers=8, n_resident=4):
+    """Eight (or `world`) ranks' HOST side at once: every rank runs the sharded dataset pass over clips that live in pageable host
+    memory - loader threads, pinned pool, copy stream, as in production - against a stand-in engine that waits `stub_ms` per batch.
+    On a one-GPU box (RELAX_DIST_BACKEND=gloo) all ranks share the device and its ONE PCIe link, so the H2D figure is the rate of
+    that link shared by the ranks; the staging figure (pageable -> pinned, on the host's cores and memory) and the pinned totals are
+    what an 8-GPU node's host would see.  -> the record (rank 0 prints it)."""
+    from relax_vqa_amd import dataset
+    H, W, T, use_vit = WORKLOADS[workload]
+    host = [synth.synthetic_clip(T, H, W, clip_id=700 + i, distinct=2) for i in range(n_resident)]
+    stub = StubEngine(device, vit_dim, stub_ms)
+    kw = dict(clips_per_step=B, resnet=True, vit=use_vit, rank=rank, world=world, prefetch=prefetch, workers=workers, batch_invariant=False)
+
+    def sync():
+        if world > 1:
+            rdist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_pass(source):
+        dataset.extract_dataset_clips(source, min(n, (prefetch + 2) * B * world), stub, **kw)     # warm-up: pins the pool
+        sync()
+        t = {}
+        t0 = time.perf_counter()
+        _, errors = dataset.extract_dataset_clips(source, n, stub, timings=t, **kw)
+        sync()
+        t["wall_s"] = time.perf_counter() - t0
+        assert not errors, errors[:3]
+        return t
+
+    clip_bytes = host[0].nbytes
+    copy = timed_pass(lambda i: host[i % n_resident])                    # pageable source: staged by a loader-thread copy
+    def decode_into(i, alloc):                                           # `alloc` protocol: "decoded" straight into pinned memory
+        out = alloc(host[i % n_resident].shape)
+        np.copyto(out, host[i % n_resident])
+        return out
+    direct = timed_pass(decode_into)
+    per_rank = {"rank": rank, "clips": len(rdist.shard_clips(n, rank, world)),
+                "copy": {k: copy[k] for k in ("wall_s", "loader_wait_s", "h2d_bytes", "staged_bytes", "pinned_peak_bytes", "pinned_live_bytes",
+                                             "pinned_pool_limit_bytes", "loader_cpus")},
+                "direct": {k: direct[k] for k in ("wall_s", "loader_wait_s", "h2d_bytes", "staged_bytes", "pinned_peak_bytes", "pinned_live_bytes")}}
+    allr = rdist.gather_objects(per_rank, world)
+    wall_c = max(r["copy"]["wall_s"] for r in allr)
+    wall_d = max(r["direct"]["wall_s"] for r in allr)
+    need = {"config3": 101.7, "config4": 200.0, "config2": 600.0}.get(workload, 0.0) * clip_bytes / 1e9     # GB/s per GPU at this round's rates
+    return {
+        "what": f"host-feed REHEARSAL, not a feature-extraction rate: {world} ranks ({dist.get_backend() if world > 1 else 'single process'}) sharing "
+                f"{torch.cuda.device_count()} GPU(s); backbones replaced by a {stub_ms} ms device-side wait per batch of {B} clips",
+        "workload": workload_text(workload), "ranks": world, "gpus_on_box": torch.cuda.device_count(), "clips": n, "clip_MB": clip_bytes / 1e6,
+        "clips_per_step_per_rank": B, "prefetch_batches": prefetch, "loader_workers_per_rank": workers,
+        "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(),
+        "staged_through_a_copy": {"aggregate_clips_per_s": n / wall_c, "aggregate_staging_GBps": sum(r["copy"]["staged_bytes"] for r in allr) / wall_c / 1e9,
+                                  "aggregate_h2d_GBps": sum(r["copy"]["h2d_bytes"] for r in allr) / wall_c / 1e9,
+                                  "loader_wait_s_max": max(r["copy"]["loader_wait_s"] for r in allr), "wall_s": wall_c},
+        "decoded_into_pinned": {"aggregate_clips_per_s": n / wall_d, "aggregate_staging_GBps": sum(r["direct"]["staged_bytes"] for r in allr) / wall_d / 1e9,
+                                "aggregate_h2d_GBps": sum(r["direct"]["h2d_bytes"] for r in allr) / wall_d / 1e9,
+                                "loader_wait_s_max": max(r["direct"]["loader_wait_s"] for r in allr), "wall_s": wall_d},
+        "stub_ceiling_clips_per_s": world * B / (stub_ms * 1e-3),
+        "need_per_gpu_GBps": need, "need_node_GBps": need * world,
+        "pinned_GB_total_peak": sum(max(r["copy"]["pinned_peak_bytes"], r["direct"]["pinned_peak_bytes"]) for r in allr) / 2 ** 30,
+        "pinned_GB_total_kept": sum(r["direct"]["pinned_live_bytes"] for r in allr) / 2 ** 30,
+        "pinned_pool_limit_GB_per_rank": allr[0]["copy"]["pinned_pool_limit_bytes"] / 2 ** 30,
+        "loader_cpus_bound_per_rank": [r["copy"]["loader_cpus"] for r in allr],
+        "note": "one GPU on this box: the H2D rate is ONE PCIe link shared by all ranks (an 8-GPU node has eight); the staging rate and the "
+                "pinned totals are host-side and carry over"}
+
+
+def write_frame_files(directory, n_videos, T, H, W):
+    """Sampled-frame PNGs of n_videos synthetic videos under `directory`, as the reference's ffmpeg step leaves them
+    (src/video_frames_extract.py:51-69: {video}_{n}.png, {video}_{n}_next.png).  Content: low-pass noise + fine noise (compresses about
+    like camera footage; pure noise would be the PNG decoder's easiest case).  Skipped if the files are there."""
+    from PIL import Image
+    os.makedirs(directory, exist_ok=True)
+    rng = np.random.default_rng(11)
+    for v in range(n_videos):
+        name = f"video{v}"
+        if os.path.exists(os.path.join(directory, f"{name}_{T - 1}_next.png")):
+            continue
+        for t in range(T):
+            coarse = rng.integers(0, 256, (H // 16 + 2, W // 16 + 2, 3), dtype=np.uint8)
+            base = np.asarray(Image.fromarray(coarse).resize((W, H), Image.BICUBIC)).astype(np.int16)
+            for suffix in ("", "_next"):
+                frame = np.clip(base + rng.integers(-6, 7, base.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+                Image.fromarray(frame).save(os.path.join(directory, f"{name}_{t}{suffix}.png"), compress_level=3)
+    return [f"video{v}" for v in range(n_videos)]
+
+
+def dataset_pass(eng, workload, n, B, rank, world, split_k, host_clips=False, prefetch=2, workers=8, n_resident=4, warmup=1, dump=None,
+                 frame_files=None, workers_sweep=None):
     """BASELINE config 4 as written: n clips sharded over the ranks (relax-vqa_amd/dataset.py), ONE all-gather of the [n, F] matrix;
     strong scaling: value = n clips / the time of the whole pass (max over ranks), warm-up batches untimed.  `value` is the pass over
     device-resident clips (the metric's definition); host_clips adds the same pass fed from pageable host memory.
@@ -662,13 +794,46 @@ def dataset_pass(eng, workload, n, B, rank, world, split_k, host_clips=False, pr
                            "note": "clips in pageable host memory -> loader threads copy them into pinned staging -> side-stream H2D of batch "
                                    "k+1 under the compute of batch k (relax-vqa_amd/dataset.py::ClipStager); never `value`"}
         del pin, dst
+    if frame_files:
+        # the same pass with every clip read from sampled-frame PNG files by the loader threads (sampling.load_clip_from_frames, decoded
+        # straight into pinned staging memory): where a from-files run saturates, by loader-thread count
+        from relax_vqa_amd import sampling
+        names = write_frame_files(frame_files, n_resident, T, H, W) if rank == 0 else None
+        barrier()
+        names = [f"video{v}" for v in range(n_resident)]
+        size = sum(os.path.getsize(os.path.join(frame_files, f)) for f in os.listdir(frame_files) if f.startswith("video0_")) / (2 * T)
+        sweep = []
+        for w in (workers_sweep or [workers]):
+            kw_w = dict(kw, workers=w)
+            src = lambda i, alloc=None: sampling.load_clip_from_frames(frame_files, names[i % n_resident], alloc=alloc)   # noqa: E731
+            dataset.extract_dataset_clips(src, min(n, 2 * B * world), eng, ramp=False, **kw_w)        # warm-up (page cache, pinned pool)
+            barrier()
+            t_f = {}
+            t0 = time.perf_counter()
+            m_f, err_f = dataset.extract_dataset_clips(src, n, eng, timings=t_f, ramp=True, **kw_w)
+            barrier()
+            e_f = time.perf_counter() - t0
+            if world > 1:
+                e_f = rdist.all_reduce_max(e_f, "cuda")
+            assert not err_f and bool(torch.isfinite(m_f).all()), err_f[:3]
+            sweep.append({"loader_workers_per_rank": w, "value": n / e_f, "unit": "clips/s", "frac_of_device_resident": elapsed / e_f,
+                          "png_decodes_per_s": n * 2 * T / e_f, "png_decodes_per_s_per_loader_thread": n * 2 * T / e_f / (w * world),
+                          "loader_wait_s": t_f["loader_wait_s"], "staged_bytes": t_f["staged_bytes"], "loader_cpus_bound": t_f["loader_cpus"]})
+        rec["from_frame_files"] = {"sweep": sweep, "frame": f"{W}x{H} PNG, {size / 1e6:.2f} MB on disk (low-pass noise + fine noise)",
+                                   "decoder": "Pillow in the loader threads (GIL released while decoding), frames written straight into the "
+                                              "clip's pinned staging buffer (the `alloc` protocol of dataset.extract_dataset_clips)",
+                                   "host_cpus": os.cpu_count(), "cpu_model": _cpu_model(),
+                                   "note": "PNG decode is outside the metric on both sides (SURVEY 8(d)); this is what a from-files run of the "
+                                           "dataset driver sustains - never `value`"}
     return rec
 
 
 def dataset_mode(args, eng, rank, world, barrier, precision):
     rec = dataset_pass(eng, args.workload, args.dataset_clips, args.clips_per_step, rank, world, args.gemm_split_k,
                        host_clips=args.host_clips, prefetch=args.prefetch, workers=args.loader_workers,
-                       n_resident=args.resident_clips or 4, warmup=args.warmup, dump=args.dump_matrix)
+                       n_resident=args.resident_clips or 4, warmup=args.warmup, dump=args.dump_matrix,
+                       frame_files=args.from_frame_files,
+                       workers_sweep=[int(x) for x in args.loader_workers_sweep.split(",")] if args.loader_workers_sweep else None)
     if rank == 0:
         print(json.dumps(rec))
     if world > 1:

@@ -9,8 +9,11 @@ frames of every file into one [n_videos, F] matrix, saved as a .mat keyed by the
   rank r owns the contiguous block `shard_clips(n_clips, r, world)` of clip indices          (distributed.py)
   batches of `clips_per_step` clips go through RelaxEngine.clip_vectors / full_clip_vectors   (one pass of each backbone)
   the pass is HOST-FED and OVERLAPPED: `workers` loader threads call clips(i) for the next `prefetch` batches (decode / read /
-    resume-from-file happen there) and land host clips in pinned staging buffers; a side HIP stream copies batch k+1 into the
-    other of two device slots while the engine works on batch k; events order the two streams both ways      (ClipStager)
+    resume-from-file happen there) and land host clips in pinned staging buffers - a loader that takes an `alloc` argument
+    decodes STRAIGHT into one (no pageable copy of the clip ever exists); a side HIP stream copies batch k+1 into the other of
+    two device slots while the engine works on batch k; events order the two streams both ways               (ClipStager)
+  the loader threads of a rank run on the CPUs of its GPU's NUMA node and allocate its pinned buffers there, and the pinned pool a
+    rank keeps is its share of a per-node budget                                                               (hostnode.py)
   optional: the per-frame [T,F] rows of every clip are written under the reference's file name (resume: skip_existing)
   the [n_local, F] means are all-gathered into the [n_clips, F] matrix every rank returns     (RCCL over xGMI; gloo on CPU)
   optional: rank 0 writes the .mat the reference's regression scripts read
@@ -20,15 +23,18 @@ row in the matrix is NaN and (clip index, message) goes into the returned error 
 the reference's imputer zeroes NaN / inf before the regressor (src/model_regression.py:123-126), relax_mlp_head imputes
 them with the training means.  A loader thread that raises yields exactly that entry for its clip; nothing waits on it forever.
 """
+import inspect
 import os
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import TimeoutError as FutureTimeout
 
 import numpy as np
 import torch
 
 from . import distributed as rdist
+from . import hostnode
 from . import sampling
 from .engine import LAYER_STACK_DIM, RN50_POOL_DIM
 
@@ -56,6 +62,54 @@ def _check_clip(clip):
         raise ValueError(f"frames of {shape[3]}x{shape[2]} hold no 16x16 patch")
 
 
+class _PinnedGate:
+    """The byte budget of a rank's pinned staging memory, granted IN CLIP ORDER.  A loader thread asks for its clip's bytes before it
+    decodes; it waits until (a) every earlier clip of the pass has been served or has declared that it needs nothing (`skip`) and
+    (b) the bytes fit under the cap - or nothing at all is held (one clip larger than the cap still goes through).  Bytes come back
+    when the clip's host -> device copy has landed.  Because the grant follows the clip order, the memory is always held by the
+    earliest clips - the ones the driver copies next - and a pass cannot lock itself up however small the cap; loaders that run too
+    far ahead of the copy engine simply wait (back-pressure instead of unbounded pinned memory)."""
+
+    def __init__(self, cap):
+        self.cap = int(cap)
+        self.in_use = 0
+        self.peak = 0
+        self._next = 0
+        self._served = set()
+        self._cv = threading.Condition()
+
+    def start_pass(self):
+        with self._cv:
+            self._next, self._served = 0, set()
+            self._cv.notify_all()
+
+    def _advance(self, seq):
+        if seq >= self._next:
+            self._served.add(seq)
+            while self._next in self._served:
+                self._served.remove(self._next)
+                self._next += 1
+        self._cv.notify_all()
+
+    def acquire(self, seq, n):
+        with self._cv:
+            while not ((seq is None or seq <= self._next) and (self.in_use == 0 or self.in_use + n <= self.cap)):
+                self._cv.wait(0.05)
+            self.in_use += n
+            self.peak = max(self.peak, self.in_use)
+            if seq is not None:
+                self._advance(seq)
+
+    def skip(self, seq):
+        with self._cv:
+            self._advance(seq)
+
+    def release(self, n):
+        with self._cv:
+            self.in_use -= n
+            self._cv.notify_all()
+
+
 class ClipStager:
     """Pinned host staging + two device slots + a side stream for one (process, device).  Kept on the engine object between
     passes so that the pinned and device buffers are allocated once (hipHostMalloc of GBs is slow).
@@ -64,13 +118,19 @@ class ClipStager:
     has enqueued the compute of batch k, then `done_with(token)` once that batch has been consumed.  Clips already on the device
     pass through untouched; on a CPU 'device' (tests with a stand-in engine) everything passes through."""
 
-    def __init__(self, device):
+    def __init__(self, device, world=1):
         self.device = device
         self.on_gpu = device.type == "cuda"
         self._lock = threading.Lock()
         self._pinned_free = {}                       # nbytes -> [pinned flat uint8 tensors]
         self._pooled_bytes = 0
-        self.bytes_copied = 0
+        self.pool_limit_bytes = hostnode.pinned_pool_budget(world)   # pinned staging kept for reuse: this rank's share of the node's budget
+        self.bytes_copied = 0                        # host -> device
+        self.bytes_staged = 0                        # pageable -> pinned (zero for loaders that decode into `alloc` buffers)
+        self.pinned_live_bytes = 0                   # pinned bytes this stager has allocated and not dropped (pool + handed out)
+        self.pinned_peak_bytes = 0
+        self.gate = _PinnedGate(self.pool_limit_bytes)   # bytes handed out to clips in flight never exceed the same budget
+        self._landing = []                           # (event of the clip's host -> device copy, its pinned buffer)
         if self.on_gpu:
             self.copy_stream = torch.cuda.Stream(device=device)
             self._slots = [None, None]               # flat uint8 device buffers, grown on demand
@@ -80,45 +140,88 @@ class ClipStager:
             self._turn = 0
 
     # ---- loader-thread side ------------------------------------------------------------------------------
-    def to_pinned(self, t):
-        """host uint8 tensor -> (pinned tensor of the same shape, buffer to hand back) - a copy unless `t` is pinned already."""
-        if not self.on_gpu or t.is_pinned():
-            return t, None
-        n = t.numel()
+    def _take_pinned(self, n, seq=None):
+        """A flat pinned uint8 buffer of n bytes, once the budget allows it (in clip order: _PinnedGate): from the pool, else a new
+        allocation - made by the CALLING (loader) thread, which runs on the CPUs of the GPU's NUMA node, so the pages land there."""
+        if self.on_gpu:                              # (a CPU 'device' uses the clips where they lie: nothing is pinned, nothing is budgeted)
+            self.gate.acquire(seq, n)
         with self._lock:
             free = self._pinned_free.get(n)
             buf = free.pop() if free else None
             if buf is not None:
                 self._pooled_bytes -= n
         if buf is None:
-            buf = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+            buf = torch.empty(n, dtype=torch.uint8, pin_memory=self.on_gpu)
+            with self._lock:
+                self.pinned_live_bytes += n
+                self.pinned_peak_bytes = max(self.pinned_peak_bytes, self.pinned_live_bytes)
+        return buf
+
+    def alloc_pinned(self, shape, seq=None):
+        """-> (uint8 tensor of `shape` over pinned memory, buffer to hand back): what a loader decodes into (the `alloc` protocol)."""
+        n = int(np.prod(shape))
+        buf = self._take_pinned(n, seq)
+        return buf.view(tuple(int(d) for d in shape)), buf
+
+    def to_pinned(self, t, seq=None):
+        """host uint8 tensor -> (pinned tensor of the same shape, buffer to hand back) - a copy unless `t` is pinned already."""
+        if not self.on_gpu or t.is_pinned():
+            if seq is not None:
+                self.gate.skip(seq)
+            return t, None
+        buf = self._take_pinned(t.numel(), seq)
         buf.copy_(t.reshape(-1))                     # releases the GIL: the loader threads copy in parallel
+        with self._lock:
+            self.bytes_staged += t.numel()
         return buf.view(t.shape), buf
 
-    POOL_LIMIT_BYTES = 32 << 30      # pinned staging kept for reuse (a dataset of many distinct clip sizes must not pin the host's memory)
-
     def give_back(self, bufs):
+        """Buffers whose copies have landed (or that were never used) go back to the pool - their bytes back to the budget -, up to this
+        rank's share of the node's pinned budget; beyond it they are dropped (unpinned and freed)."""
+        if self.on_gpu:
+            for b in bufs:
+                if b is not None:
+                    self.gate.release(b.numel())
         with self._lock:
             for b in bufs:
-                if b is not None and self._pooled_bytes + b.numel() <= self.POOL_LIMIT_BYTES:
+                if b is None:
+                    continue
+                if self._pooled_bytes + b.numel() <= self.pool_limit_bytes:
                     self._pinned_free.setdefault(b.numel(), []).append(b)
                     self._pooled_bytes += b.numel()
+                else:
+                    self.pinned_live_bytes -= b.numel()
 
     # ---- driver-thread side --------------------------------------------------------------------------------
-    def begin(self):
-        """Start a batch: take this turn's device slot, make the side stream wait until the batch that used it two turns ago is
-        through.  Then `add(clip)` per clip as its loader finishes (the copy starts at once, under the loading of the batch's other
-        clips), `end()` -> token."""
+    def begin(self, n_clips=0):
+        """Start a batch of (at most) n_clips clips: take this turn's device slot, make the side stream wait until the batch that used
+        it two turns ago is through.  Then `add(clip)` per clip as its loader finishes (the copy starts at once, under the loading of
+        the batch's other clips), `end()` -> token."""
         slot = self._turn
         self._turn ^= 1
-        self._cur = {"slot": slot, "at": 0, "any": False}
+        self._cur = {"slot": slot, "at": 0, "any": False, "left": max(int(n_clips), 1)}
         self.copy_stream.wait_event(self._free[slot])
         return self._cur
 
-    def add(self, c):
+    def reap(self, wait=False):
+        """Hand back the pinned buffers of the clips whose host -> device copies have landed (wait: of all clips copied so far)."""
+        if not self.on_gpu or not self._landing:
+            return
+        keep, done = [], []
+        for ev, buf in self._landing:
+            if wait:
+                ev.synchronize()
+            (done if (wait or ev.query()) else keep).append((ev, buf))
+        self._landing = keep
+        self.give_back([b for _, b in done])
+
+    def add(self, c, pinned_buf=None):
         """One clip of the batch begun: device tensors pass through; a (pinned) host tensor is copied on the side stream into the slot
-        (a slot that turns out too small is replaced by a larger block: the views handed out keep the old one alive)."""
+        (a slot that turns out too small is replaced by a larger block: the views handed out keep the old one alive).  pinned_buf: the
+        staging buffer behind `c`, handed back (reap) as soon as this copy has landed."""
         if not self.on_gpu or c.is_cuda:
+            if pinned_buf is not None:
+                self.give_back([pinned_buf])
             return c
         st = self._cur
         slot, sz = st["slot"], -(-c.numel() // 256) * 256
@@ -126,15 +229,22 @@ class ClipStager:
         with torch.cuda.stream(self.copy_stream):
             buf = self._slots[slot]
             if buf is None or st["at"] + sz > buf.numel():
-                grow = max(2 * (buf.numel() if buf is not None else 0), st["at"] + 8 * sz)
-                buf = torch.empty(grow, dtype=torch.uint8, device=self.device)          # block of the copy stream's pool ...
+                # sized once per batch: room for the clips still to come at this clip's size (exact for a batch of equal clips; a
+                # ragged batch that outgrows it gets one more block for ITS rest, and the clips copied so far stay in the old block,
+                # which the views handed out keep alive until the batch is through).  A slot is never larger than one batch.
+                self._slots[slot] = None                                                  # drop the old block before asking for the new one
+                buf = torch.empty(st["left"] * sz, dtype=torch.uint8, device=self.device)   # block of the copy stream's pool ...
                 buf.record_stream(cur)                                                    # ... that the compute stream reads
-                if st["at"] > 0:
-                    st["at"] = 0                                                          # (the clips copied so far stay in the old block)
+                st["at"] = 0
                 self._slots[slot] = buf
             d = buf[st["at"]:st["at"] + c.numel()].view(c.shape)
             d.copy_(c, non_blocking=True)
+            if pinned_buf is not None:
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+                self._landing.append((ev, pinned_buf))
         st["at"] += sz
+        st["left"] = max(st["left"] - 1, 1)
         st["any"] = True
         self.bytes_copied += c.numel()
         return d
@@ -170,10 +280,10 @@ class ClipStager:
             token[1].synchronize()
 
 
-def _stager(engine):
+def _stager(engine, world=1):
     st = getattr(engine, "_clip_stager", None)
     if st is None or st.device != engine.device:
-        st = ClipStager(engine.device)
+        st = ClipStager(engine.device, world)
         try:
             engine._clip_stager = st
         except AttributeError:
@@ -202,7 +312,11 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
              overwritten.  Not available with full=True (whole-frame and fragment features have different frame counts there).
     mat_path / data_name: rank 0 saves the matrix as {data_name: float64 [n_clips, F]} (extract_npy2mat.py:79-84).
     timings: optional dict, receives 'extract_s', 'all_gather_s' (device-synchronised wall times of the two phases),
-             'loader_wait_s' (time the driver thread spent waiting for loader threads) and 'h2d_bytes'."""
+             'loader_wait_s' (time the driver thread spent waiting for loader threads), 'h2d_bytes', 'staged_bytes' (pageable ->
+             pinned copies: zero for `alloc` loaders), 'pinned_peak_bytes' / 'pinned_live_bytes' / 'pinned_pool_limit_bytes' and
+             'loader_cpus' (CPUs the loader threads were bound to; 0 = not bound).
+    A callable with an `alloc` parameter - clips(i, alloc=f) - gets f(shape) -> a uint8 ndarray of that shape in this rank's PINNED
+    staging pool and returns the clip decoded into it: the clip is then copied host -> device straight from there."""
     if rank is None or world is None:
         import torch.distributed as dist
         on = dist.is_available() and dist.is_initialized()
@@ -220,11 +334,29 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
     on_gpu = dev.type == "cuda"
     local = torch.full((len(mine), F), float("nan"), dtype=torch.float32, device=dev)
     errors = []
-    stager = _stager(engine) if prefetch > 0 else None
-    # (loader threads start on device 0 like every new thread: name this rank's device before they pin memory or touch tensors)
+    stager = _stager(engine, world) if prefetch > 0 else None
+    # loader threads: (1) start on device 0 like every new thread: name this rank's device before they pin memory or touch tensors;
+    # (2) run on the CPUs of the GPU's NUMA node (hostnode.py): decode, the pinned buffers they allocate and the PCIe root of the GPU
+    # then sit on one socket
+    cpus = hostnode.loader_cpus(dev.index if on_gpu else None)
+
+    def _loader_init():
+        if on_gpu:
+            torch.cuda.set_device(dev)
+        hostnode.bind_this_thread(cpus)
+
     pool = ThreadPoolExecutor(max_workers=max(int(workers), 1), thread_name_prefix="relax-loader",
-                              initializer=(lambda: torch.cuda.set_device(dev)) if on_gpu else None) if prefetch > 0 else None
+                              initializer=_loader_init) if prefetch > 0 else None
     h2d_bytes0 = stager.bytes_copied if stager is not None else 0
+    staged_bytes0 = stager.bytes_staged if stager is not None else 0
+    # the `alloc` protocol: a loader `clips(i, alloc=f)` asks f(shape) for the uint8 array it decodes into - pinned staging memory of
+    # this rank's pool - and returns it (or a view of it): no pageable copy of the clip exists and nothing is copied on the host
+    takes_alloc = False
+    if callable(clips) and stager is not None:
+        try:
+            takes_alloc = "alloc" in inspect.signature(clips).parameters
+        except (TypeError, ValueError):
+            takes_alloc = False
     writes = []
 
     restore_split = None
@@ -257,9 +389,20 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
                     except Exception as e:              # noqa: BLE001
                         errors.append((i, f"per-frame file not written: {type(e).__name__}: {e}"))
 
+    seq_of = {i: k for k, i in enumerate(mine)}        # a clip's place in this rank's pass: the order pinned memory is granted in
+    if stager is not None:
+        stager.gate.start_pass()
+
     def load(i):
         """One clip, in a loader thread (or inline when prefetch = 0) -> ("rows", the stored per-frame rows of a finished clip) | ("clip", tensor, pinned buffer) |
-        ("err", message).  Never raises."""
+        ("err", message).  Never raises.  Whatever happens, the clip's turn at the pinned budget is taken or given up (the clips
+        behind it wait for that)."""
+        seq, took = seq_of[i], [False]
+
+        def my_turn():
+            first, took[0] = not took[0], True
+            return seq if first else None
+
         try:
             if out_dir is not None and skip_existing:
                 path = os.path.join(out_dir, sampling.feature_file_name(i, network_name))
@@ -270,15 +413,35 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
                             return ("rows", np.ascontiguousarray(rows))
                     except Exception:                   # noqa: BLE001 - truncated / foreign file: recompute and overwrite it
                         pass
-            clip = get(i)
+            handed = []                                 # pinned buffers this call's `alloc` gave out
+            if takes_alloc:
+                def alloc(shape):
+                    view, buf = stager.alloc_pinned(shape, my_turn())
+                    handed.append(buf)
+                    return view.numpy()                 # (shares the pinned memory)
+                try:
+                    clip = get(i, alloc=alloc)
+                except Exception:
+                    stager.give_back(handed)
+                    raise
+            else:
+                clip = get(i)
             _check_clip(clip)
             t = clip if isinstance(clip, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(clip))
             if t.is_cuda or stager is None:
                 return ("clip", t, None)
-            t, buf = stager.to_pinned(t.contiguous())
+            if handed and t.is_contiguous() and any(t.data_ptr() == b.data_ptr() for b in handed):
+                keep = next(b for b in handed if b.data_ptr() == t.data_ptr())
+                stager.give_back([b for b in handed if b is not keep])
+                return ("clip", t, keep)                # decoded in place: pinned already, nothing to stage
+            stager.give_back(handed)
+            t, buf = stager.to_pinned(t.contiguous(), my_turn())
             return ("clip", t, buf)
         except Exception as e:                          # noqa: BLE001 - the contract: the clip fails, the run goes on
             return ("err", f"{type(e).__name__}: {e}")
+        finally:
+            if stager is not None and not took[0]:
+                stager.gate.skip(seq)
 
     # ramp: the first batch has nothing to hide its loading under, so the pass opens with short batches (B/8, 3B/8, B/2) - the
     # engine starts after an eighth of a batch has been loaded and every next batch loads under the previous one's compute
@@ -304,10 +467,18 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         slots, idxs, devs, pinned = [], [], [], []
         staging = stager is not None and stager.on_gpu
         if staging:
-            stager.begin()
+            stager.begin(len(batches[b]))
         for k, (slot, i) in enumerate(zip(range(starts[b], starts[b] + len(batches[b])), batches[b])):
             t_w = time.perf_counter()
-            r = futs[k].result() if futs is not None else load(i)
+            if futs is None:
+                r = load(i)
+            else:
+                while True:                             # while the loader works (or waits for pinned memory): hand back what has landed
+                    try:
+                        r = futs[k].result(timeout=0.02 if staging else None)
+                        break
+                    except FutureTimeout:
+                        stager.reap()
             loader_wait += time.perf_counter() - t_w
             if r[0] == "err":
                 errors.append((i, r[1]))
@@ -319,8 +490,12 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
             else:
                 slots.append(slot)
                 idxs.append(i)
-                devs.append(stager.add(r[1]) if staging else r[1])    # the copy of this clip starts while the others still load
-                pinned.append(r[2])
+                if staging:
+                    devs.append(stager.add(r[1], r[2]))     # the copy of this clip starts while the others still load; its pinned
+                    stager.reap()                           # buffer goes back to the budget as soon as the copy has landed
+                else:
+                    devs.append(r[1])
+                    pinned.append(r[2])
         token = stager.end() if staging else None
         return slots, idxs, devs, token, pinned
 
@@ -359,7 +534,8 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
                 if stager is not None:
                     stager.done_with(token)
                     stager.copies_landed(token)
-                    stager.give_back(pinned)
+                    stager.reap()
+                    stager.give_back(pinned)            # (a CPU 'device': the clips were used where they lay)
         for i, w in writes:
             try:
                 w.result()
@@ -367,6 +543,8 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
                 errors.append((i, f"per-frame file not written: {type(e).__name__}: {e}"))
         torch.cuda.synchronize(dev) if on_gpu else None
         t1 = time.perf_counter()
+        if stager is not None:
+            stager.reap(wait=True)
     finally:
         if pool is not None:
             pool.shutdown(wait=True, cancel_futures=True)
@@ -381,6 +559,12 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         timings["all_gather_s"] = t2 - t1
         timings["loader_wait_s"] = loader_wait
         timings["h2d_bytes"] = stager.bytes_copied - h2d_bytes0 if stager is not None else 0
+        timings["staged_bytes"] = stager.bytes_staged - staged_bytes0 if stager is not None else 0     # pageable -> pinned copies
+        timings["pinned_live_bytes"] = stager.pinned_live_bytes if stager is not None else 0
+        timings["pinned_peak_bytes"] = stager.pinned_peak_bytes if stager is not None else 0
+        timings["pinned_in_flight_peak_bytes"] = stager.gate.peak if stager is not None else 0
+        timings["pinned_pool_limit_bytes"] = stager.pool_limit_bytes if stager is not None else 0
+        timings["loader_cpus"] = len(cpus) if cpus else 0
     if mat_path is not None and rank == 0:
         sampling.save_mat(mat_path, data_name or "features", matrix.cpu().numpy().astype(np.float64))
     return matrix, all_errors

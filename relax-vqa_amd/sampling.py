@@ -57,19 +57,25 @@ def read_frame_bgr(path):
         return np.ascontiguousarray(np.asarray(im.convert("RGB"))[..., ::-1])
 
 
-def load_clip_from_frames(sampled_frame_path, video_name):
+def load_clip_from_frames(sampled_frame_path, video_name, alloc=None):
     """The sampled frames of one video on disk -> uint8 [T,2,H,W,3] BGR, the input of relax_fragment_pairs / of
     dataset.extract_dataset_clips (as its `clips(i)` callable: the decode then runs in the loader threads, ahead of the engine).
+    alloc (the dataset driver's protocol): shape -> the uint8 array to fill - pinned staging memory: every frame is decoded and
+    written straight into its slot of the clip, no pageable copy of the clip is made.
     Raises if the directory holds no pair or the frames differ in size."""
     pairs = frame_pair_paths(sampled_frame_path, video_name)
     if not pairs:
         raise FileNotFoundError(f"no `{video_name}_<n>.png` / `{video_name}_<n>_next.png` pair under {sampled_frame_path}")
-    frames = [(read_frame_bgr(a), read_frame_bgr(b)) for a, b in pairs]
-    shape = frames[0][0].shape
-    for (a, b), (pa, pb) in zip(frames, pairs):
-        if a.shape != shape or b.shape != shape:
-            raise ValueError(f"{pa} / {pb}: frame sizes differ inside one video ({a.shape}, {b.shape} vs {shape})")
-    return np.stack([np.stack(p) for p in frames])
+    first = read_frame_bgr(pairs[0][0])
+    shape = first.shape
+    out = (alloc or np.empty)((len(pairs), 2) + shape) if alloc is not None else np.empty((len(pairs), 2) + shape, dtype=np.uint8)
+    for t, (pa, pb) in enumerate(pairs):
+        for j, path in enumerate((pa, pb)):
+            f = first if (t == 0 and j == 0) else read_frame_bgr(path)
+            if f.shape != shape:
+                raise ValueError(f"{pa} / {pb}: frame sizes differ inside one video ({f.shape} vs {shape})")
+            out[t, j] = f
+    return out
 
 
 def feature_file_name(video_index, network_name, resolution=None):

@@ -3,6 +3,7 @@ per-frame files + resume, the NaN-row failure contract and the all-gather, at wo
 per-frame rows from the clip's bytes, so any mix-up of clips, rows or ranks changes values."""
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -123,6 +124,41 @@ def test_a_per_frame_file_that_cannot_be_written_costs_only_its_clip(tmp_path, m
     assert os.path.exists(os.path.join(str(tmp_path / "f"), sampling.feature_file_name(3, "resnet50")))
 
 
+def test_a_loader_with_an_alloc_parameter_decodes_into_the_staging_pool(tmp_path):
+    """clips(i, alloc=f): the driver hands the loader its staging allocator, the loader fills f(shape) and returns it; nothing is copied
+    on the host (staged_bytes stays 0) and the rows equal those of the plain loader.  sampling.load_clip_from_frames is such a loader."""
+    _patched()
+    asked = []
+
+    def loader(i, alloc):
+        c = np.asarray(_clip([0, 1, 2, 4, 7, 8][i]))
+        out = alloc(c.shape)
+        assert out.dtype == np.uint8 and out.shape == c.shape
+        asked.append(i)
+        np.copyto(out, c)
+        return out
+
+    t = {}
+    got, errors = dataset.extract_dataset_clips(loader, 6, FakeEngine(), clips_per_step=4, rank=0, world=1, prefetch=2, workers=3, timings=t)
+    want, _ = dataset.extract_dataset_clips(lambda i: _clip([0, 1, 2, 4, 7, 8][i]), 6, FakeEngine(), clips_per_step=4, rank=0, world=1)
+    assert not errors and sorted(asked) == list(range(6)) and torch.equal(got, want) and t["staged_bytes"] == 0
+    # frames on disk -> the same protocol through sampling.load_clip_from_frames
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    clip = rng.integers(0, 256, (2, 2, 32, 48, 3), dtype=np.uint8)
+    for n in range(2):
+        Image.fromarray(clip[n, 0][..., ::-1]).save(tmp_path / f"v_{n}.png")
+        Image.fromarray(clip[n, 1][..., ::-1]).save(tmp_path / f"v_{n}_next.png")
+    seen = []
+
+    def alloc(shape):
+        seen.append(tuple(shape))
+        return np.empty(shape, dtype=np.uint8)
+
+    out = sampling.load_clip_from_frames(str(tmp_path), "v", alloc=alloc)
+    assert seen == [clip.shape] and np.array_equal(out, clip) and np.array_equal(sampling.load_clip_from_frames(str(tmp_path), "v"), clip)
+
+
 def test_sequence_input_and_empty_shards():
     _patched()
     clips = [_clip(i) for i in (0, 1)]
@@ -214,7 +250,8 @@ def _worker(rank, world, port, n, q):
     rd.init_from_env(backend="gloo")
     ds.feature_dim = lambda engine, resnet=True, vit=True, full=False: F
     eng = FakeEngine()
-    matrix, errors = ds.extract_dataset_clips(_clip, n, eng, clips_per_step=2)        # rank / world from the process group
+    # rank / world from the process group; eight ranks: loader threads on, as a node's eight ranks would run (prefetch 2, 2 workers each)
+    matrix, errors = ds.extract_dataset_clips(_clip, n, eng, clips_per_step=2 if world <= 2 else 3, **({} if world <= 2 else dict(prefetch=2, workers=2)))
     q.put((rank, matrix.numpy().copy(), errors, sum(eng.batches)))
     rd.barrier()
     torch.distributed.destroy_process_group()
@@ -237,3 +274,93 @@ def test_two_ranks_equal_one_rank_bit_for_bit(n):
     for rank, matrix, errors, _ in results:
         assert np.array_equal(matrix, want, equal_nan=True), f"rank {rank}"
         assert [i for i, _ in errors] == [i for i in (3, 5, 6) if i < n]              # every rank holds the whole error list
+
+
+def test_eight_ranks_finish_a_64_clip_pass_with_their_loaders_running():
+    """The shape of a full node: eight processes (gloo), each with its own loader threads, pinned-pool bookkeeping and shard of a
+    64-clip list; every rank returns the whole matrix and the whole error list, equal to the single-rank result bit for bit."""
+    n, world = 64, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = _want(n)
+    assert sorted(r[0] for r in results) == list(range(world))
+    for rank, matrix, errors, _ in results:
+        assert np.array_equal(matrix, want, equal_nan=True), f"rank {rank}"
+        assert [i for i, _ in errors] == [3, 5, 6]
+
+
+def test_pinned_budget_is_granted_in_clip_order_and_never_locks_up():
+    """dataset._PinnedGate: 12 'loader threads' ask for 40 bytes each under a cap of 100, in scrambled arrival order, while a 'copy
+    engine' hands bytes back in clip order: every clip is served, in order, never more than the cap is out - and a clip larger than
+    the cap still goes through once nothing else is held.  Clips that need nothing (errors, resumed rows) give their turn up."""
+    import random
+    import threading
+    gate = dataset._PinnedGate(100)
+    gate.start_pass()
+    order, lock = [], threading.Lock()
+    sizes = {k: (250 if k == 7 else 40) for k in range(12)}
+    skipped = {3, 9}
+
+    def loader(k):
+        time.sleep(random.Random(k).random() * 0.05)
+        if k in skipped:
+            gate.skip(k)
+            return
+        gate.acquire(k, sizes[k])
+        with lock:
+            order.append(k)
+            assert gate.in_use <= max(gate.cap, sizes[k])
+
+    threads = [threading.Thread(target=loader, args=(k,)) for k in random.Random(1).sample(range(12), 12)]
+    for t in threads:
+        t.start()
+    released = 0
+    deadline = time.time() + 30
+    while released < 10 and time.time() < deadline:          # the copy engine: releases in the order the clips were served
+        with lock:
+            todo = order[released:]
+        for k in todo:
+            time.sleep(0.005)
+            gate.release(sizes[k])
+            released += 1
+        time.sleep(0.002)
+    for t in threads:
+        t.join(timeout=5)
+        assert not t.is_alive()
+    assert order == [k for k in range(12) if k not in skipped] and gate.in_use == 0 and gate.peak <= 250
+
+
+def test_host_placement_helpers(tmp_path, monkeypatch):
+    """hostnode.py against a stand-in /sys tree: the GPU's NUMA node, that node's CPUs, the per-rank share of the pinned budget; and
+    'do nothing' when the platform does not tell."""
+    from relax_vqa_amd import hostnode
+    assert hostnode.parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11} and hostnode.parse_cpulist("") == set()
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    allowed = sorted(os.sched_getaffinity(0))
+    (node / "cpulist").write_text(f"{allowed[0]}-{allowed[-1]}\n")
+    monkeypatch.setattr(hostnode, "pci_address", lambda i: "0000:c1:00.0")
+    assert hostnode.gpu_numa_node(0, sysfs=str(tmp_path)) == 1
+    assert hostnode.loader_cpus(0, sysfs=str(tmp_path)) == set(allowed)
+    (dev / "numa_node").write_text("-1\n")
+    assert hostnode.gpu_numa_node(0, sysfs=str(tmp_path)) is None and hostnode.loader_cpus(0, sysfs=str(tmp_path)) is None
+    monkeypatch.setenv("RELAX_NUMA_BIND", "0")
+    (dev / "numa_node").write_text("1\n")
+    assert hostnode.loader_cpus(0, sysfs=str(tmp_path)) is None
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    monkeypatch.delenv("RELAX_PINNED_POOL_GB", raising=False)
+    assert hostnode.pinned_pool_budget() == 8 << 30                    # 64 GiB per node over eight ranks
+    monkeypatch.setenv("RELAX_PINNED_POOL_GB", "16")
+    assert hostnode.pinned_pool_budget() == 2 << 30
+    assert hostnode.bind_this_thread(set()) is False and hostnode.bind_this_thread(set(allowed)) is True

@@ -130,6 +130,39 @@ def test_host_fed_overlapped_pass_equals_the_inline_pass_bit_for_bit():
     assert eng._clip_stager is st and torch.equal(again[ok], over[ok])
 
 
+def test_pinned_staging_stays_under_its_budget_and_alloc_loaders_copy_nothing_on_the_host(monkeypatch):
+    """A pinned budget far below one batch (1.5 clips; batches of 4, loaders three batches ahead): the pass completes - the budget is
+    granted in clip order and comes back as each clip's copy lands -, never holds more than the budget, and returns the rows of the
+    unconstrained pass bit for bit.  A loader with an `alloc` parameter decodes into the staging memory: no pageable -> pinned copy."""
+    rn50_weights(), vit_weights("vit_base")
+    eng = engine()
+    host = [synth.synthetic_clip(2, 240, 320, clip_id=680 + i) for i in range(11)]
+    want, _ = dataset.extract_dataset_clips(host, 11, eng, clips_per_step=4, rank=0, world=1, prefetch=0)
+    clip_bytes = host[0].nbytes
+    monkeypatch.setenv("RELAX_PINNED_POOL_GB", str(1.5 * clip_bytes / 2 ** 30))
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    old = getattr(eng, "_clip_stager", None)
+    eng._clip_stager = None                                  # a fresh stager: it reads its budget when it is made
+    try:
+        t = {}
+        got, errors = dataset.extract_dataset_clips(lambda i: host[i], 11, eng, clips_per_step=4, rank=0, world=1, prefetch=3, workers=6, timings=t)
+        assert not errors and torch.equal(got, want)
+        assert t["pinned_pool_limit_bytes"] == int(1.5 * clip_bytes) and 0 < t["pinned_in_flight_peak_bytes"] <= int(1.5 * clip_bytes)
+        assert t["staged_bytes"] == 11 * clip_bytes and t["h2d_bytes"] == 11 * clip_bytes
+
+        def decode_into(i, alloc):
+            out = alloc(host[i].shape)
+            np.copyto(out, host[i])
+            return out
+
+        t2 = {}
+        got2, errors2 = dataset.extract_dataset_clips(decode_into, 11, eng, clips_per_step=4, rank=0, world=1, prefetch=3, workers=6, timings=t2)
+        assert not errors2 and torch.equal(got2, want) and t2["staged_bytes"] == 0 and t2["h2d_bytes"] == 11 * clip_bytes
+        assert t2["pinned_in_flight_peak_bytes"] <= int(1.5 * clip_bytes)
+    finally:
+        eng._clip_stager = old
+
+
 def test_dataset_pass_from_frame_files_equals_the_pass_from_arrays(tmp_path):
     """The reference's data flow (src/main_fragment_layerstack.py:283-296): sampled frames as PNG files on disk, read in the loader
     threads (sampling.load_clip_from_frames = cv2.imread's BGR bytes) -> the same [n, 19779] matrix, bit for bit, as from the arrays."""
