@@ -14,7 +14,7 @@
 //   blur in double + 2x2 solve in one kernel; the first one takes the x2 linear upsampling of the coarser level's flow on the fly, the
 //   last one of the finest level the magnitude range)   [flow_fused = 0: update_matrices_k + box_solve_fused, the matrix plane through HBM]
 //   flow_visualise: fastAtan2, normalisation, 8-bit HSV -> BGR (float formula, truncated).
-// DESIGN.md section 3.3 has the measurements and what was tried and not kept.
+// LAB_NOTES.md section 3.3 has the measurements and what was tried and not kept.
 #include <cfloat>
 #include <cmath>
 

@@ -14,7 +14,7 @@
 // reads the 4 consecutive floats k = 8q+4h .. 8q+4h+3 of row i with ONE 128-bit LDS read and feeds them to 4 MFMAs.
 // Workgroup ids are remapped so that the workgroups sharing one XCD (and its L2) walk neighbouring tiles.
 // Defaults (launch_conv): fp32 128x128 tile, 4 waves, BK = 16, three workgroups per CU; 128x64 for N % 128 != 0;
-// opt-in bf16x3 precision: 256x256 tile on 8 waves for large plain GEMMs, 128-wide tiles otherwise.
+// opt-in bf16x3 precision: 256x256 tile on 8 waves for large plain GEMMs, 128-wide tiles otherwise (LAB_NOTES.md 3.1 / 3.2).
 #include "relax_internal.h"
 #include "host_logic.h"
 #include "gelu.h"

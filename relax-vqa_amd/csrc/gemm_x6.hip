@@ -42,7 +42,7 @@
 // segments, and can add bias / an sp3 or fp32 residual, apply ReLU / GELU, write fp32 (optionally only the first out_rows rows)
 // and / or sp3, and emit 16-row column sums for the global-average-pool taps.  What was measured and NOT adopted (staggered
 // starts, pinned instruction order of the 32x32 loop, non-temporal stores, 128x256 tiles on two workgroups per CU, K-slice phase
-// starts, static wave priorities) is recorded in DESIGN.md sections 3.2 / 3.2.1; none of that code is kept here.
+// starts, static wave priorities) is recorded in LAB_NOTES.md sections 3.2 / 3.2.1; none of that code is kept here.
 #include "relax_internal.h"
 #include "host_logic.h"
 #include "sp3.h"
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     // are the six partial products in three instructions per 16 x 16 outputs (same FLOPs, same order smallest first; measured
     // error against fp64 equal to the 32x32x16 form: tools/micro/mfma_shape.hip).  The chip holds a higher clock on this shape
     // on real data: the K loop takes 3.8 - 4.3 k cycles per step here against 3.55 k on the 32x32x16 loop and still finishes a
-    // ViT pass 2.7 % sooner (profiles/r03_mfma_shape.txt).  B (2 forms x 4 fragments) is double-buffered in registers across steps, A (3 forms) streams one 16-row
+    // ViT pass 2.7 % sooner (profiles/r03_mfma_shape.txt, LAB_NOTES.md section 3.2).  B (2 forms x 4 fragments) is double-buffered in registers across steps, A (3 forms) streams one 16-row
     // fragment at a time, two buffers.  The LDS image is linear here (no half swap: these reads are conflict-free on it).
     const int r16 = lane & 15, g16 = lane >> 4, second16 = g16 >> 1;
     const int rowoff16 = r16 * kChunkBytes + ((g16 & 1) << 4);

@@ -3,7 +3,7 @@ which is neither vendored in the reference nor installed here.  This file pins i
 the 15 tapped activations, the avgpool vector, the preprocess tensor and the 2051-d statistics against independent
 implementations (HuggingFace transformers' ResNetModel with forward hooks; plain float64 numpy), at 1e-5, on two weight sets
 (the regular synthetic one and an adversarial one: BatchNorm variances over 1e-3..10, gammas of mixed sign).
-What remains unpinned is stated in DESIGN.md section 5: torchvision's Resize / ToTensor / Normalize on a PIL image - the
+What remains unpinned is stated in LAB_NOTES.md section 5: torchvision's Resize / ToTensor / Normalize on a PIL image - the
 resize is covered by Pillow itself (tests/test_oracle_resize.py), ToTensor / Normalize by the numpy restatement below."""
 import numpy as np
 import pytest

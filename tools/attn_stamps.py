@@ -2,7 +2,7 @@
 """Ticks per phase of an (image, head) item of attention_x6, from the stamped build (GPU box only):
    tools/build_ablations.sh a6stamps;  RELAX_HIP_LIB=tools/abl/librelax_a6stamps.so python tools/attn_stamps.py [images]
 The stamped kernel writes the per-item averages of workgroup 3's waves 0 and 6 into the first floats of its fp32 output
-(wave 0: the older wave of a shared SIMD; wave 6: the younger one of another).  The table of DESIGN.md section 3.2.1."""
+(wave 0: the older wave of a shared SIMD; wave 6: the younger one of another).  The table of LAB_NOTES.md section 3.2.1."""
 import os
 import sys
 

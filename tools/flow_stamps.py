@@ -4,7 +4,7 @@
 One producer wave (wave 4) and one box wave (wave 0) of block (1, 1) of pair 0 add their per-phase sums to a device array at the end of
 every launch; the table is per step (3 rows of a 240-column band), for the launches of the level whose width is given (0: all levels).
 The stamped producer waits for ALL of a step's operands before the first row (the product waits row by row), so `wait for loads` is
-an upper bound of the product's exposed wait.  DESIGN.md section 3.3."""
+an upper bound of the product's exposed wait.  LAB_NOTES.md section 3.3."""
 import ctypes
 import os
 import sys
