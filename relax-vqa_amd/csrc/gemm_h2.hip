@@ -60,14 +60,14 @@ typedef _Float16 h2k_f16x8 __attribute__((ext_vector_type(8)));
 // fp32 [rows][K] (row stride ld floats) -> h2 [rows][K*4 B] with value * scale * row_scale[row] (either factor optional); one
 // thread per 8 values
 __global__ __launch_bounds__(256) void to_h2_kernel(const float* __restrict__ x, int64_t ld, char* __restrict__ y, int K, int64_t total8,
-                                                    float scale, const float* __restrict__ row_scale) {
+                                                    float scale, const float* __restrict__ row_scale, int rows_per_scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total8) return;
     const int k8 = K >> 3;
     const int64_t row = i / k8;
     const int k = (int)(i - row * k8) * 8;
     const float* s = x + row * ld + k;
-    const float f = row_scale ? scale * row_scale[row] : scale;
+    const float f = row_scale ? scale * row_scale[row / rows_per_scale] : scale;
     store_h2_x8(y + row * (int64_t)K * 4, k, *reinterpret_cast<const h2k_f32x4*>(s), *reinterpret_cast<const h2k_f32x4*>(s + 4), f);
 }
 
@@ -95,11 +95,64 @@ __global__ __launch_bounds__(256) void to_h2_rows_kernel(const float* __restrict
 }
 
 int launch_to_h2(relax_handle* h, const float* x, int64_t ld, void* y, int64_t rows, int K, float scale, const float* row_scale,
-                 hipStream_t s) {
-    RELAX_REQUIRE(h, K % 16 == 0 && ld % 4 == 0 && rows > 0, "to_h2: K=%d must be a multiple of 16 (ld %lld)", K, (long long)ld);
+                 hipStream_t s, int rows_per_scale) {
+    RELAX_REQUIRE(h, K % 16 == 0 && ld % 4 == 0 && rows > 0 && rows_per_scale >= 1, "to_h2: K=%d must be a multiple of 16 (ld %lld)", K, (long long)ld);
     const int64_t total8 = rows * (K / 8);
     hipLaunchKernelGGL(to_h2_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, x, ld, static_cast<char*>(y), K, total8,
-                       scale, row_scale);
+                       scale, row_scale, rows_per_scale);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+// ---- per-image scales -------------------------------------------------------------------------------------------------------
+// ResNet-50's activations have no input-independent bound (50 ReLU layers: any norm bound compounds), so a tensor that travels as
+// fp16 planes gets one power-of-two scale per IMAGE, from a bound on that image's values that is known BEFORE the tensor is
+// written: Hoelder's inequality on the producing convolution,
+//        max |out| <= max_n sum_k |W[n,k]| * max |in|  (+ the second source's term) + max |bias| + max |residual|,
+// with the maxima of the inputs MEASURED (the producer of each input atomicMax-es the bits of its non-negative outputs into the
+// image's slot; integer max: order-free, so the value does not depend on the batch) - a bound that is loose by the ratio of the L1
+// bound to the real maximum of ONE layer (5 - 7 binades of fp16's 19-binade window) and never compounds.  Everything on the device,
+// no host synchronisation: one tiny launch per convolution turns the maxima into scales.
+//   scale[i] = the power of two that puts (la * amax_a[i] + lb * amax_b[i] + amax_r[i] + bmax) into [2^14, 2^15),  inv[i] = 1 / scale[i]
+__global__ __launch_bounds__(256) void h2_image_scales_kernel(const unsigned* __restrict__ amax_a, float la, const unsigned* __restrict__ amax_b,
+                                                              float lb, const unsigned* __restrict__ amax_r, float bmax,
+                                                              float* __restrict__ scale, float* __restrict__ inv, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float b = la * __uint_as_float(amax_a[i]) + bmax;
+    if (amax_b) b += lb * __uint_as_float(amax_b[i]);
+    if (amax_r) b += __uint_as_float(amax_r[i]);
+    const float sc = h2_scale_for(b * 1.0001f);   // (the sum above is rounded: a hair of margin; the window has a factor 2 to spare)
+    scale[i] = sc;
+    inv[i] = 1.f / sc;
+}
+
+int launch_h2_image_scales(relax_handle* h, const unsigned* amax_a, float la, const unsigned* amax_b, float lb, const unsigned* amax_r,
+                           float bmax, float* scale, float* inv, int n, hipStream_t s) {
+    RELAX_REQUIRE(h, amax_a && scale && inv && n > 0, "h2_image_scales: bad arguments");
+    hipLaunchKernelGGL(h2_image_scales_kernel, dim3((n + 255) / 256), dim3(256), 0, s, amax_a, la, amax_b, lb, amax_r, bmax, scale, inv, n);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+// max |x| over each image's per_image values (grid: blocks x images; operator-level conversions)
+__global__ __launch_bounds__(256) void image_absmax_kernel(const float* __restrict__ x, int64_t per_image, unsigned* __restrict__ amax) {
+    const float* p = x + (int64_t)blockIdx.y * per_image;
+    float m = 0.f;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < per_image; i += (int64_t)gridDim.x * 1024) {
+        const h2k_f32x4 v = *reinterpret_cast<const h2k_f32x4*>(p + i);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax + blockIdx.y, __float_as_uint(m));
+}
+
+int launch_image_absmax(relax_handle* h, const float* x, int64_t per_image, int n_images, unsigned* amax, hipStream_t s) {
+    RELAX_REQUIRE(h, x && amax && n_images > 0 && per_image > 0 && per_image % 4 == 0, "image_absmax: bad arguments");
+    RELAX_HIP_CHECK(h, hipMemsetAsync(amax, 0, sizeof(unsigned) * (size_t)n_images, s));
+    const int blocks = (int)((per_image / 4 + 255) / 256 < 64 ? (per_image / 4 + 255) / 256 : 64);
+    hipLaunchKernelGGL(image_absmax_kernel, dim3(blocks, n_images), dim3(256), 0, s, x, per_image, amax);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }
@@ -128,6 +181,18 @@ struct H2Params {
     int no_split;
     int tiles_m, tiles_n, ntiles, group_m;
     int full_tiles, nsplit;
+    // gemm_h3 as a convolution (ResNet-50 layer3 / layer4): the rows of A are the output pixels of NHWC images [Nimg*H*W][Cin*4 B],
+    // taken at (oy, ox) * stride - pad (+ the tap's (dy, dx) for KH*KW > 1, implicit GEMM); weight rows k = (dy*KW + dx)*Cin + c
+    int pixels, H, W, Cin, Ho, Wo, KW, stride, pad;
+    // per-IMAGE scales (activations without an input-independent bound: see the scale kernel below): image = row / rows_per_img
+    int rows_per_img;               // Ho*Wo; 0 = no per-image tables
+    const float* img_in_inv;        // [Nimg]: 1 / (scale of image i's A planes), or null
+    const float* img_out_scale;     // [Nimg]: scale of image i's rows of out_h2, or null (then out_scale)
+    unsigned* amax_out;             // [Nimg]: atomicMax of the bits of the (non-negative: ReLU) outputs of image i, or null
+    const char* residual_h2;        // the residual as fp16 planes [M][N*4 B] (hi + lo, times img_res_inv[image]: exact), or null
+    const float* img_res_inv;
+    float* gap;                     // fused spatial mean, stage 1: sums of the outputs over aligned 4-row groups [M/4][N] (rows < gap_rows), or null
+    int out_rows, gap_rows;         // rows below these limits get the fp32 output / the group sums
     unsigned long long* stamps;   // diagnostic builds only; null in the product
 };
 
@@ -437,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2(const H2Params p) {
 constexpr int H3_STAGE = (H2_BM + H2_BN) * 128;   // 64 KB
 constexpr int H3_NSTG = 2;
 
-template <bool FOUR>
+template <bool FOUR, bool TAPS = false>
 __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (no __amdgpu_buffer_rsrc_t there)
     constexpr int BM = H2_BM, BN = H2_BN, STAGE = H3_STAGE, NSTG = H3_NSTG, IMG = STAGE / 2;
@@ -483,30 +548,90 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     // weight rows: 16 .. 31).  Piece j of this wave: image j >> 2 (hi, lo), piece wave + 8 (j & 3) of it; lane l fills slot l & 3 of row
     // 16 * piece + (l >> 2), which holds unit slot ^ f(row) = chunk (unit >> 1), half (unit & 1) of the step.  The hi and the lo piece
     // of the same rows share the per-lane offset (the plane is + 32 B in the scalar offset): four offsets.
-    const int64_t row_bytes = (int64_t)p.K * 4;
+    // Convolutions (p.pixels): an activation row is an output pixel; its offset is the input pixel it reads at tap (0, 0), the step's
+    // tap adds (dy W + dx) pixels, a tap outside the image (bit mask per piece) or a row past M an out-of-range offset: the DMA
+    // writes zeros.  K order: 32-channel groups outermost, the KH*KW taps of a group innermost (they re-read neighbouring pixels: L2).
+    const int64_t row_bytes = (int64_t)p.K * 4;                               // weight rows
+    const int64_t arow_bytes = p.pixels ? (int64_t)p.Cin * 4 : row_bytes;     // activation rows / pixels
+    const int img0 = p.pixels ? m0 / (p.Ho * p.Wo) : 0;
     __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
     {
-        const int64_t left = (int64_t)(p.M - m0) * row_bytes;
-        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a + (int64_t)m0 * row_bytes), 0,
-                                                   (int)(left < kH2MaxRecords ? left : kH2MaxRecords), 0x00020000);
+        const int64_t base = p.pixels ? (int64_t)img0 * p.H * p.W * arow_bytes : (int64_t)m0 * arow_bytes;
+        const int64_t total = p.pixels ? (int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * arow_bytes : (int64_t)p.M * arow_bytes;
+        const int64_t left = total - base;
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a + base), 0, (int)(left < kH2MaxRecords ? left : kH2MaxRecords), 0x00020000);
         rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w + (int64_t)n0 * row_bytes), 0, (int)(BN * row_bytes), 0x00020000);
     }
     unsigned voff[4];
+    [[maybe_unused]] unsigned a_taps[2] = {0u, 0u};   // TAPS: bit t set = tap t of this piece's pixel lies inside the image (KH*KW <= 32)
+    const int ntaps = TAPS ? p.K / p.Cin : 1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int trow = (wave + 8 * q) * 16 + (lane >> 2);           // 0 .. 511
         const int unit = (lane & 3) ^ ((4 - ((trow >> 2) & 3)) & 3);
         const int off = (unit >> 1) * kH2ChunkBytes + (unit & 1) * 16;
-        if (q < 2) voff[q] = m0 + trow < p.M ? (unsigned)(trow * (int)row_bytes + off) : kH2OutOfRange;
-        else voff[q] = (unsigned)((trow - BM) * (int)row_bytes + off);
+        if (q >= 2) {
+            voff[q] = (unsigned)((trow - BM) * (int)row_bytes + off);
+        } else if (m0 + trow >= p.M) {
+            voff[q] = kH2OutOfRange;
+        } else if (p.pixels) {
+            const int m = m0 + trow;
+            const int img = m / (p.Ho * p.Wo);
+            const int rem = m - img * (p.Ho * p.Wo);
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            const int iy = oy * p.stride - p.pad, ix = ox * p.stride - p.pad;
+            if (TAPS) {
+                for (int t = 0, dy = 0, dx = 0; t < ntaps; ++t) {
+                    if ((unsigned)(iy + dy) < (unsigned)p.H && (unsigned)(ix + dx) < (unsigned)p.W) a_taps[q] |= 1u << t;
+                    if (++dx == p.KW) { dx = 0; ++dy; }
+                }
+            }
+            voff[q] = (unsigned)((((img - img0) * p.H + iy) * p.W + ix) * (int)arow_bytes + off);
+        } else {
+            voff[q] = (unsigned)(trow * (int)arow_bytes + off);
+        }
     }
-    int d_kt = kt_begin;   // the next 32-k step to issue (steps are issued in order)
+    // the next 32-k step to issue (steps are issued in order): plain = a byte offset; taps = (32-channel group, dy, dx)
+    int d_kt = kt_begin;
+    [[maybe_unused]] int d_cc = 0, d_tap = 0, d_dy = 0, d_dx = 0;
+    [[maybe_unused]] const int cin_chunks = p.Cin >> 4;
+    if (TAPS) {
+        d_cc = kt_begin / ntaps;
+        d_tap = kt_begin - d_cc * ntaps;
+        d_dy = d_tap / p.KW;
+        d_dx = d_tap - d_dy * p.KW;
+    }
 #define H3_ISSUE_PIECE(st_, j_)                                                                                         \
     {                                                                                                                   \
-        const int soff_ = d_kt * (2 * kH2ChunkBytes) + ((j_) >> 2) * 32;                                                \
         const int dst_ = (st_) * STAGE + ((j_) >> 2) * IMG + (wave + 8 * ((j_) & 3)) * 1024;                             \
-        if (((j_) & 3) < 2) { H2_DMA(rsrc_a, dst_, voff[(j_) & 3], soff_); }                                             \
-        else { H2_DMA(rsrc_w, dst_, voff[(j_) & 3], soff_); }                                                            \
+        if (((j_) & 3) < 2) {                                                                                           \
+            if (TAPS) {                                                                                                 \
+                const bool ok_ = (a_taps[(j_) & 1] >> d_tap) & 1u;                                                      \
+                const int tapoff_ = (d_dy * p.W + d_dx) * (int)arow_bytes + d_cc * (2 * kH2ChunkBytes) + ((j_) >> 2) * 32; \
+                H2_DMA(rsrc_a, dst_, ok_ ? voff[(j_) & 3] + (unsigned)tapoff_ : kH2OutOfRange, 0);                      \
+            } else {                                                                                                    \
+                H2_DMA(rsrc_a, dst_, voff[(j_) & 3], d_kt * (2 * kH2ChunkBytes) + ((j_) >> 2) * 32);                    \
+            }                                                                                                           \
+        } else {                                                                                                        \
+            const int wk_ = TAPS ? (d_tap * cin_chunks + 2 * d_cc) * kH2ChunkBytes : d_kt * (2 * kH2ChunkBytes);        \
+            H2_DMA(rsrc_w, dst_, voff[(j_) & 3], wk_ + ((j_) >> 2) * 32);                                                \
+        }                                                                                                               \
+    }
+#define H3_ISSUE_ADVANCE()                                                                                              \
+    {                                                                                                                   \
+        ++d_kt;                                                                                                         \
+        if (TAPS) {                                                                                                     \
+            ++d_tap;                                                                                                    \
+            ++d_dx;                                                                                                     \
+            const bool wx_ = d_dx == p.KW;                                                                              \
+            d_dx = wx_ ? 0 : d_dx;                                                                                      \
+            d_dy += wx_ ? 1 : 0;                                                                                        \
+            const bool wt_ = d_tap == ntaps;                                                                            \
+            d_tap = wt_ ? 0 : d_tap;                                                                                    \
+            d_dy = wt_ ? 0 : d_dy;                                                                                      \
+            d_cc += wt_ ? 1 : 0;                                                                                        \
+        }                                                                                                               \
     }
 
     floatx4 acc[8][4];   // 16-row A fragments x 16-column B fragments of the wave's 128 x 64
@@ -568,7 +693,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                 if (has_d_) H3_ISSUE_PIECE(xs_, e + 1);                                                                 \
                 H3_MFMAS((xs_) ^ 1, e & 1, e);                                                                          \
             }                                                                                                           \
-            if (has_d_) ++d_kt;                                                                                         \
+            if (has_d_) H3_ISSUE_ADVANCE();                                                                             \
         }                                                                                                               \
     }
 
@@ -576,11 +701,11 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     {
 #pragma unroll
         for (int j = 0; j < 8; ++j) H3_ISSUE_PIECE(0, j);
-        ++d_kt;
+        H3_ISSUE_ADVANCE();
         if (nk > 1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) H3_ISSUE_PIECE(1, j);
-            ++d_kt;
+            H3_ISSUE_ADVANCE();
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // step 0 has landed; step 1 stays in flight
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -612,6 +737,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
 #undef H3_READ_A
 #undef H3_READ_XB
 #undef H3_ISSUE_PIECE
+#undef H3_ISSUE_ADVANCE
     H2_STAMP(2);
     __syncthreads();   // no DMA is in flight and every fragment is in registers: the stages become the epilogue staging
 
@@ -626,7 +752,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     static_assert(EP_ROWS * LDC * 4 <= NSTG * STAGE, "epilogue pass must fit the staging LDS");
     constexpr int EP_STEP = NT / C8;
     constexpr int EP_ITERS = EP_ROWS / EP_STEP;
-    const bool planes = p.out_h2 != nullptr;   // workgroup-uniform
+    const bool planes = p.out_h2 != nullptr || p.residual_h2 != nullptr;   // workgroup-uniform
     const int lcA = planes ? (tid % C8) * 8 : (tid % C8) * 4;
     const int lcB = planes ? lcA + 4 : lcA + BN / 2;
     const int lr0 = tid / C8;
@@ -641,17 +767,25 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
         }
     }
     const bool interior = m0 + BM <= p.M;   // workgroup-uniform
+    // per-image maxima of this tile, behind the staging area (which takes the first EP_ROWS * LDC * 4 = 66.5 KB of the stages)
+    unsigned* simg = reinterpret_cast<unsigned*>(smem + 96 * 1024);
+    const int img_first = p.rows_per_img > 0 ? m0 / p.rows_per_img : 0;
+    const bool lds_amax = p.amax_out && slice < 0 && p.rows_per_img >= 18;   // at most 16 images under the tile's 256 rows
+    if (lds_amax && tid < 16) simg[tid] = 0u;   // (ordered before the first use by the barrier of the first pass)
 #pragma unroll
     for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
         if (pass > 0) __syncthreads();
         f32x4 ra[EP_ITERS], rb[EP_ITERS];
-        float rs[EP_ITERS];
+        float rs[EP_ITERS], os[EP_ITERS];
+        int im[EP_ITERS];
 #pragma unroll
         for (int it = 0; it < EP_ITERS; ++it) {
             const int m = m0 + pass * EP_ROWS + it * EP_STEP + lr0;
             ra[it] = zero4;
             rb[it] = zero4;
             rs[it] = 1.f;
+            os[it] = p.out_scale;
+            im[it] = 0;
             if (slice < 0 && (interior || m < p.M)) {
                 if (p.residual) {
                     const float* r = p.residual + (int64_t)m * p.N + n0;
@@ -659,6 +793,24 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                     rb[it] = *reinterpret_cast<const f32x4*>(r + lcB);
                 }
                 if (p.rowscale) rs[it] = p.rowscale[m];
+                if (p.rows_per_img > 0) {   // per-image scales: the row's image
+                    im[it] = m / p.rows_per_img;
+                    if (p.img_in_inv) rs[it] = p.img_in_inv[im[it]];
+                    if (p.img_out_scale) os[it] = p.img_out_scale[im[it]];
+                }
+                if (p.residual_h2) {   // the residual as fp16 planes: (hi + lo) / scale is the stored 22-bit value, exactly (planes: lcB = lcA + 4)
+                    const char* r = p.residual_h2 + (int64_t)m * ((int64_t)p.N * 4) + h2_offset(n0 + lcA);
+                    const h2_u32x4 hi = *reinterpret_cast<const h2_u32x4*>(r), lo = *reinterpret_cast<const h2_u32x4*>(r + 32);
+                    const float ri = p.img_res_inv[im[it]];
+#define H2_LO16(u_) ((float)__builtin_bit_cast(_Float16, (unsigned short)((u_) & 0xffffu)))
+#define H2_HI16(u_) ((float)__builtin_bit_cast(_Float16, (unsigned short)((u_) >> 16)))
+                    ra[it] = (f32x4){H2_LO16(hi.x) + H2_LO16(lo.x), H2_HI16(hi.x) + H2_HI16(lo.x), H2_LO16(hi.y) + H2_LO16(lo.y),
+                                     H2_HI16(hi.y) + H2_HI16(lo.y)} * ri;
+                    rb[it] = (f32x4){H2_LO16(hi.z) + H2_LO16(lo.z), H2_HI16(hi.z) + H2_HI16(lo.z), H2_LO16(hi.w) + H2_LO16(lo.w),
+                                     H2_HI16(hi.w) + H2_HI16(lo.w)} * ri;
+#undef H2_LO16
+#undef H2_HI16
+                }
             }
         }
 #pragma unroll
@@ -689,7 +841,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
             // powers of two: exact.  Then (acc + bias) + residual, the same order on every path
             va = va * (cs_a * rs[it]) + bias_a;
             vb = vb * (cs_b * rs[it]) + bias_b;
-            if (p.residual) {
+            if (p.residual || p.residual_h2) {
                 va += ra[it];
                 vb += rb[it];
             }
@@ -701,12 +853,49 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                 vb = gelu_erf4(vb);
             }
             const int64_t o = (int64_t)m * p.N + n0;
-            if (p.out) {
+            if (p.out && m < p.out_rows) {
                 *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
                 *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
             }
-            if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, p.out_scale);   // (planes: lcB = lcA + 4)
+            if (p.gap) {   // the finished values go back to the staging rows for the group sums below
+                *reinterpret_cast<f32x4*>(stg + lr * LDC + lcA) = va;
+                *reinterpret_cast<f32x4*>(stg + lr * LDC + lcB) = vb;
+            }
+            if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, os[it]);   // (planes: lcB = lcA + 4)
+            if (p.amax_out) {
+                // the largest output of this row segment (outputs are >= 0: these launches end in a ReLU), over the 32 lanes that share
+                // the row, into the image's slot: integer max of the bits = float max, order-free, so the maximum - and every scale
+                // derived from it - is the same whatever batch the image travels in.  Collected per tile in LDS first (a tile spans a few
+                // images): one global atomic per image and tile instead of one per row segment
+                float mx = fmaxf(fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w)), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)));
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                if ((tid & 31) == 0) {
+                    if (lds_amax) atomicMax(simg + (im[it] - img_first), __float_as_uint(mx));
+                    else atomicMax(p.amax_out + im[it], __float_as_uint(mx));
+                }
+            }
         }
+        if (p.gap && slice < 0) {
+            // fused spatial mean, stage 1: sums over the aligned 4-row groups of this pass, rows added in order.  Images start at multiples
+            // of 4 rows (the launcher checks Ho*Wo % 4 == 0): a group never spans two images and the grouping - hence every bit - does
+            // not depend on where in the batch an image sits.  gap_groups_finish (layers.hip) adds an image's group sums in order.
+            __syncthreads();
+            for (int e = tid; e < (EP_ROWS / 4) * BN; e += NT) {
+                const int g = e / BN, col = e - g * BN;
+                const int mg = m0 + pass * EP_ROWS + g * 4;
+                if (mg < p.gap_rows) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t += stg[(g * 4 + r) * LDC + col];
+                    p.gap[(int64_t)(mg >> 2) * p.N + n0 + col] = t;
+                }
+            }
+        }
+    }
+    if (lds_amax) {
+        __syncthreads();
+        if (tid < 16 && simg[tid] != 0u) atomicMax(p.amax_out + img_first + tid, simg[tid]);
     }
     H2_STAMP(3);
 #endif
@@ -729,11 +918,15 @@ __global__ __launch_bounds__(256) void splitk_finish_h2(const H2Params p) {
     }
     const int m0 = tm * BM;
     const int n0 = tn * BN;
-    const int e8 = blockIdx.x * 256 + threadIdx.x;  // 8-column group index inside the tile
-    if (e8 >= BM * BN / 8) return;
+    const int e8 = blockIdx.x * 256 + threadIdx.x;  // 8-column group index inside the tile (the grid covers the tile exactly)
     const int lr = e8 / (BN / 8), lc = (e8 % (BN / 8)) * 8;
     const int m = m0 + lr;
-    if (m >= p.M) return;
+    // per-image maxima of this block's 8 rows (at most 8 images), collected in LDS: one global atomic per image and block
+    __shared__ unsigned s_mx[8];
+    const int img_b0 = p.rows_per_img > 0 ? (m0 + blockIdx.x * 8) / p.rows_per_img : 0;
+    if (threadIdx.x < 8) s_mx[threadIdx.x] = 0u;
+    __syncthreads();
+    if (m < p.M) {
     const float* pt = p.partial + (int64_t)split_tile * p.nsplit * (BM * BN) + lr * BN + lc;
     f32x4 va = *reinterpret_cast<const f32x4*>(pt), vb = *reinterpret_cast<const f32x4*>(pt + 4);
     for (int k = 1; k < p.nsplit; ++k) {
@@ -741,7 +934,12 @@ __global__ __launch_bounds__(256) void splitk_finish_h2(const H2Params p) {
         vb += *reinterpret_cast<const f32x4*>(pt + (int64_t)k * (BM * BN) + 4);
     }
     const int64_t o = (int64_t)m * p.N + n0 + lc;
-    const float rs = p.rowscale ? p.rowscale[m] : 1.f;
+    float rs = p.rowscale ? p.rowscale[m] : 1.f, os = p.out_scale;
+    const int img = p.rows_per_img > 0 ? m / p.rows_per_img : 0;
+    if (p.rows_per_img > 0) {
+        if (p.img_in_inv) rs = p.img_in_inv[img];
+        if (p.img_out_scale) os = p.img_out_scale[img];
+    }
     va = va * (*reinterpret_cast<const f32x4*>(p.colscale + n0 + lc) * rs);
     vb = vb * (*reinterpret_cast<const f32x4*>(p.colscale + n0 + lc + 4) * rs);
     if (p.bias) {
@@ -759,14 +957,26 @@ __global__ __launch_bounds__(256) void splitk_finish_h2(const H2Params p) {
         va = gelu_erf4(va);
         vb = gelu_erf4(vb);
     }
-    if (p.out) {
+    if (p.out && m < p.out_rows) {
         *reinterpret_cast<f32x4*>(p.out + o) = va;
         *reinterpret_cast<f32x4*>(p.out + o + 4) = vb;
     }
-    if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lc, va, vb, p.out_scale);
+    if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lc, va, vb, os);
+    if (p.amax_out) {
+        float mx = fmaxf(fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w)), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)));
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 31) == 0) atomicMax(&s_mx[(img - img_b0) & 7], __float_as_uint(mx));   // (8 rows: at most 8 images)
+    }
+    }   // m < p.M
+    if (p.amax_out) {
+        __syncthreads();
+        if (threadIdx.x < 8 && s_mx[threadIdx.x] != 0u) atomicMax(p.amax_out + img_b0 + threadIdx.x, s_mx[threadIdx.x]);
+    }
 }
 
-// FORM 0: gemm_h2<3>, 1: gemm_h2<4> (16-k steps, four products), 2: gemm_h3<false> (32-k steps, three products), 3: gemm_h3<true> (four)
+// FORM 0: gemm_h2<3>, 1: gemm_h2<4> (16-k steps, four products), 2: gemm_h3<false> (32-k steps, three products), 3: gemm_h3<true> (four),
+// 4: gemm_h3<false, true> (three products, implicit-GEMM taps)
 template <int FORM>
 static int launch_h2_variant(relax_handle* h, H2Params& p, hipStream_t s) {
     constexpr int BM = H2_BM, BN = H2_BN;
@@ -777,7 +987,9 @@ static int launch_h2_variant(relax_handle* h, H2Params& p, hipStream_t s) {
     p.group_m = h->gemm.group_m;
     p.partial = nullptr;
     // Tail split-K: the last, partial round of tiles is cut along K (cost model: host_logic.cpp, shared with the other kernels)
-    const host::TailSplit ts = host::choose_tail_split(p.ntiles, 256, BK32 ? p.K / 32 : p.K / 16, BK32 ? 4 : 8, h->gemm.split_k && !p.no_split);
+    // (splitk_finish_h2 knows neither the fused group sums nor a plane residual: those launches run unsplit)
+    const host::TailSplit ts = host::choose_tail_split(p.ntiles, 256, BK32 ? p.K / 32 : p.K / 16, BK32 ? 4 : 8,
+                                                       h->gemm.split_k && !p.no_split && !p.gap && !p.residual_h2);
     p.full_tiles = ts.full_tiles;
     p.nsplit = ts.nsplit;
     if (p.nsplit > 1) {
@@ -790,7 +1002,8 @@ static int launch_h2_variant(relax_handle* h, H2Params& p, hipStream_t s) {
         if constexpr (FORM == 0) return &gemm_h2<3>;
         else if constexpr (FORM == 1) return &gemm_h2<4>;
         else if constexpr (FORM == 2) return &gemm_h3<false>;
-        else return &gemm_h3<true>;
+        else if constexpr (FORM == 3) return &gemm_h3<true>;
+        else return &gemm_h3<false, true>;
     }();
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
@@ -814,25 +1027,43 @@ int launch_gemm_h2(relax_handle* h, const GemmDescH2& d, hipStream_t s) {
     p.colscale = d.colscale; p.rowscale = d.rowscale;
     p.bias = d.bias; p.residual = d.residual; p.out = d.out; p.out_h2 = static_cast<char*>(d.out_h2); p.out_scale = d.out_scale;
     p.M = d.M; p.N = d.N; p.K = d.K; p.act = d.act; p.no_split = d.no_split;
+    const bool conv = d.pixels != 0;
+    const bool taps = conv && d.KH * d.KW > 1;
+    if (conv) {
+        p.pixels = 1; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Ho = d.Ho; p.Wo = d.Wo; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
+        RELAX_REQUIRE(h, d.Nimg > 0 && d.M == d.Nimg * d.Ho * d.Wo && d.K == d.KH * d.KW * d.Cin && d.Cin % 32 == 0 && d.KH * d.KW <= 32 &&
+                             (taps || d.pad == 0) && d.stride >= 1 && (int64_t)d.H * d.W * d.Cin * 4 * 4 < kH2MaxRecords,
+                      "f16x2 conv: bad geometry (Cin=%d must be a multiple of 32, at most 32 taps, M = Nimg*Ho*Wo, K = KH*KW*Cin)", d.Cin);
+    }
+    p.rows_per_img = d.rows_per_img; p.img_in_inv = d.img_in_inv; p.img_out_scale = d.img_out_scale; p.amax_out = d.amax_out;
+    p.residual_h2 = static_cast<const char*>(d.residual_h2); p.img_res_inv = d.img_res_inv; p.gap = d.gap_groups;
+    p.out_rows = d.out_rows > 0 && d.out_rows < d.M ? d.out_rows : d.M;
+    p.gap_rows = d.gap_rows > 0 && d.gap_rows < d.M ? d.gap_rows : d.M;
+    RELAX_REQUIRE(h, !(d.residual && d.residual_h2) && (!d.residual_h2 || (d.img_res_inv && d.rows_per_img > 0)), "f16x2 gemm: bad residual");
+    RELAX_REQUIRE(h, !d.gap_groups || (d.rows_per_img > 0 && d.rows_per_img % 4 == 0), "f16x2 conv: the fused spatial mean needs Ho*Wo %% 4 == 0");
+    RELAX_REQUIRE(h, d.rows_per_img > 0 || (!d.img_in_inv && !d.img_out_scale && !d.amax_out), "f16x2 gemm: per-image tables need rows_per_img");
     RELAX_REQUIRE(h, p.M > 0 && p.N > 0 && p.K > 0, "f16x2 gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     RELAX_REQUIRE(h, p.K % 16 == 0 && p.N % 256 == 0, "f16x2 gemm: K=%d must be a multiple of 16 and N=%d of 256", p.K, p.N);
     RELAX_REQUIRE(h, (int64_t)p.K * 4 * 256 < kH2MaxRecords, "f16x2 gemm: K=%d too large", p.K);
-    RELAX_REQUIRE(h, d.a && d.w && d.colscale && (d.out || d.out_h2), "f16x2 gemm: missing operand / no output requested");
-    RELAX_REQUIRE(h, !d.out_h2 || (d.out_scale > 0.f && d.out_scale < 3.0e38f), "f16x2 gemm: the plane output needs its scale");
+    RELAX_REQUIRE(h, d.a && d.w && d.colscale && (d.out || d.out_h2 || d.gap_groups), "f16x2 gemm: missing operand / no output requested");
+    RELAX_REQUIRE(h, !d.out_h2 || d.img_out_scale || (d.out_scale > 0.f && d.out_scale < 3.0e38f), "f16x2 gemm: the plane output needs its scale");
     auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     RELAX_REQUIRE(h, aligned16(d.a) && aligned16(d.w) && aligned16(d.colscale) && aligned16(d.bias) && aligned16(d.residual) && aligned16(d.out) &&
                          aligned16(d.out_h2),
                   "f16x2 gemm: every operand pointer must be 16-byte aligned");
     const double flops = 2.0 * p.M * (double)p.N * (double)p.K;
     // algorithmic HBM bytes: operands as planes (4 B per value), outputs (+ residual), each touched once
-    const double bytes = 4.0 * ((double)p.M * p.K + (double)p.N * p.K) +
+    const double bytes = 4.0 * ((conv ? (double)d.Nimg * d.H * d.W * d.Cin : (double)p.M * p.K) + (double)p.N * p.K) +
                          (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_h2 ? 4.0 : 0.0) + (d.residual ? 4.0 : 0.0));
     int span;
     RELAX_TRY(prof_begin(h, s, 5, flops, &span, bytes));
     // "h2_form": 1 (default) = 32-k steps with three products for K >= 256 and four below (and 16-k steps for K % 32 != 0);
     // 0 = 16-k steps, four products ("h2_stages" LDS stages); 2 = 32-k steps, four products at every K
     int rc;
-    if (h->gemm.h2_form == 0 || p.K % 32 != 0) rc = h->gemm.h2_stages == 4 ? launch_h2_variant<1>(h, p, s) : launch_h2_variant<0>(h, p, s);
+    if (conv) {
+        RELAX_REQUIRE(h, p.K % 32 == 0, "f16x2 conv: K=%d must be a multiple of 32", p.K);
+        rc = taps ? launch_h2_variant<4>(h, p, s) : launch_h2_variant<2>(h, p, s);
+    } else if (h->gemm.h2_form == 0 || p.K % 32 != 0) rc = h->gemm.h2_stages == 4 ? launch_h2_variant<1>(h, p, s) : launch_h2_variant<0>(h, p, s);
     else if (h->gemm.h2_form == 2 || p.K < 256) rc = launch_h2_variant<3>(h, p, s);
     else rc = launch_h2_variant<2>(h, p, s);
     if (rc != RELAX_OK) { prof_abort(h, span); return rc; }

@@ -46,6 +46,7 @@
 #include "relax_internal.h"
 #include "host_logic.h"
 #include "sp3.h"
+#include "h2.h"
 #include "gelu.h"
 
 // Phase-stamp hooks of the diagnostic build: empty in the product.  tools/abl/gemm_x6_stamps.hip defines them (and the report) and
@@ -100,6 +101,9 @@ struct X6Params {
     float* gap;              // fused spatial mean, stage 1: sums of the outputs over aligned groups of 16 (or 4: gap_shift) rows [M/16][N], or null
     float* out;              // fp32 [M][N] or null
     char* out_sp3;           // sp3 [M][N*6 B] or null
+    char* out_h2;            // the outputs also as two fp16 planes [M][N*4 B], image i's rows scaled by img_out_scale[i] (csrc/h2.h), or null
+    const float* img_out_scale;
+    unsigned* amax_out;      // [images]: atomicMax of the bits of the (non-negative) outputs of each image, or null (image = row / (Ho*Wo))
     float* partial;          // split-K partial tiles
     int M, N, K;
     int K1, H2, W2, Cin2, stride2;   // DUAL only
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int EP_STEP = NT / C8;
     constexpr int EP_ITERS = EP_ROWS / EP_STEP;
     const int half = lane >> 5;
-    const bool planes = p.out_sp3 != nullptr || p.residual_sp3 != nullptr;   // workgroup-uniform
+    const bool planes = p.out_sp3 != nullptr || p.residual_sp3 != nullptr || p.out_h2 != nullptr;   // workgroup-uniform
     const int lcA = planes ? (tid % C8) * 8 : (tid % C8) * 4;
     const int lcB = planes ? lcA + 4 : lcA + BN / 2;
     const int lr0 = tid / C8;
@@ -618,6 +622,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         bias_b = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcB);
     }
     const bool interior = m0 + BM <= p.M;   // workgroup-uniform
+    // per-image maxima of this tile (amax_out), collected in LDS right behind the staging rows: one global atomic per image and tile (a
+    // global atomic per row segment - 1.6 M per launch of layer2's conv3, hundreds per address - cost 1.7 ms of a 1.1 ms launch)
+    static_assert(EP_ROWS * LDC * 4 + 64 <= 2 * STAGE + 1024, "no room for the per-image maxima behind the staging rows");
+    unsigned* simg = reinterpret_cast<unsigned*>(smem + EP_ROWS * LDC * 4);
+    const int img_first = p.amax_out ? m0 / (p.Ho * p.Wo) : 0;
+    const bool lds_amax = p.amax_out && slice < 0 && p.Ho * p.Wo >= 18;   // at most 16 images under the tile's 256 rows
+    if (lds_amax && tid < 16) simg[tid] = 0u;   // (ordered before the first use by the barrier of the first pass)
 #pragma unroll
     for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
         if (pass > 0) __syncthreads();
@@ -717,6 +728,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
             }
             if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lcA, va, vb);   // (planes: lcB = lcA + 4)
+            if (p.out_h2 || p.amax_out) {   // hand-over to the f16x2 layers: fp16 planes with the image's scale, the image's maximum
+                const int img = m / (p.Ho * p.Wo);
+                if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, p.img_out_scale[img]);
+                if (p.amax_out) {   // outputs are >= 0 (ReLU): integer max of the bits = float max, order-free; per tile in LDS first
+                    float mx = fmaxf(fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w)), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)));
+                    _Pragma("unroll") for (int o = C8 / 2; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                    if ((tid % C8) == 0) {
+                        if (lds_amax) atomicMax(simg + (img - img_first), __float_as_uint(mx));
+                        else atomicMax(p.amax_out + img, __float_as_uint(mx));
+                    }
+                }
+            }
             if (p.gap) {   // the finished values go back to the staging rows for the group sums below
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcA) = va;
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcB) = vb;
@@ -751,6 +774,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 }
             }
         }
+    }
+    if (lds_amax) {
+        __syncthreads();
+        if (tid < 16 && simg[tid] != 0u) atomicMax(p.amax_out + img_first + tid, simg[tid]);
     }
     X6_STAMP(3);
 #endif
@@ -818,7 +845,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     p.partial = nullptr;
     // Tail split-K: the last, partial round of tiles is cut along K (cost model: host_logic.cpp, shared with gemm.hip);
     // splitk_finish_x6 knows neither the fused group sums nor a split-plane residual, so those launches run unsplit
-    const bool can_split = h->gemm.split_k && !p.gap && !p.residual_sp3 && !p.no_split;
+    const bool can_split = h->gemm.split_k && !p.gap && !p.residual_sp3 && !p.no_split && !p.out_h2 && !p.amax_out;
     const host::TailSplit ts = host::choose_tail_split(p.ntiles, 256 * WG_PER_CU, p.K / 16, 8, can_split);
     p.full_tiles = ts.full_tiles;
     p.nsplit = ts.nsplit;
@@ -850,6 +877,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     p.w = static_cast<const char*>(d.w);
     p.bias = d.bias; p.residual = d.residual; p.out = d.out; p.out_sp3 = static_cast<char*>(d.out_sp3);
     p.residual_sp3 = static_cast<const char*>(d.residual_sp3);
+    p.out_h2 = static_cast<char*>(d.out_h2); p.img_out_scale = d.img_out_scale; p.amax_out = d.amax_out;
     p.gap = d.gap_groups;
     p.M = d.Nimg * d.Ho * d.Wo;
     p.N = d.Cout;
@@ -868,8 +896,10 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, d.Cin % 16 == 0, "x6 conv/gemm: Cin=%d must be a multiple of 16", d.Cin);
     RELAX_REQUIRE(h, p.N % 64 == 0, "x6 conv/gemm: N=%d must be a multiple of 64", p.N);
     RELAX_REQUIRE(h, (int64_t)p.K * 6 * 256 < kMaxRecords, "x6 conv/gemm: K=%d too large", p.K);
-    RELAX_REQUIRE(h, d.out || d.out_sp3 || d.gap_groups, "x6 conv/gemm: no output requested");
+    RELAX_REQUIRE(h, d.out || d.out_sp3 || d.gap_groups || d.out_h2, "x6 conv/gemm: no output requested");
     RELAX_REQUIRE(h, !(d.residual && d.residual_sp3), "x6 conv/gemm: two residuals");
+    RELAX_REQUIRE(h, (!d.out_h2 || d.img_out_scale) && (!(d.out_h2 || d.amax_out) || d.act == 1),
+                  "x6 conv/gemm: the fp16-plane output needs its per-image scales, and it and the per-image maximum go with a ReLU");
     RELAX_REQUIRE(h, !d.gap_groups || (d.Ho * d.Wo) % 4 == 0, "x6 conv: the fused spatial mean needs Ho*Wo %% 4 == 0");
     RELAX_REQUIRE(h, !taps || (d.pad >= 0 && d.KH * d.KW <= 32), "x6 conv: bad padding, or more than 32 taps (%dx%d)", d.KH, d.KW);
     RELAX_REQUIRE(h, taps || d.pad == 0, "x6 conv: 1x1 with padding is not supported");

@@ -86,6 +86,11 @@ struct ConvDescX6 {
     float* gap_groups;      // fused spatial mean, stage 1: sums over aligned 16-row groups [M/16][Cout] (Ho*Wo % 16 != 0: 4-row groups [M/4][Cout]), or null
     float* out;             // fp32 [M, Cout] or null
     void* out_sp3;          // sp3 [M][Cout*6 B] or null (at least one output)
+    // the hand-over to the f16x2 convolutions of layer3 (gemm_h2.hip, "per-image scales"): the outputs also as two fp16 planes with
+    // image i's rows scaled by img_out_scale[i], and / or the per-image maximum of the (non-negative) outputs; both run unsplit
+    void* out_h2;
+    const float* img_out_scale;
+    unsigned* amax_out;
     int act;                // 0 none, 1 relu, 2 gelu(erf)
     double flops;           // algorithmic FLOPs for the profiler (0 = 2*M*N*K)
 };
@@ -104,12 +109,28 @@ struct GemmDescH2 {
     int M, N, K;
     int act;                // 0 none, 1 relu, 2 gelu(erf)
     bool no_split;
+    // convolution form (gemm_h3 as implicit GEMM; ResNet-50 layer3 / layer4): a = NHWC planes [Nimg*H*W][Cin*4 B], M = Nimg*Ho*Wo,
+    // K = KH*KW*Cin, weight rows k = (dy*KW + dx)*Cin + c; pixels = 0: plain GEMM
+    int pixels, Nimg, H, W, Cin, Ho, Wo, KH, KW, stride, pad;
+    // per-image scales (image = row / rows_per_img) and the per-image maximum of the outputs (see h2_image_scales)
+    int rows_per_img;
+    const float* img_in_inv;
+    const float* img_out_scale;
+    unsigned* amax_out;
+    const void* residual_h2;      // the residual as fp16 planes [M][N*4 B] with img_res_inv[image] (instead of `residual`), or null
+    const float* img_res_inv;
+    float* gap_groups;            // fused spatial mean, stage 1: sums over aligned 4-row groups [M/4][N], or null
+    int out_rows, gap_rows;       // rows below these limits get the fp32 output / the group sums (0 = all rows)
 };
 
 // ---- model weights ------------------------------------------------------------------------------
 struct ConvW {          // one folded conv (+BN) of ResNet-50
     float* w = nullptr;     // device [Cout][Kpad]
     void* w_sp3 = nullptr;  // the same as split planes (bf16x6 kernel); conv1: [64][224], k = ky*32 + kx*3 + c (conv1_x6.hip)
+    void* w_h2 = nullptr;   // layer3 / layer4: the same as two fp16 planes, row n scaled by 2^t_n (gemm_h2.hip)
+    float* w_inv = nullptr; // [Cout]: 2^-t_n
+    float l1max = 0.f;      // max_n sum_k |W[n,k]| of the folded weights and max_n |bias[n]|: Hoelder bound of the outputs from the
+    float bmax = 0.f;       // measured maximum of the inputs (per-image scales, gemm_h2.hip)
     float* bias = nullptr;  // device [Cout] (null for the raw conv1)
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, Kpad = 0;
 };
@@ -221,6 +242,8 @@ struct GemmOptions {
                                  // height and width are multiples of 8), 0 = gray plane + per-level blur / resize kernels (any size) - same bits
     int flow_fused = 1;      // "flow_fused": 1 = one kernel per Farneback iteration (flow_iteration: M never leaves the chip); 0 = update_matrices_k +
                              // box_solve_fused (M through HBM) - same bits, the A/B switch of a test
+    int rn_h2 = 1;         // "rn_h2": under "gemm_precision" 3, ResNet-50's layer3 / layer4 (the matrix-pipe-bound third of its time) run f16x2 with
+                           // per-image scales; 0 = the whole network on bf16x6 (the A/B switch of a test)
     int fp32_rows = 1;     // "x6_fp32_rows": bf16x6 contractions onto 64 / 128 columns take fp32 activation rows and split them in the K loop
                            // (ResNet-50 layer1 / layer2 block outputs travel as fp32); 0 = split planes everywhere (same bits, more bytes: the A/B switch of a test)
     int debug_poison = 0;  // "debug_poison": fill every workspace with 0xFF bytes when it is requested (test mode: reads of unwritten workspace surface as NaN)
@@ -284,7 +307,11 @@ inline int launch_gemm_x6(relax_handle* h, const void* A_sp3, const void* W_sp3,
 
 // f16x2 contraction kernel (gemm_h2.hip)
 int launch_gemm_h2(relax_handle* h, const GemmDescH2& d, hipStream_t s);
-int launch_to_h2(relax_handle* h, const float* x, int64_t ld, void* y, int64_t rows, int K, float scale, const float* row_scale, hipStream_t s);
+int launch_to_h2(relax_handle* h, const float* x, int64_t ld, void* y, int64_t rows, int K, float scale, const float* row_scale, hipStream_t s,
+                 int rows_per_scale = 1);
+int launch_h2_image_scales(relax_handle* h, const unsigned* amax_a, float la, const unsigned* amax_b, float lb, const unsigned* amax_r,
+                           float bmax, float* scale, float* inv, int n, hipStream_t s);
+int launch_image_absmax(relax_handle* h, const float* x, int64_t per_image, int n_images, unsigned* amax, hipStream_t s);
 int launch_to_h2_rows(relax_handle* h, const float* x, int64_t ld, void* y, int rows, int K, float* inv_scale, hipStream_t s);
 
 // small kernels (layers.hip)

@@ -123,6 +123,15 @@ static int make_conv(relax_handle* h, const HostSD& sd, const std::string& conv,
     host::pack_conv_oihw(w, scale.data(), cout, cin, cin_pad, k, kpad, packed.data());
     out->Cin = cin_pad; out->Cout = cout; out->KH = k; out->KW = k; out->stride = stride; out->pad = pad;
     out->Kpad = kpad;
+    // Hoelder constants of the folded convolution: |out[n]| <= l1max * max |in| + bmax  (per-image scales of the f16x2 layers, gemm_h2.hip)
+    out->l1max = 0.f;
+    out->bmax = 0.f;
+    for (int o = 0; o < cout; ++o) {
+        double l1 = 0.0;
+        for (int kk = 0; kk < kpad; ++kk) l1 += std::fabs((double)packed[(size_t)o * kpad + kk]);
+        out->l1max = std::fmax(out->l1max, (float)(l1 * (1.0 + 1e-6)));
+        if (!bn.empty()) out->bmax = std::fmax(out->bmax, std::fabs(shift[o]));
+    }
     RELAX_TRY(upload(h, packed.data(), packed.size(), &out->w, allocs));
     if (!bn.empty()) RELAX_TRY(upload(h, shift.data(), shift.size(), &out->bias, allocs));
     else out->bias = nullptr;
@@ -142,10 +151,12 @@ static constexpr size_t kT1 = 56 * 56 * 128;        // largest conv1-of-block ou
 static constexpr size_t kT2 = 56 * 56 * 64;         // largest conv2 output
 static constexpr size_t kGapWs = 196 * 256;         // GAP partial sums (16 x 2048 two-stage kernel; 3136/16 x 256 fused group sums)
 static constexpr size_t kAvg = 2048;
+static constexpr size_t kFirstH2Block = 7;          // layer3[0]: from here on the blocks run f16x2 under "gemm_precision" 3 (with "rn_h2")
+static constexpr size_t kImgSlots = 64;             // per-image tables of the f16x2 blocks: slot t = {maximum, scale, 1 / scale} x images
 static constexpr size_t kRnFloatsPerImage = kX0 + 3 * kBig + kT1 + kT2 + kGapWs + kAvg;
 // bf16x6 path: block inputs / outputs exist twice (fp32 for the residual add and the taps, split planes = 1.5 floats per
 // value for the next convolutions), the intermediates of a block only as split planes
-static constexpr size_t kRnFloatsPerImageX6 = kX0 + 3 * kBig + 2 * (kBig * 3 / 2) + (kT1 + kT2) * 3 / 2 + kGapWs + kAvg;
+static constexpr size_t kRnFloatsPerImageX6 = kX0 + 3 * kBig + 2 * (kBig * 3 / 2) + (kT1 + kT2) * 3 / 2 + kGapWs + kAvg + 3 * kImgSlots;
 
 size_t resnet_arena_bytes(int n) {
     return sizeof(float) * (kRnFloatsPerImage > kRnFloatsPerImageX6 ? kRnFloatsPerImage : kRnFloatsPerImageX6) * (size_t)n;
@@ -263,6 +274,30 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
             if (rc != RELAX_OK) { free_resnet(h); return rc; }
         }
     }
+    // ... the convolutions of layer3 / layer4 (blocks 7 .. 15: 256 / 512-wide, every Cout a multiple of 256, every Cin of 32) also as two
+    // fp16 planes with one power-of-two scale per output row (gemm_h2.hip; w_inv = the inverse scales, the epilogue's colscale)
+    for (size_t b = kFirstH2Block; b < rn.blocks.size(); ++b) {
+        Bottleneck& blk = rn.blocks[b];
+        for (ConvW* c : {&blk.c1, &blk.c2, &blk.c3, &blk.down}) {
+            if (!c->w) continue;
+            const int K = c->KH * c->KW * c->Cin;
+            void* q = nullptr;
+            float* inv = nullptr;
+            if (c->Cin % 32 != 0 || c->Cout % 256 != 0 || hipMalloc(&q, (size_t)c->Cout * K * 4) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&inv), sizeof(float) * (size_t)c->Cout) != hipSuccess) {
+                if (q) (void)hipFree(q);
+                set_error(h, "resnet50: fp16-plane weights of block %zu (Cin %d, Cout %d) could not be made", b, c->Cin, c->Cout);
+                free_resnet(h);
+                return RELAX_ERR_NOMEM;
+            }
+            rn.allocs.push_back(q);
+            rn.allocs.push_back(inv);
+            c->w_h2 = q;
+            c->w_inv = inv;
+            rc = launch_to_h2_rows(h, c->w, K, q, c->Cout, K, inv, nullptr);
+            if (rc != RELAX_OK) { free_resnet(h); return rc; }
+        }
+    }
     // ... and, for the four blocks with a downsample branch, [conv3 | downsample] rows side by side
     for (Bottleneck& blk : rn.blocks) {
         if (!blk.has_down) continue;
@@ -359,6 +394,16 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
         float* gapws6 = reinterpret_cast<float*>(T2s + sizeof(float) * (kT2 * 3 / 2) * n);
         float* avg6 = gapws6 + kGapWs * n;
         gapws = gapws6;
+        // f16x2 for layer3 / layer4 ("gemm_precision" 3 with "rn_h2"): per-image tables {maximum, scale, 1 / scale}, one slot per tensor
+        const bool use_h2 = h->gemm.precision == 3 && h->gemm.rn_h2 && rn.blocks.size() == 16;
+        float* imgtab = avg6 + kAvg * n;
+        int next_slot = 0;
+        auto slot_amax = [&](int t) { return reinterpret_cast<unsigned*>(imgtab + (size_t)(3 * t) * n); };
+        auto slot_scale = [&](int t) { return imgtab + (size_t)(3 * t + 1) * n; };
+        auto slot_inv = [&](int t) { return imgtab + (size_t)(3 * t + 2) * n; };
+        if (use_h2) RELAX_HIP_CHECK(h, hipMemsetAsync(imgtab, 0, sizeof(float) * 3 * kImgSlots * n, s));
+        int slot_x = -1;          // the current block input's slot, once it exists as fp16 planes
+        int slot_prev_out = -1;   // maximum of the previous block's output (the residual of the hand-over block)
         RELAX_TRY(launch_bn_relu_maxpool_sp3(h, bufA, rn.bn1_scale, rn.bn1_shift, spa, N, 112, 112, 64, s));
         // A block output exists as split planes (next convolutions, next residual: hi + mid + lo is the fp32 value, exactly) and as
         // fp32 only where something needs it, and only for the images that need it: the tap export, the spatial mean of the 7x7
@@ -390,6 +435,77 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             // fp32 rows: every image for the next block, an export or the pool images behind the layer-stack ones, else the
             // layer-stack images only
             const int rows32 = (out_is_f32 || want_export || pool_needs32) ? N * HWo : n_ls * HWo;
+            if (use_h2 && b >= kFirstH2Block) {
+                // ---- an f16x2 block (gemm_h2.hip).  Every tensor that feeds a convolution travels as two fp16 planes with one scale per
+                // image; the scale of a tensor is fixed BEFORE it is written, from Hoelder's bound on its producer (measured maxima of
+                // the producer's inputs, l1max / bmax of its weights).  cursp = the block input's planes (slot_x).
+                const int s1 = next_slot++, s2 = next_slot++, sy = next_slot++;
+                // fp32 copies only where something reads them: an export, the spatial mean of the 7x7 taps (49 rows do not divide into the
+                // 4-row groups of the fused mean), the last block's map of the pool images - and only for the images that need them.  The
+                // residual of a block without a downsample branch is read from the block input's PLANES (hi + lo, the stored 22-bit value).
+                const bool fuse_h2 = want_mean && HWo % 4 == 0 && HWo % 16 != 0;   // 14x14 maps: 4-row groups (gemm_h3's fused mean)
+                const bool need32_h2 = want_export || (want_mean && !fuse_h2) || pool_needs32;
+                const int rows32_h2 = (want_export || pool_needs32) ? N * HWo : n_ls * HWo;
+                auto conv_h2 = [&](const ConvW& c, const void* in, int Hin, int slot_in, GemmDescH2 g, int slot_out, int act) {
+                    g.a = in; g.w = c.w_h2; g.colscale = c.w_inv; g.bias = c.bias; g.act = act;
+                    g.pixels = 1; g.Nimg = N; g.H = Hin; g.W = Hin; g.Cin = c.Cin;
+                    g.Ho = (Hin + 2 * c.pad - c.KH) / c.stride + 1; g.Wo = g.Ho;
+                    g.KH = c.KH; g.KW = c.KW; g.stride = c.stride; g.pad = c.pad;
+                    g.M = N * g.Ho * g.Wo; g.N = c.Cout; g.K = c.KH * c.KW * c.Cin;
+                    g.rows_per_img = g.Ho * g.Wo; g.img_in_inv = slot_inv(slot_in);
+                    if (g.out_h2) { g.img_out_scale = slot_scale(slot_out); g.amax_out = slot_amax(slot_out); }
+                    return launch_gemm_h2(h, g, s);
+                };
+                // conv1 1x1 + ReLU
+                RELAX_TRY(launch_h2_image_scales(h, slot_amax(slot_x), blk.c1.l1max, nullptr, 0.f, nullptr, blk.c1.bmax, slot_scale(s1), slot_inv(s1), N, s));
+                { GemmDescH2 g{}; g.out_h2 = T1s; RELAX_TRY(conv_h2(blk.c1, cursp, H, slot_x, g, s1, 1)); }
+                // conv2 3x3 (stride) + ReLU
+                RELAX_TRY(launch_h2_image_scales(h, slot_amax(s1), blk.c2.l1max, nullptr, 0.f, nullptr, blk.c2.bmax, slot_scale(s2), slot_inv(s2), N, s));
+                { GemmDescH2 g{}; g.out_h2 = T2s; RELAX_TRY(conv_h2(blk.c2, T1s, H, s1, g, s2, 1)); }
+                // conv3 1x1 + identity + ReLU: the identity is the block input (its planes) or the downsample convolution of it (fp32, no
+                // activation; bounded by its own Hoelder term)
+                GemmDescH2 g3{};
+                if (blk.has_down) {
+                    GemmDescH2 gd{};
+                    gd.out = bufA;
+                    RELAX_TRY(conv_h2(blk.down, cursp, H, slot_x, gd, -1, 0));
+                    g3.residual = bufA;
+                    RELAX_TRY(launch_h2_image_scales(h, slot_amax(s2), blk.c3.l1max, slot_amax(slot_x), blk.down.l1max, nullptr,
+                                                     blk.c3.bmax + blk.down.bmax, slot_scale(sy), slot_inv(sy), N, s));
+                } else {
+                    g3.residual_h2 = cursp; g3.img_res_inv = slot_inv(slot_x);
+                    RELAX_TRY(launch_h2_image_scales(h, slot_amax(s2), blk.c3.l1max, nullptr, 0.f, slot_amax(slot_x), blk.c3.bmax, slot_scale(sy),
+                                                     slot_inv(sy), N, s));
+                }
+                g3.out = need32_h2 ? out32 : nullptr; g3.out_rows = rows32_h2;
+                g3.out_h2 = is_last ? nullptr : othersp;
+                g3.gap_groups = fuse_h2 ? gapws : nullptr; g3.gap_rows = n_ls * HWo;
+                g3.no_split = tapped && HWo % 4 == 0 && HWo % 16 != 0;   // a launch that fuses the mean when the layer stack is asked for runs
+                                                                         // unsplit either way: the pool vector's bits do not depend on the request
+                RELAX_TRY(conv_h2(blk.c3, T2s, Ho, s2, g3, sy, 1));
+                cur32 = need32_h2 ? out32 : nullptr;
+                if (need32_h2) out32 = out32 == f32a ? f32b : f32a;
+                { char* t = cursp; cursp = othersp; othersp = t; }
+                cur_is_f32 = false;
+                slot_x = sy;
+                H = Ho;
+                if (tapped) {
+                    const int off = tap_offset(blk.tap);
+                    if (fuse_h2)
+                        RELAX_TRY(launch_gap_groups_finish(h, gapws, layer_stack + off, n_ls, HWo, Cout, RELAX_RN50_LAYER_STACK_DIM, s));
+                    else if (want_mean)
+                        RELAX_TRY(launch_gap_ws(h, cur32, layer_stack + off, n_ls, HWo, Cout, RELAX_RN50_LAYER_STACK_DIM, gapws, s));
+                    if (want_export) RELAX_TRY(launch_nhwc_to_nchw(h, cur32, taps_nchw[blk.tap], N, HWo, Cout, s));
+                }
+                continue;
+            }
+            // the two blocks in front of the f16x2 ones hand over: block 5's output maximum (the residual of block 6), block 6's conv2
+            // maximum, and block 6's output as fp32 + fp16 planes with its Hoelder scale + its maximum
+            const bool handover = use_h2 && b + 1 == kFirstH2Block;
+            const bool pre_handover = use_h2 && b + 2 == kFirstH2Block;
+            int slot_c2 = -1, slot_y = -1;
+            if (handover) { slot_c2 = next_slot++; slot_y = next_slot++; }
+            if (pre_handover) slot_prev_out = next_slot++;
             {
                 ConvDescX6 d{};
                 d.in = cur_is_f32 ? static_cast<const void*>(cur32) : cursp; d.in_f32 = cur_is_f32;
@@ -398,7 +514,17 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 d.w = blk.c1.w_sp3; d.Cout = blk.c1.Cout; d.bias = blk.c1.bias; d.out_sp3 = T1s; d.act = 1;
                 RELAX_TRY(launch_conv_x6(h, d, s));
             }
-            RELAX_TRY(run_conv_x6(h, blk.c2, T1s, N, H, H, nullptr, nullptr, T2s, 1, s));
+            if (handover) {
+                ConvDescX6 d2{};
+                d2.in = T1s; d2.Nimg = N; d2.H = H; d2.W = H; d2.Cin = blk.c2.Cin;
+                d2.Ho = (H + 2 * blk.c2.pad - blk.c2.KH) / blk.c2.stride + 1; d2.Wo = d2.Ho;
+                d2.KH = blk.c2.KH; d2.KW = blk.c2.KW; d2.stride = blk.c2.stride; d2.pad = blk.c2.pad;
+                d2.w = blk.c2.w_sp3; d2.Cout = blk.c2.Cout; d2.bias = blk.c2.bias; d2.out_sp3 = T2s; d2.act = 1;
+                d2.amax_out = slot_amax(slot_c2);
+                RELAX_TRY(launch_conv_x6(h, d2, s));
+            } else {
+                RELAX_TRY(run_conv_x6(h, blk.c2, T1s, N, H, H, nullptr, nullptr, T2s, 1, s));
+            }
             ConvDescX6 d{};
             d.in = T2s; d.Nimg = N; d.H = Ho; d.W = Ho; d.Cin = blk.c3.Cin; d.Ho = Ho; d.Wo = Ho;
             d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
@@ -417,7 +543,33 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 d.w = blk.c3.w_sp3; d.bias = blk.c3.bias;
                 if (cur_is_f32) d.residual = cur32; else d.residual_sp3 = cursp;
             }
+            if (pre_handover) d.amax_out = slot_amax(slot_prev_out);
+            if (handover) {
+                // (block 6 has no downsample branch and its input is fp32 rows: residual = cur32; its output leaves as fp16 planes with the
+                // Hoelder scale of conv3 + identity)
+                RELAX_TRY(launch_h2_image_scales(h, slot_amax(slot_c2), blk.c3.l1max, nullptr, 0.f, slot_amax(slot_prev_out), blk.c3.bmax,
+                                                 slot_scale(slot_y), slot_inv(slot_y), N, s));
+                d.out_sp3 = nullptr;       // (fp32 rows as the tap logic above decided; block 7 takes its identity from its downsample branch)
+                d.out_h2 = othersp; d.img_out_scale = slot_scale(slot_y); d.amax_out = slot_amax(slot_y);
+            }
             RELAX_TRY(launch_conv_x6(h, d, s));
+            if (handover) {
+                cur32 = need32 ? out32 : nullptr;
+                if (need32) out32 = out32 == f32a ? f32b : f32a;
+                { char* t = cursp; cursp = othersp; othersp = t; }
+                cur_is_f32 = false;
+                slot_x = slot_y;
+                H = Ho;
+                if (tapped) {
+                    const int off = tap_offset(blk.tap);
+                    if (fuse_mean)
+                        RELAX_TRY(launch_gap_groups_finish(h, gapws, layer_stack + off, n_ls, HWo, Cout, RELAX_RN50_LAYER_STACK_DIM, s));
+                    else if (want_mean)
+                        RELAX_TRY(launch_gap_ws(h, cur32, layer_stack + off, n_ls, HWo, Cout, RELAX_RN50_LAYER_STACK_DIM, gapws, s));
+                    if (want_export) RELAX_TRY(launch_nhwc_to_nchw(h, cur32, taps_nchw[blk.tap], N, HWo, Cout, s));
+                }
+                continue;
+            }
             cur32 = need32 ? out32 : nullptr;
             if (need32) out32 = out32 == f32a ? f32b : f32a;
             if (!out_is_f32) { char* t = cursp; cursp = othersp; othersp = t; }

@@ -158,6 +158,42 @@ def test_split_k_is_deterministic_and_optional_and_stages_agree(h2):
     assert_close(a, whole.cpu().numpy(), "split-K vs whole-K", rtol=1e-4, atol_frac=1e-5)
 
 
+# ---- convolutions under f16x2 (the geometries of ResNet-50 layer3 / layer4: Cin % 32 == 0, Cout % 256 == 0) -----------------------------
+from relax_vqa_amd.engine import pack_conv_weight  # noqa: E402
+
+CONVS = [  # Nimg, H, Cin, Cout, k, stride, pad
+    (2, 14, 256, 256, 3, 1, 1), (5, 7, 512, 512, 3, 1, 1), (2, 7, 2048, 512, 1, 1, 0), (3, 28, 256, 512, 1, 2, 0), (7, 7, 512, 2048, 1, 1, 0),
+    (2, 14, 1024, 256, 1, 1, 0), (3, 14, 512, 512, 3, 2, 1), (40, 14, 256, 256, 3, 1, 1), (3, 30, 32, 256, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("Nimg,H,Cin,Cout,k,stride,pad", CONVS)
+def test_conv2d_nhwc_under_f16x2(Nimg, H, Cin, Cout, k, stride, pad):
+    """gemm_h3 as implicit GEMM (taps, strides, padding by the DMA's range check, rows of a tile spanning several images) with one scale
+    per IMAGE: images of very different magnitude in one batch (x 2^-12 .. 2^12) keep their own precision.  Error against fp64 no
+    larger than the exact-fp32 path's."""
+    eng = engine()
+    x = _rand(Nimg, Cin, H, H, seed=7) * torch.exp2(torch.linspace(-12, 12, Nimg))[:, None, None, None]
+    w = _rand(Cout, Cin, k, k, seed=8, scale=(Cin * k * k) ** -0.5)
+    b = _rand(Cout, seed=9) * 1e-3
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad))
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = torch.from_numpy(pack_conv_weight(w.numpy())).cuda()
+    eng.set_precision("fp32")
+    e32 = (eng.op_conv2d_nhwc(x_nhwc, wp, b.cuda(), None, Cout, k, k, stride, pad, act=1).permute(0, 3, 1, 2).cpu().double() - ref).abs()
+    eng.set_precision("f16x2")
+    got = eng.op_conv2d_nhwc(x_nhwc, wp, b.cuda(), None, Cout, k, k, stride, pad, act=1).permute(0, 3, 1, 2)
+    assert torch.equal(got, eng.op_conv2d_nhwc(x_nhwc, wp, b.cuda(), None, Cout, k, k, stride, pad, act=1).permute(0, 3, 1, 2))
+    e2 = (got.cpu().double() - ref).abs()
+    per_img = ref.abs().mean(dim=(1, 2, 3)).clamp_min(1e-300)
+    r32, r2 = (e32.mean(dim=(1, 2, 3)) / per_img), (e2.mean(dim=(1, 2, 3)) / per_img)
+    print(f"\nconv {Nimg}x{H}x{Cin}->{Cout} k{k}s{stride}: per-image mean err / mean |ref|: fp32 {r32.mean().item():.3e} (max {r32.max().item():.3e})  "
+          f"f16x2 {r2.mean().item():.3e} (max {r2.max().item():.3e})")
+    for i in range(Nimg):
+        assert_close(got[i], ref[i].float().numpy(), f"f16x2 conv image {i}")
+    assert r2.mean().item() <= 1.05 * r32.mean().item() + 1e-12 and r2.max().item() <= 1.25 * r32.max().item() + 1e-12
+
+
 # ---- the ViT under f16x2 ------------------------------------------------------------------------------------------------
 def _fragments(n, seed=0):
     frs = []
@@ -244,3 +280,68 @@ def test_extreme_inputs_cannot_overflow_the_static_scales():
         assert err["f16x2"][0] <= 1.25 * err["fp32"][0] and err["f16x2"][1] <= 2.0 * err["fp32"][1]
         if not adv:
             assert_close(tokens, ref.astype(np.float32), "extreme inputs, regular weights")
+
+
+# ---- ResNet-50 under f16x2: layer3 / layer4 on fp16 planes with per-image scales ------------------------------------------------------------
+from oracle import resnet50_ref  # noqa: E402
+from tests.gpu_common import rn50_weights  # noqa: E402
+
+
+@pytest.mark.parametrize("adv", [False, True], ids=["regular", "adversarial"])
+def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
+    """All 15 taps + both feature vectors with layer3 / layer4 on the f16x2 kernels ("rn_h2", the default under gemm_precision 3): inside
+    the bar against the fp32 oracle, deterministic, and against an fp64 run of the oracle no further away than bf16x6 everywhere (x 1.25) and
+    than torch-CPU fp32 - the reference's own arithmetic - on every tap.  Images of very different brightness share the batch: the scales are
+    per image.  The adversarial set (BatchNorm variances 1e-3 .. 10: activations of very different size from layer to layer) exercises
+    the Hoelder bounds."""
+    sd = rn50_weights(adversarial=adv)
+    eng = engine()
+    frags = _fragments(4)
+    frags[1] = frags[1] // 16                      # a dark image and a bright one in the same batch
+    frags[2] = 255 - frags[2] // 8
+    f = torch.from_numpy(frags).cuda()
+    eng.set_precision("f16x2")
+    assert eng.get_option("rn_h2") == 1
+    ls2, pool2, taps2 = eng.resnet50_features(f, taps=range(15))
+    ls2b, pool2b = eng.resnet50_features(f)
+    assert torch.equal(ls2, ls2b) and torch.equal(pool2, pool2b), "f16x2 ResNet-50 is not deterministic"
+    eng.set_option("rn_h2", 0)
+    try:
+        ls6, pool6, taps6 = eng.resnet50_features(f, taps=range(15))
+    finally:
+        eng.set_option("rn_h2", 1)
+    tsd = resnet50_ref.to_torch_state_dict(sd)
+    ref_taps, _ = resnet50_ref.forward_taps(tsd, resnet50_ref.preprocess_bgr_u8(frags))
+    sd64 = {k: v.double() for k, v in tsd.items()}
+    ref64, _ = resnet50_ref.forward_taps(sd64, resnet50_ref.preprocess_bgr_u8(frags).double())
+
+    def rel(a, r):
+        return float(np.linalg.norm(np.asarray(a, dtype=np.float64) - r) / np.linalg.norm(r))
+
+    for i, name in enumerate(pooling_ref.RESNET50_TAPS):
+        assert_close(taps2[i], ref_taps[name].numpy(), f"f16x2 {name}")
+        r = ref64[name].numpy()
+        n2, n6, ncpu = rel(taps2[i].cpu().numpy(), r), rel(taps6[i].cpu().numpy(), r), rel(ref_taps[name].numpy(), r)
+        print(f"{name:22s} vs fp64: f16x2 layers 3-4 {n2:.3e}  bf16x6 everywhere {n6:.3e}  torch CPU fp32 {ncpu:.3e}")
+        assert n2 <= 1.25 * n6 + 1e-9 and n2 <= ncpu, name
+        if i < 7:   # (layer2[3], the hand-over block, runs unsplit with its fp16-plane output: same kernel, possibly another K-slice order)
+            assert torch.equal(taps2[i], taps6[i]), f"{name}: layer1 / layer2 run the same kernels either way"
+    assert_close(ls2, resnet50_ref.layer_stack_features(tsd, frags), "f16x2 layer-stack")
+    assert_close(pool2, resnet50_ref.pool_features(tsd, frags), "f16x2 pool")
+
+
+def test_resnet50_rows_do_not_depend_on_the_batch_under_f16x2(h2):
+    """Per-image scales from per-image maxima (integer atomic max: order-free): with the tail split off an image's features are the same
+    bits alone, among 5, and among 37 images."""
+    rn50_weights()
+    f = torch.from_numpy(_fragments(5, seed=4)).cuda()
+    big = f.repeat(8, 1, 1, 1)[:37]
+    h2.set_option("gemm_split_k", 0)
+    try:
+        ls1, p1 = h2.resnet50_features(f[2:3])
+        ls5, p5 = h2.resnet50_features(f)
+        ls37, p37 = h2.resnet50_features(big)
+    finally:
+        h2.set_option("gemm_split_k", 1)
+    assert torch.equal(ls1[0], ls5[2]) and torch.equal(ls5[2], ls37[2]) and torch.equal(ls37[2], ls37[32])
+    assert torch.equal(p1[0], p5[2]) and torch.equal(p5[2], p37[2]) and torch.equal(p37[2], p37[32])
