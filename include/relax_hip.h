@@ -65,7 +65,14 @@ const char* relax_last_error(const relax_handle* h);
  * backbone entry points; call it up front to keep allocation out of timed code. */
 int relax_reserve(relax_handle* h, int max_images);
 
-/* Integer options.  "gemm_precision": 0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 2 = "bf16x6" (fp32-grade):
+/* Integer options.  "gemm_precision": 3 (default) = "f16x2" (fp32-grade): every fp32 operand is held as two fp16 numbers of a
+ * power-of-two multiple of itself, x * s = hi + lo (22 bits), and a*b = ah*bh + ah*bl + al*bh on v_mfma_f32_16x16x32_f16 with fp32
+ * accumulation (al*bl, 2^-22 of the product, is added for K < 256 only); every scale comes from a bound, never from the data of a
+ * batch - weights per output row, ViT activations one static power of two per tensor, ResNet-50 activations one per image from
+ * Hoelder's inequality on the measured per-image maxima of the producer's inputs - so nothing can overflow and no row depends on its
+ * batch (csrc/gemm_h2.hip, csrc/h2.h, tests/test_gpu_h2.py).  It covers the plain GEMMs with N % 256 == 0 (the whole ViT-B/16;
+ * relax_op_gemm) and the convolutions of ResNet-50's layer3 / layer4 (relax_op_conv2d_nhwc with Cin % 32 == 0, Cout % 256 == 0);
+ * everything else runs as under 2.  0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 2 = "bf16x6" (fp32-grade):
  * every fp32 operand is held as three bf16 numbers hi + mid + lo (exact) and a*b = the six partial products of weight
  * >= 2^-16 on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, two products per instruction; 32x32x16 on the 64 / 128-column
  * tiles) with fp32 accumulation - as close to the exact sum as the fp32 FMA chain
@@ -80,6 +87,9 @@ int relax_reserve(relax_handle* h, int max_images);
  * (0 = by workspace size).  "x6_fp32_rows" (default 1): bf16x6 contractions onto 64 / 128 output columns read fp32 activation rows and
  * split them in the K loop, and the ResNet-50 block outputs inside layer1 / layer2 travel as fp32 (4 bytes per value instead of 6);
  * 0 = split planes everywhere: the same bits, more bytes (kept as the A/B switch of tests/test_gpu_x6.py).
+ * "h2_form" (default 1): 1 = the f16x2 loop with 32-deep K steps and three products for K >= 256; 0 = 16-deep steps, four products
+ * ("h2_stages" = 3 or 4 LDS stages, same bits); 2 = 32-deep steps, four products at every K.  "rn_h2" (default 1): under
+ * "gemm_precision" 3 ResNet-50's layer3 / layer4 run f16x2; 0 = the whole network on bf16x6 (the A/B switch of tests/test_gpu_h2.py).
  * "debug_poison" (test mode, default 0): every workspace request fills the buffer with 0xFF bytes
  * first (synchronously), so a read of workspace that was not written in the same call shows up in the results. */
 int relax_set_option(relax_handle* h, const char* key, int value);
@@ -197,8 +207,9 @@ int relax_mlp_head(relax_handle* h, const float* features, int n, float* scores,
 /* ---- operator level (what the backbones are built from; parity-tested one by one) ------------ */
 /* out[M,N] = act(A[M,K] * W[N,K]^T + bias[N] + residual[M,N]);  act: 0 none, 1 relu, 2 gelu(erf).
  * fp32 in, fp32 MFMA accumulate.  K % 32 == 0 (bf16x6: K % 16 == 0), N % 64 == 0.  bias/residual may be NULL; every pointer
- * 16-byte aligned.  These operator-level entry points are test / bench paths: under "gemm_precision" 2 (default) the
- * operands are converted to split planes on every call (two extra kernels, (M+N)*K*6 bytes; the model drivers keep weights
+ * 16-byte aligned.  These operator-level entry points are test / bench paths: under "gemm_precision" 3 (default; N % 256 == 0)
+ * both operands are converted to fp16 planes on every call, each row with the power-of-two scale of its own maximum; under 2 (and under
+ * 3 for the other shapes) the operands are converted to split planes on every call (two extra kernels, (M+N)*K*6 bytes; the model drivers keep weights
  * and activations in that format instead; where N % 256 != 0 only W is converted: the 64 / 128-column form of the kernel
  * splits the fp32 rows of A in its K loop, as ResNet-50's layer1 / layer2 do), into a workspace the handle owns - like every entry point they must not run
  * concurrently on two streams of one handle.  Finite operands up to 3.38e38 (csrc/sp3.h); beyond: "gemm_precision" 0. */
@@ -242,7 +253,7 @@ int relax_segment_mean(relax_handle* h, const float* src, int64_t src_stride, in
  * kernel is bracketed by HIP events on the caller's stream.  relax_profile_read synchronises those events and
  * returns totals since the last enable: kind 0 = fp32 / bf16x3 contraction launches (work = algorithmic FLOPs), kind 1 =
  * patch score (work = bytes), kind 2 = kind 0 again with work = algorithmic HBM bytes (operands and results touched once),
- * kind 3 / 4 = the same two views of the bf16x6 contraction launches, kind 5 = flow_iteration, the dominant kernel of the
+ * kind 3 / 4 = the same two views of the bf16x6 contraction launches, kind 7 / 8 = those of the f16x2 launches, kind 5 = flow_iteration, the dominant kernel of the
  * Farneback stage (one launch per iteration; work = algorithmic bytes: 56 per pixel, level and iteration), kind 6 = the whole
  * Farneback stage of a relax_optical_flow chunk, first launch to last (work = the algorithmic bytes of all its kernels: every
  * kernel's inputs read once and outputs written once; launches = chunks). */

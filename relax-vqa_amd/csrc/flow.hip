@@ -18,6 +18,8 @@
 #include <cfloat>
 #include <cmath>
 
+#include <atomic>
+
 #include "relax_internal.h"
 
 // This file is compiled with -ffp-contract=off (Makefile): a * b + c is a multiply and an add, as in the oracle and in OpenCV's scalar code,
@@ -1330,11 +1332,13 @@ static int flow_segment_rows(const relax_handle* h, int bands, int hh) {
 template <bool UP, bool MINMAX>
 static int launch_flow_iteration(relax_handle* h, const float* R, const float* flow_in, float* flow_out, int hh, int w, int P, const FlowUp& up,
                                  unsigned* mm, hipStream_t s) {
-    static bool attr_set[kMaxDevices] = {};   // per (instantiation, device)
-    if (!attr_set[h->device]) {
+    // per (instantiation, device); atomic: two handles of one device may launch from two threads (the call is idempotent, so the worst
+    // a lost race does is set the attribute twice)
+    static std::atomic<bool> attr_set[kMaxDevices];
+    if (!attr_set[h->device].load(std::memory_order_acquire)) {
         RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_iteration<UP, MINMAX>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)IT_LDS));
-        attr_set[h->device] = true;
+        attr_set[h->device].store(true, std::memory_order_release);
     }
     const int bands = (w + IT_OUT - 1) / IT_OUT;
     const int seg = flow_segment_rows(h, bands, hh);

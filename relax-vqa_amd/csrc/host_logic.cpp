@@ -222,5 +222,13 @@ void relax_host_tail_split(int ntiles, int slots, int nk, int min_steps, int can
     if (nsplit) *nsplit = r.nsplit;
 }
 
+// the f16x2 scale helpers (csrc/h2.h): scales[rows], and the two bounds
+void relax_host_h2_weight_row_scales(const float* w, int rows, int k, float* scale) { relax::host::h2_weight_row_scales(w, rows, k, scale); }
+float relax_host_h2_scale_for_bound(double amax) { return relax::host::h2_scale_for_bound(amax); }
+double relax_host_layernorm_out_bound(const float* gamma, const float* beta, int dim) { return relax::host::layernorm_out_bound(gamma, beta, dim); }
+double relax_host_linear_of_layernorm_bound(const float* w, const float* b, const float* gamma, const float* beta, int dim, int n0, int n1) {
+    return relax::host::linear_of_layernorm_bound(w, b, gamma, beta, dim, n0, n1);
+}
+
 }  // extern "C"
 #endif  // RELAX_HOST_TEST_API

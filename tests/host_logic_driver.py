@@ -149,3 +149,41 @@ lib.relax_host_tail_split(0, 256, 48, 8, 1, C.byref(ft), C.byref(ns))
 assert (ft.value, ns.value) == (0, 1)
 print("tail split-K model ok")
 print("HOST_LOGIC_SANITIZED_OK")
+
+
+# ---- the f16x2 scale helpers: powers of two, and bounds that BOUND (LayerNorm rows of any shape, Linear behind LayerNorm) ------------------
+lib.relax_host_h2_scale_for_bound.restype = C.c_float
+lib.relax_host_h2_scale_for_bound.argtypes = [C.c_double]
+lib.relax_host_layernorm_out_bound.restype = C.c_double
+lib.relax_host_linear_of_layernorm_bound.restype = C.c_double
+for amax in (1e-30, 3e-5, 0.7, 1.0, 27.7, 65504.0, 1e30):
+    sc = lib.relax_host_h2_scale_for_bound(amax)
+    assert sc > 0 and np.log2(sc) == np.round(np.log2(sc)) and 2.0 ** 14 <= amax * sc < 2.0 ** 15 or amax in (1e-30, 1e30), (amax, sc)
+for bad in (0.0, -1.0, float("inf"), float("nan")):
+    assert lib.relax_host_h2_scale_for_bound(bad) == 1.0
+rng = np.random.default_rng(3)
+dim, nout = 192, 40
+W = (rng.standard_normal((nout, dim)) * 0.3).astype(np.float32)
+W[5] = 0
+bias = rng.standard_normal(nout).astype(np.float32)
+gamma = (rng.standard_normal(dim) * 2).astype(np.float32)
+beta = rng.standard_normal(dim).astype(np.float32)
+scales = np.zeros(nout, np.float32)
+lib.relax_host_h2_weight_row_scales(W.ctypes.data_as(C.c_void_p), nout, dim, scales.ctypes.data_as(C.c_void_p))
+rowmax = np.abs(W).max(axis=1)
+assert scales[5] == 1.0 and all(2.0 ** 14 <= rowmax[n] * scales[n] < 2.0 ** 15 for n in range(nout) if n != 5)
+ln_bound = lib.relax_host_layernorm_out_bound(gamma.ctypes.data_as(C.c_void_p), beta.ctypes.data_as(C.c_void_p), dim)
+lin_bound = lib.relax_host_linear_of_layernorm_bound(W.ctypes.data_as(C.c_void_p), bias.ctypes.data_as(C.c_void_p), gamma.ctypes.data_as(C.c_void_p),
+                                                     beta.ctypes.data_as(C.c_void_p), dim, 8, nout)
+worst_ln = worst_lin = 0.0
+top = int(np.argmax(np.abs(gamma) * np.sqrt(dim - 1) + np.abs(beta)))      # the channel whose one-hot row attains the LayerNorm bound
+rows = [rng.standard_normal(dim) * s + o for s, o in ((1, 0), (1e-3, 50), (100, -7))] + [np.eye(dim)[top] * 1e4, np.eye(dim)[top] * -1e4,
+                                                                                           np.eye(dim)[3] * -5 + 1e-4 * rng.standard_normal(dim)]
+for x in rows:
+    z = (x - x.mean()) / np.sqrt(x.var() + 1e-6)
+    y = z * gamma.astype(np.float64) + beta.astype(np.float64)
+    worst_ln = max(worst_ln, np.abs(y).max())
+    worst_lin = max(worst_lin, np.abs(W[8:].astype(np.float64) @ y + bias[8:]).max())
+assert worst_ln <= ln_bound and worst_lin <= lin_bound, (worst_ln, ln_bound, worst_lin, lin_bound)
+assert worst_ln > 0.5 * ln_bound          # (the one-hot row nearly attains the LayerNorm bound: it is tight, not merely safe)
+print("f16x2 bound helpers ok: LayerNorm", worst_ln, "<=", ln_bound, " Linear", worst_lin, "<=", lin_bound)
