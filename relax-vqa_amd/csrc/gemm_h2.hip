@@ -502,7 +502,9 @@ __global__ __launch_bounds__(512, 2) void gemm_h2(const H2Params p) {
 constexpr int H3_STAGE = (H2_BM + H2_BN) * 128;   // 64 KB
 constexpr int H3_NSTG = 2;
 
-template <bool FOUR, bool TAPS = false>
+// PERIMG: the per-image features of the convolution launches (per-image scales, plane residual, fused means, maxima, out_rows): the
+// plain GEMMs of the ViT keep the lean epilogue
+template <bool FOUR, bool TAPS = false, bool PERIMG = false>
 __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (no __amdgpu_buffer_rsrc_t there)
     constexpr int BM = H2_BM, BN = H2_BN, STAGE = H3_STAGE, NSTG = H3_NSTG, IMG = STAGE / 2;
@@ -676,6 +678,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     // region k: [wait for step k+1 (every piece of this wave: two stages), barrier, B forms and A fragment 0 of step k+1, piece 0 of step
     // k+2 into the stage step k has left, MFMAs of fragment 7 of step k, then fragments 0..6 of step k+1 each behind the read of the next
     // one and one more piece]; xs_ = k & 1 = the register set of B = the LDS stage of step k.
+    // the order the eight pieces of a step are issued in: activation and weight pieces interleaved (A, A, W, W of the hi planes, then of
+    // the lo planes).  Measured, cycles per 16 k of the qkv / fc2 loops: this order 1767 / 1956, all four activation pieces first 1836 /
+    // 2070, all four weight pieces first 1943 / 2116 (profiles/r05_h3_group_m_and_dma_placement.txt)
+#define H3_ORDER(i_) (i_)
 #define H3_REGION(xs_, has_next_, has_d_)                                                                               \
     {                                                                                                                   \
         const char* sn_ = smem + ((xs_) ^ 1) * STAGE;                                                                   \
@@ -684,13 +690,13 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
             __builtin_amdgcn_s_barrier();                                                                               \
             H3_READ_XB((xs_) ^ 1, sn_);                                                                                 \
             H3_READ_A(0, 0, sn_);                                                                                       \
-            if (has_d_) H3_ISSUE_PIECE(xs_, 0);                                                                         \
+            if (has_d_) H3_ISSUE_PIECE(xs_, H3_ORDER(0));                                                               \
         }                                                                                                               \
         H3_MFMAS(xs_, 1, 7);                                                                                            \
         if (has_next_) {                                                                                                \
             _Pragma("unroll") for (int e = 0; e < 7; ++e) {                                                             \
                 H3_READ_A((e + 1) & 1, e + 1, sn_);                                                                     \
-                if (has_d_) H3_ISSUE_PIECE(xs_, e + 1);                                                                 \
+                if (has_d_) H3_ISSUE_PIECE(xs_, H3_ORDER(e + 1));                                                       \
                 H3_MFMAS((xs_) ^ 1, e & 1, e);                                                                          \
             }                                                                                                           \
             if (has_d_) H3_ISSUE_ADVANCE();                                                                             \
@@ -733,6 +739,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
         }
     }
 #undef H3_REGION
+#undef H3_ORDER
 #undef H3_MFMAS
 #undef H3_READ_A
 #undef H3_READ_XB
@@ -752,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     static_assert(EP_ROWS * LDC * 4 <= NSTG * STAGE, "epilogue pass must fit the staging LDS");
     constexpr int EP_STEP = NT / C8;
     constexpr int EP_ITERS = EP_ROWS / EP_STEP;
-    const bool planes = p.out_h2 != nullptr || p.residual_h2 != nullptr;   // workgroup-uniform
+    const bool planes = p.out_h2 != nullptr || (PERIMG && p.residual_h2 != nullptr);   // workgroup-uniform
     const int lcA = planes ? (tid % C8) * 8 : (tid % C8) * 4;
     const int lcB = planes ? lcA + 4 : lcA + BN / 2;
     const int lr0 = tid / C8;
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     // per-image maxima of this tile, behind the staging area (which takes the first EP_ROWS * LDC * 4 = 66.5 KB of the stages)
     unsigned* simg = reinterpret_cast<unsigned*>(smem + 96 * 1024);
     const int img_first = p.rows_per_img > 0 ? m0 / p.rows_per_img : 0;
-    const bool lds_amax = p.amax_out && slice < 0 && p.rows_per_img >= 18;   // at most 16 images under the tile's 256 rows
+    const bool lds_amax = PERIMG && p.amax_out && slice < 0 && p.rows_per_img >= 18;   // at most 16 images under the tile's 256 rows
     if (lds_amax && tid < 16) simg[tid] = 0u;   // (ordered before the first use by the barrier of the first pass)
 #pragma unroll
     for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
@@ -793,12 +800,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                     rb[it] = *reinterpret_cast<const f32x4*>(r + lcB);
                 }
                 if (p.rowscale) rs[it] = p.rowscale[m];
-                if (p.rows_per_img > 0) {   // per-image scales: the row's image
+                if (PERIMG && p.rows_per_img > 0) {   // per-image scales: the row's image
                     im[it] = m / p.rows_per_img;
                     if (p.img_in_inv) rs[it] = p.img_in_inv[im[it]];
                     if (p.img_out_scale) os[it] = p.img_out_scale[im[it]];
                 }
-                if (p.residual_h2) {   // the residual as fp16 planes: (hi + lo) / scale is the stored 22-bit value, exactly (planes: lcB = lcA + 4)
+                if (PERIMG && p.residual_h2) {   // the residual as fp16 planes: (hi + lo) / scale is the stored 22-bit value, exactly (planes: lcB = lcA + 4)
                     const char* r = p.residual_h2 + (int64_t)m * ((int64_t)p.N * 4) + h2_offset(n0 + lcA);
                     const h2_u32x4 hi = *reinterpret_cast<const h2_u32x4*>(r), lo = *reinterpret_cast<const h2_u32x4*>(r + 32);
                     const float ri = p.img_res_inv[im[it]];
@@ -841,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
             // powers of two: exact.  Then (acc + bias) + residual, the same order on every path
             va = va * (cs_a * rs[it]) + bias_a;
             vb = vb * (cs_b * rs[it]) + bias_b;
-            if (p.residual || p.residual_h2) {
+            if (p.residual || (PERIMG && p.residual_h2)) {
                 va += ra[it];
                 vb += rb[it];
             }
@@ -853,16 +860,16 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                 vb = gelu_erf4(vb);
             }
             const int64_t o = (int64_t)m * p.N + n0;
-            if (p.out && m < p.out_rows) {
+            if (p.out && (!PERIMG || m < p.out_rows)) {
                 *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
                 *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
             }
-            if (p.gap) {   // the finished values go back to the staging rows for the group sums below
+            if (PERIMG && p.gap) {   // the finished values go back to the staging rows for the group sums below
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcA) = va;
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcB) = vb;
             }
             if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, os[it]);   // (planes: lcB = lcA + 4)
-            if (p.amax_out) {
+            if (PERIMG && p.amax_out) {
                 // the largest output of this row segment (outputs are >= 0: these launches end in a ReLU), over the 32 lanes that share
                 // the row, into the image's slot: integer max of the bits = float max, order-free, so the maximum - and every scale
                 // derived from it - is the same whatever batch the image travels in.  Collected per tile in LDS first (a tile spans a few
@@ -876,7 +883,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                 }
             }
         }
-        if (p.gap && slice < 0) {
+        if (PERIMG && p.gap && slice < 0) {
             // fused spatial mean, stage 1: sums over the aligned 4-row groups of this pass, rows added in order.  Images start at multiples
             // of 4 rows (the launcher checks Ho*Wo % 4 == 0): a group never spans two images and the grouping - hence every bit - does
             // not depend on where in the batch an image sits.  gap_groups_finish (layers.hip) adds an image's group sums in order.
@@ -976,7 +983,7 @@ __global__ __launch_bounds__(256) void splitk_finish_h2(const H2Params p) {
 }
 
 // FORM 0: gemm_h2<3>, 1: gemm_h2<4> (16-k steps, four products), 2: gemm_h3<false> (32-k steps, three products), 3: gemm_h3<true> (four),
-// 4: gemm_h3<false, true> (three products, implicit-GEMM taps)
+// 4: gemm_h3<false, true, true> (three products, implicit-GEMM taps, per-image epilogue), 5: gemm_h3<false, false, true> (1x1 convolutions)
 template <int FORM>
 static int launch_h2_variant(relax_handle* h, H2Params& p, hipStream_t s) {
     constexpr int BM = H2_BM, BN = H2_BN;
@@ -1003,7 +1010,8 @@ static int launch_h2_variant(relax_handle* h, H2Params& p, hipStream_t s) {
         else if constexpr (FORM == 1) return &gemm_h2<4>;
         else if constexpr (FORM == 2) return &gemm_h3<false>;
         else if constexpr (FORM == 3) return &gemm_h3<true>;
-        else return &gemm_h3<false, true>;
+        else if constexpr (FORM == 4) return &gemm_h3<false, true, true>;
+        else return &gemm_h3<false, false, true>;
     }();
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
@@ -1042,6 +1050,8 @@ int launch_gemm_h2(relax_handle* h, const GemmDescH2& d, hipStream_t s) {
     RELAX_REQUIRE(h, !(d.residual && d.residual_h2) && (!d.residual_h2 || (d.img_res_inv && d.rows_per_img > 0)), "f16x2 gemm: bad residual");
     RELAX_REQUIRE(h, !d.gap_groups || (d.rows_per_img > 0 && d.rows_per_img % 4 == 0), "f16x2 conv: the fused spatial mean needs Ho*Wo %% 4 == 0");
     RELAX_REQUIRE(h, d.rows_per_img > 0 || (!d.img_in_inv && !d.img_out_scale && !d.amax_out), "f16x2 gemm: per-image tables need rows_per_img");
+    RELAX_REQUIRE(h, conv || (d.rows_per_img == 0 && !d.residual_h2 && !d.gap_groups && d.out_rows == 0),
+                  "f16x2 gemm: per-image scales, plane residuals, fused means and out_rows belong to the convolution form");
     RELAX_REQUIRE(h, p.M > 0 && p.N > 0 && p.K > 0, "f16x2 gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     RELAX_REQUIRE(h, p.K % 16 == 0 && p.N % 256 == 0, "f16x2 gemm: K=%d must be a multiple of 16 and N=%d of 256", p.K, p.N);
     RELAX_REQUIRE(h, (int64_t)p.K * 4 * 256 < kH2MaxRecords, "f16x2 gemm: K=%d too large", p.K);
@@ -1062,7 +1072,7 @@ int launch_gemm_h2(relax_handle* h, const GemmDescH2& d, hipStream_t s) {
     int rc;
     if (conv) {
         RELAX_REQUIRE(h, p.K % 32 == 0, "f16x2 conv: K=%d must be a multiple of 32", p.K);
-        rc = taps ? launch_h2_variant<4>(h, p, s) : launch_h2_variant<2>(h, p, s);
+        rc = taps ? launch_h2_variant<4>(h, p, s) : launch_h2_variant<5>(h, p, s);
     } else if (h->gemm.h2_form == 0 || p.K % 32 != 0) rc = h->gemm.h2_stages == 4 ? launch_h2_variant<1>(h, p, s) : launch_h2_variant<0>(h, p, s);
     else if (h->gemm.h2_form == 2 || p.K < 256) rc = launch_h2_variant<3>(h, p, s);
     else rc = launch_h2_variant<2>(h, p, s);

@@ -1,5 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-(for o in rn_h2=0 rn_h2=1 rn_h2=0 rn_h2=1; do RELAX_OPTS=$o timeout 300 python tools/resnet_step.py 1024 5 both; done) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05_resnet_step.txt
-timeout 900 python -m pytest tests/test_gpu_h2.py tests/test_gpu_x6.py tests/test_gpu_backbones.py -x -q 2>&1 | tail -3
+tools/build_ablations.sh h2stamps > /dev/null 2>&1
+RELAX_HIP_LIB=tools/abl/librelax_h2stamps.so timeout 300 python tools/vit_step.py f16x2 1024 1 2>&1 | grep "^h2 " | python3 tools/stamp_lines.py | tee gpurun_out/r05_h2_stamps.txt
+for i in 1 2; do timeout 300 python tools/vit_step.py f16x2 1024 5; done 2>&1 | grep -v amdgpu
