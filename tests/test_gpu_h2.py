@@ -345,3 +345,29 @@ def test_resnet50_rows_do_not_depend_on_the_batch_under_f16x2(h2):
         h2.set_option("gemm_split_k", 1)
     assert torch.equal(ls1[0], ls5[2]) and torch.equal(ls5[2], ls37[2]) and torch.equal(ls37[2], ls37[32])
     assert torch.equal(p1[0], p5[2]) and torch.equal(p5[2], p37[2]) and torch.equal(p37[2], p37[32])
+
+
+def test_resnet50_extreme_images_under_f16x2():
+    """All-black, all-white and checkerboard fragments (the per-image maxima at their extremes: a black image's layer3 input is whatever the
+    biases leave, possibly zero everywhere): finite features inside the bar against the oracle, printed beside bf16x6."""
+    sd = rn50_weights()
+    eng = engine()
+    frags = np.zeros((4, 224, 224, 3), dtype=np.uint8)
+    frags[1] = 255
+    yy, xx = np.mgrid[0:224, 0:224]
+    frags[2] = (((yy // 16 + xx // 16) % 2) * 255)[:, :, None]
+    frags[3] = _fragments(1)[0]
+    f = torch.from_numpy(frags).cuda()
+    tsd = resnet50_ref.to_torch_state_dict(sd)
+    want_ls = resnet50_ref.layer_stack_features(tsd, frags)
+    want_pool = resnet50_ref.pool_features(tsd, frags)
+    eng.set_precision("f16x2")
+    ls2, pool2 = eng.resnet50_features(f)
+    assert torch.isfinite(ls2).all() and torch.isfinite(pool2).all()
+    assert_close(ls2, want_ls, "extreme images, layer stack (f16x2)")
+    assert_close(pool2, want_pool, "extreme images, pool (f16x2)")
+    eng.set_precision("bf16x6")
+    ls6, pool6 = eng.resnet50_features(f)
+    d2 = np.abs(ls2.cpu().numpy().astype(np.float64) - want_ls).max(axis=1)
+    d6 = np.abs(ls6.cpu().numpy().astype(np.float64) - want_ls).max(axis=1)
+    print(f"\nextreme images: max |layer stack - oracle| per image: f16x2 {d2}  bf16x6 {d6}")

@@ -9,7 +9,7 @@ TAG=$1
 O=$R/gpurun_out/pmc_stalls_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-run() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/$1 -- python3 $R/tools/vit_step.py bf16x6 1024 1 > $O/$1.log 2>&1; }
+run() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $O/$1 -- python3 $R/tools/vit_step.py ${PREC:-f16x2} 1024 1 > $O/$1.log 2>&1; }
 run sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_LDS_DATA_FIFO_FULL GRBM_GUI_ACTIVE"
 run ta "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_READ_LDS_WAVEFRONTS_sum GRBM_GUI_ACTIVE"
 run tcp "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum GRBM_GUI_ACTIVE"
