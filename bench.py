@@ -405,18 +405,24 @@ def main():
 
     # metric (ii) of SURVEY §8(d): the same steps with every clip copied from pinned host memory on a side stream
     h2d = None
-    if world == 1 and not args.no_h2d and not full:
+    if not args.no_h2d and not full:      # (at every N: each rank feeds its own GPU from its own pinned clips, the all-gather stays in the step)
         from relax_vqa_amd.feeder import PinnedClipFeeder
         host_clips = [c.cpu().pin_memory() for c in clips]
         feeder = PinnedClipFeeder([host_clips[j % n_resident] for j in range(B)], B, eng.device)
-        run = lambda batch: eng.clip_vectors(batch, resnet=True, vit=use_vit)   # noqa: E731
+
+        def run(batch):
+            vecs = eng.clip_vectors(batch, resnet=True, vit=use_vit)
+            return rdist.gather_clip_vectors(vecs, world * B, rank, world) if world > 1 else vecs
+
         feeder.run(2, run)
         barrier()
         t2 = time.perf_counter()
         feeder.run(args.steps, run)     # `steps` copies and `steps` compute passes inside the clock: the first copy has nothing to hide under
         barrier()
         e2 = time.perf_counter() - t2
-        h2d = {"value": args.steps * B / e2, "unit": "clips/s", "ms_per_step": e2 / args.steps * 1e3,
+        if world > 1:
+            e2 = rdist.all_reduce_max(e2, "cuda")
+        h2d = {"value": args.steps * world * B / e2, "unit": "clips/s", "ms_per_step": e2 / args.steps * 1e3,
                "note": "every clip copied pinned host -> device on a side stream, double-buffered under the compute; all `steps` copies are "
                        "inside the timed region (the first one is exposed, the others hide under the previous step)"}
         del feeder, host_clips

@@ -1,6 +1,4 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-mkdir -p gpurun_out
-tools/build_ablations.sh h2stamps > /dev/null 2>&1
-RELAX_HIP_LIB=tools/abl/librelax_h2stamps.so timeout 300 python tools/vit_step.py f16x2 1024 1 2>&1 | grep "^h2 " | python3 tools/stamp_lines.py | tee gpurun_out/r05_h2_stamps.txt
-for i in 1 2; do timeout 300 python tools/vit_step.py f16x2 1024 5; done 2>&1 | grep -v amdgpu
+export RELAX_DIST_BACKEND=gloo
+timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 2>&1 | tail -5
