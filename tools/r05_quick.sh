@@ -1,4 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-export RELAX_DIST_BACKEND=gloo
-timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 2>&1 | tail -5
+for i in 1 2; do
+RELAX_HIP_LIB=tools/librelax_base.so timeout 300 python tools/vit_step.py f16x2 1024 5 2>&1 | grep -v amdgpu.ids | sed 's/^/base: /'
+timeout 300 python tools/vit_step.py f16x2 1024 5 2>&1 | grep -v amdgpu.ids | sed 's/^/new:  /'
+done
+timeout 900 python -m pytest tests/test_gpu_h2.py -x -q 2>&1 | tail -3
