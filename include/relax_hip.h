@@ -90,6 +90,7 @@ int relax_reserve(relax_handle* h, int max_images);
  * "h2_form" (default 1): 1 = the f16x2 loop with 32-deep K steps and three products for K >= 256; 0 = 16-deep steps, four products
  * ("h2_stages" = 3 or 4 LDS stages, same bits); 2 = 32-deep steps, four products at every K.  "rn_h2" (default 1): under
  * "gemm_precision" 3 ResNet-50's layer3 / layer4 run f16x2; 0 = the whole network on bf16x6 (the A/B switch of tests/test_gpu_h2.py).
+ * "rn_h2_early" (default 1): with "rn_h2", the 3x3 convolutions of layer1 / layer2 run f16x2 as well (four-wave tiles); 0 = bf16x6 there.
  * "debug_poison" (test mode, default 0): every workspace request fills the buffer with 0xFF bytes
  * first (synchronously), so a read of workspace that was not written in the same call shows up in the results. */
 int relax_set_option(relax_handle* h, const char* key, int value);

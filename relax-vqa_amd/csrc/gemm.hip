@@ -714,6 +714,28 @@ int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const
         g.rows_per_img = d.Ho * d.Wo; g.img_in_inv = inv;
         return launch_gemm_h2(h, g, s);
     }
+    if (h->gemm.precision == 3 && h->gemm.rn_h2_early && Cin % 16 == 0 && d.Kpad == KH * KW * Cin && KH * KW > 1 && KH * KW <= 32 && Cout % 64 == 0 &&
+        Cout % 256 != 0 && d.Kpad >= 256) {
+        // ... and the geometries of the 3x3 convolutions of layer1 / layer2: the four-wave f16x2 form of gemm_x6.hip, same conversions
+        const size_t a_bytes = (size_t)Nimg * H * W * Cin * 4, w_bytes = (size_t)Cout * d.Kpad * 4;
+        const size_t a_al = (a_bytes + 255) & ~(size_t)255, w_al = (w_bytes + 255) & ~(size_t)255, i_al = ((size_t)Nimg * 4 + 255) & ~(size_t)255;
+        RELAX_TRY(ensure_buf(h, h->sp3_ws, a_al + w_al + 3 * i_al + (size_t)Cout * 4 + 256));
+        char* As = static_cast<char*>(h->sp3_ws.p);
+        char* Ws = As + a_al;
+        unsigned* amax = reinterpret_cast<unsigned*>(Ws + w_al);
+        float* sc = reinterpret_cast<float*>(Ws + w_al + i_al);
+        float* inv = reinterpret_cast<float*>(Ws + w_al + 2 * i_al);
+        float* cs = reinterpret_cast<float*>(Ws + w_al + 3 * i_al);
+        RELAX_TRY(launch_image_absmax(h, in, (int64_t)H * W * Cin, Nimg, amax, s));
+        RELAX_TRY(launch_h2_image_scales(h, amax, 1.f, nullptr, 0.f, nullptr, 0.f, sc, inv, Nimg, s));
+        RELAX_TRY(launch_to_h2(h, in, Cin, As, (int64_t)Nimg * H * W, Cin, 1.f, sc, s, H * W));
+        RELAX_TRY(launch_to_h2_rows(h, w, d.Kpad, Ws, Cout, d.Kpad, cs, s));
+        ConvDescX6 x{};
+        x.in = As; x.in_h2 = 1; x.colscale = cs; x.img_in_inv = inv; x.Nimg = Nimg; x.H = H; x.W = W; x.Cin = Cin; x.Ho = d.Ho; x.Wo = d.Wo;
+        x.KH = KH; x.KW = KW; x.stride = stride; x.pad = pad;
+        x.w = Ws; x.Cout = Cout; x.bias = bias; x.residual = residual; x.out = out; x.act = act;
+        return launch_conv_x6(h, x, s);
+    }
     // bf16x6 where the split-plane kernel takes the geometry (16-channel chunks, at most 32 taps, 64-column tiles); anything
     // else - e.g. a 7x7 filter, Cin = 8 - runs on the exact-fp32 kernel as it did before bf16x6 became the default
     if (h->gemm.precision >= 2 && Cin % 16 == 0 && d.Kpad == KH * KW * Cin && KH * KW <= 32 && Cout % 64 == 0 &&

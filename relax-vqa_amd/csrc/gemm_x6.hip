@@ -35,6 +35,11 @@
 //     the fragment read.  N = 64 / 128 means ONE column tile, so every activation is split exactly once either way; these launches
 //     wait on memory, and their operands (ResNet-50's widest tensors) cost 4 bytes per value instead of 6.  Same values, same
 //     products, same order as split planes: bit-identical results (tests/test_gpu_x6.py).
+//     H2 (the 3x3 convolutions of ResNet-50's layer1 / layer2 under f16x2): both operands as two fp16 planes (csrc/h2.h: 64 B per row
+//     and K step, LDS rows in the AF32 geometry: unit (half h, plane q) of row r in slot (2h + q) ^ ((r >> 2) & 3)), the three
+//     partial products al bh, ah bl, ah bh on v_mfma_f32_32x32x16_f16 (K >= 256: al bl is below the accumulator's rounding, as in
+//     gemm_h2.hip), half the matrix instructions and two thirds of the staged bytes of the sp3 form; the epilogue undoes the scales
+//     (weight row x image: powers of two).  These launches are the only MFMA-bound ones of the two layers.
 // Rows beyond M and the padding taps of an implicit-GEMM convolution use an out-of-range buffer offset, which the buffer unit
 // answers with zeros.  The last, partial round of tiles is split along K (splitk_finish_x6 adds the slices in a fixed order;
 // cost model: host_logic.cpp).  DUAL: a second activation source for the K steps past K1 (ResNet conv3 + downsample in one
@@ -66,6 +71,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // fp32 [rows][K] (row stride ld floats) -> sp3 [rows][K*6 bytes]; one thread per 8 values
@@ -103,6 +109,8 @@ struct X6Params {
     char* out_sp3;           // sp3 [M][N*6 B] or null
     char* out_h2;            // the outputs also as two fp16 planes [M][N*4 B], image i's rows scaled by img_out_scale[i] (csrc/h2.h), or null
     const float* img_out_scale;
+    const float* colscale;   // H2: [N] inverse weight-row scales
+    const float* img_in_inv; // H2: [images] inverse activation scales (image = row / (Ho*Wo))
     unsigned* amax_out;      // [images]: atomicMax of the bits of the (non-negative) outputs of each image, or null (image = row / (Ho*Wo))
     float* partial;          // split-K partial tiles
     int M, N, K;
@@ -142,7 +150,7 @@ constexpr int64_t kMaxRecords = 0x7ffffff0;
 // (the loop body is rotated: one "region" = barrier .. next barrier = M1(k) + M0(k+1) is one basic block, which the compiler's
 // scheduler interleaves better than any order pinned by hand)
 // X = the operand with fewer fragments per wave (double-buffered in registers), Y = the other one (two halves).
-template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (it has no __amdgpu_buffer_rsrc_t and emits no stub for a body that names it)
     constexpr int NW = WM * WN;
@@ -154,9 +162,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     constexpr int YT = SPLIT_B ? TN : TM;
     constexpr int YH = YT / 2;
     constexpr int ROWS = BM + BN;
-    constexpr int A_ROW = AF32 ? 64 : kChunkBytes;   // LDS bytes of one activation row of a stage (AF32: 16 fp32 values, split in registers)
+    constexpr int CH = H2 ? kH2ChunkBytes : kChunkBytes;   // bytes of one 16-deep K step of one operand row (two fp16 / three bf16 planes)
+    constexpr int NP = H2 ? 2 : 3;                         // planes
+    constexpr int A_ROW = AF32 ? 64 : CH;   // LDS bytes of one activation row of a stage (AF32: 16 fp32 values, split in registers)
     constexpr int A_BYTES = BM * A_ROW;
-    constexpr int STAGE = A_BYTES + BN * kChunkBytes;
+    constexpr int STAGE = A_BYTES + BN * CH;
     constexpr int PIECES = STAGE / 1024;             // 1 KiB DMA pieces per stage
     constexpr int A_PIECES = A_BYTES / 1024;
     constexpr int PPW = (PIECES + NW - 1) / NW;   // pieces per wave (a wave short of real pieces issues dummy ones)
@@ -167,6 +177,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     static_assert(!M16 || (TM == 4 && TN == 2 && PPW <= 7), "the 16x16x32 loop is written for 128 x 64 per wave");
     static_assert(!DUAL || !TAPS, "a second activation source goes with 1x1 contractions");
     static_assert(!AF32 || (!M16 && !TAPS && !DUAL), "fp32 activation rows: the plain-GEMM form of the four-wave tiles only");
+    static_assert(!H2 || (!M16 && !DUAL && !AF32), "fp16 planes: the four-wave tiles only (the 256 x 256 tile of f16x2 is gemm_h3)");
     static_assert(STAGE % 1024 == 0 && A_BYTES % 1024 == 0, "stage regions are whole DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -212,9 +223,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     // stage; lane l fills unit u = piece*64 + l = (tile row u/6, physical unit u%6); physical unit (plane q, half h')
     // holds logical half h = h' ^ bit3(row).  Pieces j < A_PPW belong to the activation rows, the rest to the weight rows.
     const bool pixels = TAPS || p.stride != 1;     // rows are output pixels of an NHWC image (else: plain matrix rows)
-    const int64_t row_bytes = (int64_t)p.K * 6;                       // weight rows
-    const int64_t arow_bytes = (int64_t)(DUAL ? p.K1 : p.K) * (AF32 ? 4 : 6);   // plain activation rows (DUAL: the first source's K1 values)
-    const int64_t pix_bytes = (int64_t)p.Cin * 6;
+    constexpr int VB = H2 ? 4 : 6;                                    // bytes per value of a row in planes
+    const int64_t row_bytes = (int64_t)p.K * VB;                      // weight rows
+    const int64_t arow_bytes = (int64_t)(DUAL ? p.K1 : p.K) * (AF32 ? 4 : VB);   // plain activation rows (DUAL: the first source's K1 values)
+    const int64_t pix_bytes = (int64_t)p.Cin * VB;
     const int img0 = (pixels || DUAL) ? m0 / (p.Ho * p.Wo) : 0;
     __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w, rsrc_a2;
     {
@@ -239,7 +251,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     for (int j = 0; j < PPW; ++j) {
         const int piece = wave + NW * j;
         int trow, unit_off;
-        if (AF32 && j < A_PPW) {
+        if (H2) {
+            // fp16 planes: 4 units per row as well, every row of the stage (activation rows, then weight rows); slot s of row r holds
+            // the unit v = s ^ ((r >> 2) & 3) = (half v >> 1, plane v & 1) of the chunk, i.e. source bytes plane * 32 + half * 16: a lane's hi
+            // and lo fragments sit where AF32 keeps the two fp32 units of its half (the same conflict-free reads)
+            const int u = piece * 64 + lane;
+            trow = u >> 2;
+            const int v = (u & 3) ^ ((trow >> 2) & 3);
+            unit_off = (v & 1) * 32 + (v >> 1) * 16;
+        } else if (AF32 && j < A_PPW) {
             // fp32 activation rows: 4 units of 16 bytes per row; unit q of row r sits in slot q ^ ((r >> 2) & 3), which makes the
             // two ds_read_b128 of a fragment (lanes = 32 consecutive rows at one q) bank-conflict free
             const int u = piece * 64 + lane;
@@ -308,9 +328,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
 
 #define X6_ISSUE_PIECE(st_, j_)                                                                                         \
     {                                                                                                                   \
-        const int lin_ = (TAPS ? d_tap * cin_chunks + d_cc : d_kt) * kChunkBytes;                                       \
+        const int lin_ = (TAPS ? d_tap * cin_chunks + d_cc : d_kt) * CH;                                                \
         const int lin_a_ = AF32 ? d_kt * 64 : lin_;                                                                     \
-        const int tapoff_ = TAPS ? (d_dy * p.W + d_dx) * (int)pix_bytes + d_cc * kChunkBytes : 0;                        \
+        const int tapoff_ = TAPS ? (d_dy * p.W + d_dx) * (int)pix_bytes + d_cc * CH : 0;                                 \
         const int piece_ = wave + NW * (j_);                                                                            \
         const int dst_ = piece_ < PIECES ? (st_) * STAGE + piece_ * 1024 : DUMMY;                                       \
         if ((j_) < A_PPW) {                                                                                             \
@@ -320,7 +340,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 X6_DMA(rsrc_a, dst_, ok_ ? voff[j_] + (unsigned)tapoff_ : kOutOfRange, 0);                              \
             } else if (DUAL && d_kt >= k1_chunks) {   /* workgroup-uniform: the steps past K1 read the second source */    \
                 const int jj_ = (j_) < A_PPW ? (j_) : 0;                                                                \
-                X6_DMA(rsrc_a2, dst_, voff2[jj_], lin_ - k1_chunks * kChunkBytes);                                      \
+                X6_DMA(rsrc_a2, dst_, voff2[jj_], lin_ - k1_chunks * CH);                                               \
             } else {                                                                                                    \
                 X6_DMA(rsrc_a, dst_, voff[j_], lin_a_);                                                                 \
             }                                                                                                           \
@@ -350,6 +370,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     }
 
     floatx16 acc[TM][TN];
+    // H2: the two small products (al bh, ah bl: 2^-11 of the sum) have an accumulator of their own, added once at the end - the main one is
+    // rounded once per 16-deep step instead of three times (its rounding is what the result's error consists of: measured against fp64,
+    // one accumulator 1.25 x the exact-fp32 kernel's error on these 3x3 geometries, two 0.8 x)
+    floatx16 accs[H2 ? TM : 1][H2 ? TN : 1];
+#pragma unroll
+    for (int i = 0; i < (H2 ? TM : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (H2 ? TN : 1); ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[i][j][r] = 0.f;
     floatx4 acc16[M16 ? 8 : 1][4];   // M16: 16-row A fragments x 16-column B fragments of the wave's 128 x 64
 #pragma unroll
     for (int i = 0; i < (M16 ? 8 : 1); ++i)
@@ -366,16 +396,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
 
     // fragment read offsets: lane (r, h) reads the unit of half h of row r; rows with bit 3 set hold the halves swapped
     const int r32 = lane & 31;
-    const int frag = r32 * kChunkBytes + ((((lane >> 5) ^ (r32 >> 3)) & 1) << 4);
-    const int a_off = (wm * TM * 32) * kChunkBytes + frag;
-    const int b_off = A_BYTES + (wn * TN * 32) * kChunkBytes + frag;
+    // (H2: the hi fragment of lane (r, h) = slot (2h) ^ ((r >> 2) & 3) of its 64-byte row, the lo fragment = slot (2h + 1) ^ ...: FLIP apart)
+    const int frag = H2 ? r32 * CH + ((((lane >> 5) * 2) ^ ((r32 >> 2) & 3)) << 4) : r32 * CH + ((((lane >> 5) ^ (r32 >> 3)) & 1) << 4);
+    const int a_off = (wm * TM * 32) * CH + frag;
+    const int b_off = A_BYTES + (wn * TN * 32) * CH + frag;
     // AF32: lane (r, h) reads the fp32 values k = 8h .. 8h+7 of row r as two 16-byte units and splits them into the three planes
     [[maybe_unused]] const int a32_0 = (wm * TM * 32 + r32) * 64 + ((((lane >> 5) * 2) ^ ((r32 >> 2) & 3)) << 4);
     [[maybe_unused]] const int a32_1 = (wm * TM * 32 + r32) * 64 + ((((lane >> 5) * 2 + 1) ^ ((r32 >> 2) & 3)) << 4);
     const int x_off = SPLIT_B ? a_off : b_off;
     const int y_off = SPLIT_B ? b_off : a_off;
 
-    bf16x8 xf[2][XT][3], yf0[YH][3], yf1[YH][3];   // [.][fragment][plane hi, mid, lo]
+    bf16x8 xf[2][XT][NP], yf0[YH][NP], yf1[YH][NP];   // [.][fragment][plane hi, mid, lo] (H2: the bits of 8 fp16, planes hi, lo)
+    // H2: the lo fragment sits in the neighbouring slot of the swizzled row: XOR 16 on the byte offset (slots 2h and 2h + 1 differ in bit 0,
+    // the row's swizzle is the same for both)
+#define X6_PLANE(off_, pl_) (H2 ? ((off_) ^ ((pl_) << 4)) : ((off_) + (pl_) * 32))
 #define X6_READ_A32(dst_, idx_, sp_)                                                                                    \
     {                                                                                                                   \
         const f32x4 v0_ = *reinterpret_cast<const f32x4*>((sp_) + a32_0 + (idx_) * 32 * 64);                            \
@@ -391,8 +425,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         if constexpr (AF32 && SPLIT_B) {                                                                                \
             X6_READ_A32(xf[set_][x], x, sp_);                                                                           \
         } else {                                                                                                        \
-            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                            \
-                xf[set_][x][pl] = *reinterpret_cast<const bf16x8*>((sp_) + x_off + x * 32 * kChunkBytes + pl * 32);     \
+            _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                                           \
+                xf[set_][x][pl] = *reinterpret_cast<const bf16x8*>((sp_) + X6_PLANE(x_off, pl) + x * 32 * CH);          \
         }                                                                                                               \
     }
 #define X6_READ_Y(yf_, half_, sp_)                                                                                      \
@@ -400,23 +434,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         if constexpr (AF32 && !SPLIT_B) {                                                                               \
             X6_READ_A32(yf_[y], (half_) * YH + y, sp_);                                                                 \
         } else {                                                                                                        \
-            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                            \
-                yf_[y][pl] = *reinterpret_cast<const bf16x8*>((sp_) + y_off + ((half_) * YH + y) * 32 * kChunkBytes + pl * 32); \
+            _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                                           \
+                yf_[y][pl] = *reinterpret_cast<const bf16x8*>((sp_) + X6_PLANE(y_off, pl) + ((half_) * YH + y) * 32 * CH);   \
         }                                                                                                               \
     }
     // the six partial products, smallest first: (A plane, B plane) = (lo,hi) (mid,mid) (hi,lo) (mid,hi) (hi,mid) (hi,hi);
     // product type outermost: XT*YH independent accumulators between two MFMAs on the same one
+    // H2: (lo,hi) (hi,lo) (hi,hi) on the fp16 instruction
+#define X6_MFMA1(a_, b_, c_)                                                                                            \
+    (H2 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_), __builtin_bit_cast(f16x8, b_), c_, 0, 0, 0) \
+        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0))
 #define X6_MFMAS(set_, yf_, half_)                                                                                      \
-    _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                                     \
-        const int pa = t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0;                                                         \
-        const int pb = t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0;                                                         \
+    _Pragma("unroll") for (int t = 0; t < (H2 ? 3 : 6); ++t) {                                                          \
+        const int pa = H2 ? (t == 0 ? 1 : 0) : t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0;                                 \
+        const int pb = H2 ? (t == 1 ? 1 : 0) : t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0;                                 \
         _Pragma("unroll") for (int x = 0; x < XT; ++x) _Pragma("unroll") for (int y = 0; y < YH; ++y) {                 \
-            if (SPLIT_B)                                                                                                \
-                acc[x][(half_) * YH + y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[set_][x][pa], yf_[y][pb],         \
-                                                                                   acc[x][(half_) * YH + y], 0, 0, 0);  \
+            if (H2 && t < 2) {                                                                                          \
+                if (SPLIT_B)                                                                                            \
+                    accs[H2 ? x : 0][H2 ? (half_) * YH + y : 0] =                                                       \
+                        X6_MFMA1(xf[set_][x][pa], yf_[y][pb], accs[H2 ? x : 0][H2 ? (half_) * YH + y : 0]);             \
+                else                                                                                                    \
+                    accs[H2 ? (half_) * YH + y : 0][H2 ? x : 0] =                                                       \
+                        X6_MFMA1(yf_[y][pa], xf[set_][x][pb], accs[H2 ? (half_) * YH + y : 0][H2 ? x : 0]);             \
+            } else if (SPLIT_B)                                                                                         \
+                acc[x][(half_) * YH + y] = X6_MFMA1(xf[set_][x][pa], yf_[y][pb], acc[x][(half_) * YH + y]);             \
             else                                                                                                        \
-                acc[(half_) * YH + y][x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf_[y][pa], xf[set_][x][pb],         \
-                                                                                   acc[(half_) * YH + y][x], 0, 0, 0);  \
+                acc[(half_) * YH + y][x] = X6_MFMA1(yf_[y][pa], xf[set_][x][pb], acc[(half_) * YH + y][x]);             \
         }                                                                                                               \
     }
     // One pipeline region = everything between two barriers: [wait, barrier, DMA of step k+2, reads of X and Y-half-0 of step
@@ -587,6 +630,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
 #undef X6_READ_XB
 #undef X6_REGION
 #undef X6_MFMAS
+#undef X6_MFMA1
+#undef X6_PLANE
 #undef X6_READ_X
 #undef X6_READ_A32
 #undef X6_READ_Y
@@ -594,6 +639,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
 #undef X6_ISSUE_PIECE
 #undef X6_ISSUE_ADVANCE
     X6_STAMP(2);
+    if (H2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += accs[H2 ? i : 0][H2 ? j : 0];
+    }
     __syncthreads();   // no DMA is in flight and every fragment is in registers: the stages become the epilogue staging
 
     // ---- epilogue, staged through LDS in 64-row chunks (C/D map of the 32x32 MFMA: col = lane & 31,
@@ -621,6 +672,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         bias_a = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcA);
         bias_b = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcB);
     }
+    [[maybe_unused]] f32x4 cs_a = zero4, cs_b = zero4;   // H2: the inverse weight-row scales of this thread's columns
+    if (H2) {
+        cs_a = *reinterpret_cast<const f32x4*>(p.colscale + n0 + lcA);
+        cs_b = *reinterpret_cast<const f32x4*>(p.colscale + n0 + lcB);
+    }
     const bool interior = m0 + BM <= p.M;   // workgroup-uniform
     // per-image maxima of this tile (amax_out), collected in LDS right behind the staging rows: one global atomic per image and tile (a
     // global atomic per row segment - 1.6 M per launch of layer2's conv3, hundreds per address - cost 1.7 ms of a 1.1 ms launch)
@@ -629,6 +685,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     const int img_first = p.amax_out ? m0 / (p.Ho * p.Wo) : 0;
     const bool lds_amax = p.amax_out && slice < 0 && p.Ho * p.Wo >= 18;   // at most 16 images under the tile's 256 rows
     if (lds_amax && tid < 16) simg[tid] = 0u;   // (ordered before the first use by the barrier of the first pass)
+    // images of at least BM rows (layer1 / layer2): a tile spans at most TWO images - a thread keeps one running maximum for each in
+    // registers and the workgroup reduces them once, after the last pass (no shuffles or LDS atomics per row segment)
+    const bool two_img = lds_amax && p.Ho * p.Wo >= BM;
+    float tmax0 = 0.f, tmax1 = 0.f;
 #pragma unroll
     for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
         if (pass > 0) __syncthreads();
@@ -709,6 +769,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 *reinterpret_cast<f32x4*>(o + lcB) = vb;
                 continue;
             }
+            if (H2) {   // powers of two: exact
+                const float rs = p.img_in_inv[m / (p.Ho * p.Wo)];
+                va = va * (cs_a * rs);
+                vb = vb * (cs_b * rs);
+            }
             va += bias_a;
             vb += bias_b;
             if (p.residual || p.residual_sp3) {   // (acc + bias) + residual: the same order on every path
@@ -733,10 +798,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                 if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, p.img_out_scale[img]);
                 if (p.amax_out) {   // outputs are >= 0 (ReLU): integer max of the bits = float max, order-free; per tile in LDS first
                     float mx = fmaxf(fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w)), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)));
+                    if (two_img) {
+                        if (img == img_first) tmax0 = fmaxf(tmax0, mx);
+                        else tmax1 = fmaxf(tmax1, mx);
+                    } else {
                     _Pragma("unroll") for (int o = C8 / 2; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
                     if ((tid % C8) == 0) {
                         if (lds_amax) atomicMax(simg + (img - img_first), __float_as_uint(mx));
                         else atomicMax(p.amax_out + img, __float_as_uint(mx));
+                    }
                     }
                 }
             }
@@ -773,6 +843,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
                     }
                 }
             }
+        }
+    }
+    if (two_img) {   // (workgroup-uniform)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            tmax0 = fmaxf(tmax0, __shfl_xor(tmax0, o));
+            tmax1 = fmaxf(tmax1, __shfl_xor(tmax1, o));
+        }
+        if (lane == 0) {
+            atomicMax(simg, __float_as_uint(tmax0));
+            atomicMax(simg + 1, __float_as_uint(tmax1));
         }
     }
     if (lds_amax) {
@@ -834,7 +915,7 @@ __global__ __launch_bounds__(256) void splitk_finish_x6(const X6Params p) {
     if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lc, va, vb);
 }
 
-template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false>
 static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr int WG_PER_CU = NT == 256 ? 2 : 1;
@@ -845,7 +926,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     p.partial = nullptr;
     // Tail split-K: the last, partial round of tiles is cut along K (cost model: host_logic.cpp, shared with gemm.hip);
     // splitk_finish_x6 knows neither the fused group sums nor a split-plane residual, so those launches run unsplit
-    const bool can_split = h->gemm.split_k && !p.gap && !p.residual_sp3 && !p.no_split && !p.out_h2 && !p.amax_out;
+    const bool can_split = h->gemm.split_k && !p.gap && !p.residual_sp3 && !p.no_split && !p.out_h2 && !p.amax_out && !H2;
     const host::TailSplit ts = host::choose_tail_split(p.ntiles, 256 * WG_PER_CU, p.K / 16, 8, can_split);
     p.full_tiles = ts.full_tiles;
     p.nsplit = ts.nsplit;
@@ -854,16 +935,17 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
         RELAX_TRY(ensure_buf(h, h->splitk_ws, need < (size_t)(64 << 20) ? (size_t)(64 << 20) : need));
         p.partial = static_cast<float*>(h->splitk_ws.p);
     }
-    constexpr size_t lds = ((M16 && !TAPS && !DUAL) ? 3 : 2) * (size_t)(BM * (AF32 ? 64 : kChunkBytes) + BN * kChunkBytes) + 1024;
+    constexpr int CH = H2 ? kH2ChunkBytes : kChunkBytes;
+    constexpr size_t lds = ((M16 && !TAPS && !DUAL) ? 3 : 2) * (size_t)(BM * (AF32 ? 64 : CH) + BN * CH) + 1024;
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32, H2>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[h->device] = true;
     }
     const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
     X6_STAMPS_BEFORE_LAUNCH(h, p, units);
-    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32>), dim3(units), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32, H2>), dim3(units), dim3(NT), lds, s, p);
     X6_STAMPS_AFTER_LAUNCH(BM, BN, h, p, units, s);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((splitk_finish_x6<BM, BN>), dim3(BM * BN / 8 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
@@ -878,6 +960,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     p.bias = d.bias; p.residual = d.residual; p.out = d.out; p.out_sp3 = static_cast<char*>(d.out_sp3);
     p.residual_sp3 = static_cast<const char*>(d.residual_sp3);
     p.out_h2 = static_cast<char*>(d.out_h2); p.img_out_scale = d.img_out_scale; p.amax_out = d.amax_out;
+    p.colscale = d.colscale; p.img_in_inv = d.img_in_inv;
     p.gap = d.gap_groups;
     p.M = d.Nimg * d.Ho * d.Wo;
     p.N = d.Cout;
@@ -896,6 +979,8 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, d.Cin % 16 == 0, "x6 conv/gemm: Cin=%d must be a multiple of 16", d.Cin);
     RELAX_REQUIRE(h, p.N % 64 == 0, "x6 conv/gemm: N=%d must be a multiple of 64", p.N);
     RELAX_REQUIRE(h, (int64_t)p.K * 6 * 256 < kMaxRecords, "x6 conv/gemm: K=%d too large", p.K);
+    RELAX_REQUIRE(h, !d.in_h2 || (d.colscale && d.img_in_inv && !d.in2 && !d.in_f32 && p.N % 256 != 0 && p.K >= 256 && taps),
+                  "x6 conv: fp16-plane operands go with a KxK convolution of 64 or 128 output columns, K >= 256, and need both scale tables");
     RELAX_REQUIRE(h, d.out || d.out_sp3 || d.gap_groups || d.out_h2, "x6 conv/gemm: no output requested");
     RELAX_REQUIRE(h, !(d.residual && d.residual_sp3), "x6 conv/gemm: two residuals");
     RELAX_REQUIRE(h, (!d.out_h2 || d.img_out_scale) && (!(d.out_h2 || d.amax_out) || d.act == 1),
@@ -915,14 +1000,19 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
                   "x6 conv/gemm: every operand pointer must be 16-byte aligned");
     const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)p.K;
     // algorithmic HBM bytes: activation in (6 B per value), weights, outputs (+ residual), each touched once
-    const double bytes = (d.in_f32 ? 4.0 : 6.0) * ((double)d.Nimg * d.H * d.W * d.Cin) + 6.0 * ((double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) +
+    const double bytes = ((d.in_f32 || d.in_h2) ? 4.0 : 6.0) * ((double)d.Nimg * d.H * d.W * d.Cin) +
+                         (d.in_h2 ? 4.0 : 6.0) * ((double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) +
                          (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.residual ? 4.0 : 0.0) + (d.residual_sp3 ? 6.0 : 0.0));
     int span;
-    RELAX_TRY(prof_begin(h, s, 2, flops, &span, bytes));
+    RELAX_TRY(prof_begin(h, s, d.in_h2 ? 5 : 2, flops, &span, bytes));   // (kind 5 = f16x2: three executed products per fp32 product)
     int rc;
     // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA); N = 128 / 64 layers: the same
     // loop on four waves, two workgroups per CU
-    if (d.in_f32)   // fp32 activation rows, split in the K loop (ResNet-50: the block outputs of layer1 / layer2 travel as fp32)
+    if (d.in_h2)    // two fp16 planes on both sides: the 3x3 convolutions of layer1 / layer2 under f16x2
+        // (N = 128 on EIGHT waves of 64 x 64: the second accumulator does not fit the 128 x 64 wave tile of the four-wave form)
+        rc = p.N % 128 == 0 ? launch_x6_variant<256, 128, 4, 2, true, false, false, false, true>(h, p, s)
+                            : launch_x6_variant<256, 64, 4, 1, true, false, false, false, true>(h, p, s);
+    else if (d.in_f32)   // fp32 activation rows, split in the K loop (ResNet-50: the block outputs of layer1 / layer2 travel as fp32)
         rc = p.N % 128 == 0 ? launch_x6_variant<256, 128, 2, 2, false, false, false, true>(h, p, s)
                             : launch_x6_variant<256, 64, 4, 1, false, false, false, true>(h, p, s);
     else if (d.in2)

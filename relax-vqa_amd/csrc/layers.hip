@@ -286,11 +286,11 @@ int launch_attention(relax_handle* h, const float* qkv, float* out, int Nimg, in
 template <bool SP3>   // SP3: the pooled map leaves as split planes (bf16 hi + mid + lo) for the bf16x6 convolutions of layer1
 __global__ __launch_bounds__(256) void bn_relu_maxpool_nhwc(const float* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, void* __restrict__ yv,
-                                                            int Nimg, int H, int W, int C) {
+                                                            int Nimg, int H, int W, int C, unsigned* __restrict__ block_max) {
     const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
     const int64_t total = (int64_t)Nimg * Ho * Wo * C4;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+    if (i >= total) return;   // (block_max: the launcher makes total a multiple of the block - no thread leaves before the barrier below)
     const int c4 = (int)(i % C4);
     int64_t pix = i / C4;
     const int ox = (int)(pix % Wo);
@@ -321,6 +321,27 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_nhwc(const float* __restr
     } else {
         reinterpret_cast<float4*>(static_cast<float*>(yv) + opix * C)[c4] = m;
     }
+    if (block_max) {
+        // the largest output of this block (outputs are >= 0: the bits order like the values), one plain store per block: the blocks of an
+        // image are reduced by image_max_of_blocks below - no atomics, no order dependence
+        __shared__ unsigned wmax[4];
+        float mx = fmaxf(fmaxf(m.x, m.y), fmaxf(m.z, m.w));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = __float_as_uint(mx);
+        __syncthreads();
+        if (threadIdx.x == 0) block_max[blockIdx.x] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    }
+}
+
+// amax[n] = the largest of image n's `per_image` block maxima (bits of non-negative floats)
+__global__ __launch_bounds__(64) void image_max_of_blocks(const unsigned* __restrict__ block_max, int per_image, unsigned* __restrict__ amax) {
+    const unsigned* b = block_max + (int64_t)blockIdx.x * per_image;
+    unsigned m = 0u;
+    for (int i = threadIdx.x; i < per_image; i += 64) m = max(m, b[i]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (threadIdx.x == 0) amax[blockIdx.x] = m;
 }
 
 int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
@@ -328,17 +349,21 @@ int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, 
     RELAX_REQUIRE(h, Nimg > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "bn_relu_maxpool: bad shape");
     const int64_t total = (int64_t)Nimg * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(bn_relu_maxpool_nhwc<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, y,
-                       Nimg, H, W, C);
+                       Nimg, H, W, C, nullptr);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }
 
 int launch_bn_relu_maxpool_sp3(relax_handle* h, const float* x, const float* scale, const float* shift, void* y_sp3,
-                               int Nimg, int H, int W, int C, hipStream_t s) {
+                               int Nimg, int H, int W, int C, hipStream_t s, unsigned* amax_out, unsigned* block_ws) {
     RELAX_REQUIRE(h, Nimg > 0 && H % 2 == 0 && W % 2 == 0 && C % 16 == 0, "bn_relu_maxpool_sp3: bad shape");
     const int64_t total = (int64_t)Nimg * (H / 2) * (W / 2) * (C / 4);
+    const int64_t per_image = (int64_t)(H / 2) * (W / 2) * (C / 4);
+    // amax_out [Nimg]: the per-image maximum of the outputs (block_ws: total / 256 words of scratch); a block must lie inside one image
+    RELAX_REQUIRE(h, !amax_out || (block_ws && per_image % 256 == 0), "bn_relu_maxpool_sp3: per-image maxima need whole blocks per image");
     hipLaunchKernelGGL(bn_relu_maxpool_nhwc<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, y_sp3,
-                       Nimg, H, W, C);
+                       Nimg, H, W, C, amax_out ? block_ws : nullptr);
+    if (amax_out) hipLaunchKernelGGL(image_max_of_blocks, dim3(Nimg), dim3(64), 0, s, block_ws, (int)(per_image / 256), amax_out);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }

@@ -78,6 +78,11 @@ struct ConvDescX6 {
     const void* in2;
     int H2, W2, Cin2, stride2;
     int in_f32;             // 1: `in` is plain fp32 [M][Cin] rows (split into planes inside the K loop): 1x1 stride-1, Cout = 64 / 128 only
+    // f16x2 on the four-wave tiles (the 3x3 convolutions of layer1 / layer2): `in` and `w` are two fp16 planes (csrc/h2.h: [..][Cin*4 B],
+    // [Cout][K*4 B]), image i's activations scaled by 1 / img_in_inv[i], weight row n by 1 / colscale[n]; Cout = 64 / 128, K >= 256
+    int in_h2;
+    const float* colscale;
+    const float* img_in_inv;
     int out_rows, gap_rows; // rows below these limits get the fp32 output / the group sums (0 = all rows)
     bool no_split;          // never cut tail tiles along K (a launch whose bits must not depend on which outputs are requested)
     const float* bias;      // [Cout] or null
@@ -244,6 +249,8 @@ struct GemmOptions {
                              // box_solve_fused (M through HBM) - same bits, the A/B switch of a test
     int rn_h2 = 1;         // "rn_h2": under "gemm_precision" 3, ResNet-50's layer3 / layer4 (the matrix-pipe-bound third of its time) run f16x2 with
                            // per-image scales; 0 = the whole network on bf16x6 (the A/B switch of a test)
+    int rn_h2_early = 1;   // "rn_h2_early": with "rn_h2", the 3x3 convolutions of layer1 / layer2 (the MFMA-bound launches of those layers) run f16x2 too,
+                           // on the four-wave tiles of gemm_x6.hip (conv1 writes its output as fp16 planes with the image's Hoelder scale); 0 = bf16x6 there
     int fp32_rows = 1;     // "x6_fp32_rows": bf16x6 contractions onto 64 / 128 columns take fp32 activation rows and split them in the K loop
                            // (ResNet-50 layer1 / layer2 block outputs travel as fp32); 0 = split planes everywhere (same bits, more bytes: the A/B switch of a test)
     int debug_poison = 0;  // "debug_poison": fill every workspace with 0xFF bytes when it is requested (test mode: reads of unwritten workspace surface as NaN)
@@ -328,7 +335,7 @@ int launch_attention_x6(relax_handle* h, const float* qkv, float* out, void* out
 int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
                            int Nimg, int H, int W, int C, hipStream_t s);
 int launch_bn_relu_maxpool_sp3(relax_handle* h, const float* x, const float* scale, const float* shift, void* y_sp3,
-                               int Nimg, int H, int W, int C, hipStream_t s);
+                               int Nimg, int H, int W, int C, hipStream_t s, unsigned* amax_out = nullptr, unsigned* block_ws = nullptr);
 int launch_gap_groups_finish(relax_handle* h, const float* groups, float* out, int Nimg, int HW, int C, int64_t out_stride,
                              hipStream_t s);
 int launch_gap(relax_handle* h, const float* x, float* out, int Nimg, int HW, int C, int64_t out_stride,

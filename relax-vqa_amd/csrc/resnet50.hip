@@ -156,7 +156,8 @@ static constexpr size_t kImgSlots = 64;             // per-image tables of the f
 static constexpr size_t kRnFloatsPerImage = kX0 + 3 * kBig + kT1 + kT2 + kGapWs + kAvg;
 // bf16x6 path: block inputs / outputs exist twice (fp32 for the residual add and the taps, split planes = 1.5 floats per
 // value for the next convolutions), the intermediates of a block only as split planes
-static constexpr size_t kRnFloatsPerImageX6 = kX0 + 3 * kBig + 2 * (kBig * 3 / 2) + (kT1 + kT2) * 3 / 2 + kGapWs + kAvg + 3 * kImgSlots;
+static constexpr size_t kBlockMax = 256;            // block maxima of the max-pool (196 blocks of 16 output pixels per image)
+static constexpr size_t kRnFloatsPerImageX6 = kX0 + 3 * kBig + 2 * (kBig * 3 / 2) + (kT1 + kT2) * 3 / 2 + kGapWs + kAvg + 3 * kImgSlots + kBlockMax;
 
 size_t resnet_arena_bytes(int n) {
     return sizeof(float) * (kRnFloatsPerImage > kRnFloatsPerImageX6 ? kRnFloatsPerImage : kRnFloatsPerImageX6) * (size_t)n;
@@ -276,14 +277,16 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
     }
     // ... the convolutions of layer3 / layer4 (blocks 7 .. 15: 256 / 512-wide, every Cout a multiple of 256, every Cin of 32) also as two
     // fp16 planes with one power-of-two scale per output row (gemm_h2.hip; w_inv = the inverse scales, the epilogue's colscale)
-    for (size_t b = kFirstH2Block; b < rn.blocks.size(); ++b) {
+    // ... and the 3x3 convolutions of layer1 / layer2 (64 / 128 columns: the four-wave f16x2 form of gemm_x6.hip, "rn_h2_early")
+    for (size_t b = 0; b < rn.blocks.size(); ++b) {
         Bottleneck& blk = rn.blocks[b];
+        const bool early = b < kFirstH2Block;
         for (ConvW* c : {&blk.c1, &blk.c2, &blk.c3, &blk.down}) {
-            if (!c->w) continue;
+            if (!c->w || (early && (c != &blk.c2 || c->Cin % 16 != 0 || c->Cout % 64 != 0 || c->Cout % 256 == 0))) continue;
             const int K = c->KH * c->KW * c->Cin;
             void* q = nullptr;
             float* inv = nullptr;
-            if (c->Cin % 32 != 0 || c->Cout % 256 != 0 || hipMalloc(&q, (size_t)c->Cout * K * 4) != hipSuccess ||
+            if ((!early && (c->Cin % 32 != 0 || c->Cout % 256 != 0)) || hipMalloc(&q, (size_t)c->Cout * K * 4) != hipSuccess ||
                 hipMalloc(reinterpret_cast<void**>(&inv), sizeof(float) * (size_t)c->Cout) != hipSuccess) {
                 if (q) (void)hipFree(q);
                 set_error(h, "resnet50: fp16-plane weights of block %zu (Cin %d, Cout %d) could not be made", b, c->Cin, c->Cout);
@@ -404,7 +407,16 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
         if (use_h2) RELAX_HIP_CHECK(h, hipMemsetAsync(imgtab, 0, sizeof(float) * 3 * kImgSlots * n, s));
         int slot_x = -1;          // the current block input's slot, once it exists as fp16 planes
         int slot_prev_out = -1;   // maximum of the previous block's output (the residual of the hand-over block)
-        RELAX_TRY(launch_bn_relu_maxpool_sp3(h, bufA, rn.bn1_scale, rn.bn1_shift, spa, N, 112, 112, 64, s));
+        // "rn_h2_early": the 3x3 convolutions of layer1 / layer2 on f16x2 as well (gemm_x6.hip, H2 form).  Their input (conv1's output)
+        // is written as fp16 planes with the image's Hoelder scale  l1max(conv1) max|block input| + max|bias|; the block input's maximum
+        // is measured by its producer: the max-pool (block maxima, reduced per image) or the previous block's conv3 epilogue.
+        bool use_early = use_h2 && h->gemm.rn_h2_early;
+        for (size_t b = 0; b < kFirstH2Block && use_early; ++b) use_early = rn.blocks[b].c2.w_h2 != nullptr;
+        int slot_xin = -1;        // (early) the slot that holds the maximum of the current block input
+        if (use_early) slot_xin = next_slot++;
+        RELAX_TRY(launch_bn_relu_maxpool_sp3(h, bufA, rn.bn1_scale, rn.bn1_shift, spa, N, 112, 112, 64, s,
+                                             use_early ? slot_amax(slot_xin) : nullptr,
+                                             reinterpret_cast<unsigned*>(imgtab + 3 * kImgSlots * n)));
         // A block output exists as split planes (next convolutions, next residual: hi + mid + lo is the fp32 value, exactly) and as
         // fp32 only where something needs it, and only for the images that need it: the tap export, the spatial mean of the 7x7
         // taps of the layer-stack images (49 rows per image do not divide into the 16- or 4-row groups of the mean fused into
@@ -503,24 +515,36 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             // maximum, and block 6's output as fp32 + fp16 planes with its Hoelder scale + its maximum
             const bool handover = use_h2 && b + 1 == kFirstH2Block;
             const bool pre_handover = use_h2 && b + 2 == kFirstH2Block;
-            int slot_c2 = -1, slot_y = -1;
+            int slot_c2 = -1, slot_y = -1, slot_t1 = -1, slot_o = -1;
             if (handover) { slot_c2 = next_slot++; slot_y = next_slot++; }
-            if (pre_handover) slot_prev_out = next_slot++;
+            if (use_early) slot_t1 = next_slot++;
+            // the maximum of this block's output: the next block's conv1 scale (early), the residual term of the hand-over block
+            if (handover) slot_o = slot_y;
+            else if (use_early || pre_handover) slot_o = next_slot++;
+            if (pre_handover) slot_prev_out = slot_o;
             {
                 ConvDescX6 d{};
                 d.in = cur_is_f32 ? static_cast<const void*>(cur32) : cursp; d.in_f32 = cur_is_f32;
                 d.Nimg = N; d.H = H; d.W = H; d.Cin = blk.c1.Cin; d.Ho = H; d.Wo = H;
                 d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
-                d.w = blk.c1.w_sp3; d.Cout = blk.c1.Cout; d.bias = blk.c1.bias; d.out_sp3 = T1s; d.act = 1;
+                d.w = blk.c1.w_sp3; d.Cout = blk.c1.Cout; d.bias = blk.c1.bias; d.act = 1;
+                if (use_early) {   // fp16 planes for the f16x2 conv2, scaled by the image's bound
+                    RELAX_TRY(launch_h2_image_scales(h, slot_amax(slot_xin), blk.c1.l1max, nullptr, 0.f, nullptr, blk.c1.bmax, slot_scale(slot_t1),
+                                                     slot_inv(slot_t1), N, s));
+                    d.out_h2 = T1s; d.img_out_scale = slot_scale(slot_t1);
+                } else {
+                    d.out_sp3 = T1s;
+                }
                 RELAX_TRY(launch_conv_x6(h, d, s));
             }
-            if (handover) {
+            if (handover || use_early) {
                 ConvDescX6 d2{};
                 d2.in = T1s; d2.Nimg = N; d2.H = H; d2.W = H; d2.Cin = blk.c2.Cin;
                 d2.Ho = (H + 2 * blk.c2.pad - blk.c2.KH) / blk.c2.stride + 1; d2.Wo = d2.Ho;
                 d2.KH = blk.c2.KH; d2.KW = blk.c2.KW; d2.stride = blk.c2.stride; d2.pad = blk.c2.pad;
                 d2.w = blk.c2.w_sp3; d2.Cout = blk.c2.Cout; d2.bias = blk.c2.bias; d2.out_sp3 = T2s; d2.act = 1;
-                d2.amax_out = slot_amax(slot_c2);
+                if (use_early) { d2.in_h2 = 1; d2.w = blk.c2.w_h2; d2.colscale = blk.c2.w_inv; d2.img_in_inv = slot_inv(slot_t1); }
+                if (handover) d2.amax_out = slot_amax(slot_c2);
                 RELAX_TRY(launch_conv_x6(h, d2, s));
             } else {
                 RELAX_TRY(run_conv_x6(h, blk.c2, T1s, N, H, H, nullptr, nullptr, T2s, 1, s));
@@ -543,7 +567,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 d.w = blk.c3.w_sp3; d.bias = blk.c3.bias;
                 if (cur_is_f32) d.residual = cur32; else d.residual_sp3 = cursp;
             }
-            if (pre_handover) d.amax_out = slot_amax(slot_prev_out);
+            if (slot_o >= 0 && !handover) d.amax_out = slot_amax(slot_o);
             if (handover) {
                 // (block 6 has no downsample branch and its input is fp32 rows: residual = cur32; its output leaves as fp16 planes with the
                 // Hoelder scale of conv3 + identity)
@@ -574,6 +598,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             if (need32) out32 = out32 == f32a ? f32b : f32a;
             if (!out_is_f32) { char* t = cursp; cursp = othersp; othersp = t; }
             cur_is_f32 = out_is_f32;
+            slot_xin = slot_o;
             H = Ho;
             if (tapped) {
                 const int off = tap_offset(blk.tap);

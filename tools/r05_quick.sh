@@ -1,7 +1,5 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-for i in 1 2; do
-RELAX_HIP_LIB=tools/librelax_base.so timeout 300 python tools/vit_step.py f16x2 1024 5 2>&1 | grep -v amdgpu.ids | sed 's/^/base: /'
-timeout 300 python tools/vit_step.py f16x2 1024 5 2>&1 | grep -v amdgpu.ids | sed 's/^/new:  /'
-done
-timeout 900 python -m pytest tests/test_gpu_h2.py -x -q 2>&1 | tail -3
+timeout 1200 python -m pytest tests/test_gpu_h2.py tests/test_gpu_x6.py -q -x 2>&1 | tail -4
+for e in 1 0 1 0; do RELAX_OPTS=rn_h2_early=$e timeout 300 python tools/resnet_step.py 1024 5 2>&1 | grep -v amdgpu.ids | tail -1; done
+tools/resnet_layers.sh early 1024 2>&1 | head -42 | tail -36
