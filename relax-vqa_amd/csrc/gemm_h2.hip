@@ -48,6 +48,9 @@
 #define H2_STAMPS_BEFORE_LAUNCH(h_, p_, units_)
 #define H2_STAMPS_AFTER_LAUNCH(h_, p_, units_, s_)
 #endif
+#ifndef H3_KSTEP
+#define H3_KSTEP(k_) (k_)   // the K step a DMA piece of a plain gemm_h3 reads (the diagnostic build can wrap it so that every piece hits L2)
+#endif
 
 namespace relax {
 
@@ -613,10 +616,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                 const int tapoff_ = (d_dy * p.W + d_dx) * (int)arow_bytes + d_cc * (2 * kH2ChunkBytes) + ((j_) >> 2) * 32; \
                 H2_DMA(rsrc_a, dst_, ok_ ? voff[(j_) & 3] + (unsigned)tapoff_ : kH2OutOfRange, 0);                      \
             } else {                                                                                                    \
-                H2_DMA(rsrc_a, dst_, voff[(j_) & 3], d_kt * (2 * kH2ChunkBytes) + ((j_) >> 2) * 32);                    \
+                H2_DMA(rsrc_a, dst_, voff[(j_) & 3], H3_KSTEP(d_kt) * (2 * kH2ChunkBytes) + ((j_) >> 2) * 32);          \
             }                                                                                                           \
         } else {                                                                                                        \
-            const int wk_ = TAPS ? (d_tap * cin_chunks + 2 * d_cc) * kH2ChunkBytes : d_kt * (2 * kH2ChunkBytes);        \
+            const int wk_ = TAPS ? (d_tap * cin_chunks + 2 * d_cc) * kH2ChunkBytes : H3_KSTEP(d_kt) * (2 * kH2ChunkBytes); \
             H2_DMA(rsrc_w, dst_, voff[(j_) & 3], wk_ + ((j_) >> 2) * 32);                                                \
         }                                                                                                               \
     }

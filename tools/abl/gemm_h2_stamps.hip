@@ -10,6 +10,9 @@
     (p_).stamps = static_cast<unsigned long long*>((h_)->scratch.p)
 #define H2_STAMPS_AFTER_LAUNCH(h_, p_, units_, s_) RELAX_TRY((h2_report_stamps(h_, p_, units_, s_)))
 
+#ifdef H3_L2HIT   // (tools/build_ablations.sh h2l2hit) every K step of a plain gemm_h3 re-reads the first four: WRONG results, the K loop with
+#define H3_KSTEP(k_) ((k_) & 3)   // every DMA piece served by L2 - the bound of what prefetching into L2 could return
+#endif
 namespace relax {
 template <class Params>
 static int h2_report_stamps(relax_handle* h, const Params& p, int units, hipStream_t s) {

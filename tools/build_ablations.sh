@@ -4,6 +4,8 @@
 # hooks and #includes the product file), so no -D on the product build can make librelax_hip.so record stamps or return wrong numbers.
 #   tools/build_ablations.sh x6stamps       bf16x6 kernel with per-phase cycle stamps (prints per launch, syncs)
 #   tools/build_ablations.sh h2stamps       f16x2 kernel with per-phase cycle stamps (prints per launch, syncs)
+#   tools/build_ablations.sh h2l2hit        the same with every K step of a plain gemm_h3 re-reading the first four (WRONG results: the K loop with
+#                                           every DMA piece served by L2)
 #   tools/build_ablations.sh flowstamps     fused Farneback iteration with tick stamps per phase of a step (tools/flow_stamps.py prints them)
 #   tools/build_ablations.sh a6stamps       bf16x6 attention kernel with ticks per phase of an item (tools/attn_stamps.py prints them;
 #                                           overwrites the first floats of the fp32 output: timing only)
@@ -26,6 +28,7 @@ for n in "$@"; do
   case "$n" in
     x6stamps) $CC -I. -c ../../tools/abl/gemm_x6_stamps.hip -o /tmp/gemm_x6_stamps.o; link gemm_x6.o /tmp/gemm_x6_stamps.o x6stamps ;;
     h2stamps) $CC -I. -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_stamps.o; link gemm_h2.o /tmp/gemm_h2_stamps.o h2stamps ;;
+    h2l2hit) $CC -I. -DH3_L2HIT -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_l2hit.o; link gemm_h2.o /tmp/gemm_h2_l2hit.o h2l2hit ;;
     flowstamps) $FLOWCC -I. -c ../../tools/abl/flow_stamps.hip -o /tmp/flow_stamps.o; link flow.o /tmp/flow_stamps.o flowstamps ;;
     a6stamps) $CC -I. -c ../../tools/abl/attention_x6_stamps.hip -o /tmp/attention_x6_stamps.o; link attention_x6.o /tmp/attention_x6_stamps.o a6stamps ;;
     *) echo "unknown diagnostic build: $n" >&2; exit 2 ;;

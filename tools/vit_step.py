@@ -24,6 +24,9 @@ if data == "zeros":
     sd = {k: v * 0 for k, v in sd.items()}
 eng.load_vit(sd, "vit_base")
 eng.set_precision(prec)
+for kv in os.environ.get("RELAX_OPTS", "").split(","):           # e.g. RELAX_OPTS=h2_kb=0
+    if "=" in kv:
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 frags = torch.randint(0, 256, (n, 224, 224, 3), dtype=torch.uint8, device="cuda")
 eng.vit_features(frags)
 torch.cuda.synchronize()
