@@ -71,8 +71,9 @@ int relax_reserve(relax_handle* h, int max_images);
  * batch - weights per output row, ViT activations one static power of two per tensor, ResNet-50 activations one per image from
  * Hoelder's inequality on the measured per-image maxima of the producer's inputs - so nothing can overflow and no row depends on its
  * batch (csrc/gemm_h2.hip, csrc/h2.h, tests/test_gpu_h2.py).  It covers the plain GEMMs with N % 256 == 0 (the whole ViT-B/16;
- * relax_op_gemm) and the convolutions of ResNet-50's layer3 / layer4 (relax_op_conv2d_nhwc with Cin % 32 == 0, Cout % 256 == 0);
- * everything else runs as under 2.  0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 2 = "bf16x6" (fp32-grade):
+ * relax_op_gemm), the convolutions of ResNet-50's layer3 / layer4 (relax_op_conv2d_nhwc with Cin % 32 == 0, Cout % 256 == 0) and the
+ * 3x3 convolutions of its layer1 / layer2 (K x K filters onto 64 / 128 channels, K >= 256: v_mfma_f32_32x32x16_f16 on the four-wave
+ * tiles of csrc/gemm_x6.hip, the two small products in an accumulator of their own); everything else runs as under 2.  0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 2 = "bf16x6" (fp32-grade):
  * every fp32 operand is held as three bf16 numbers hi + mid + lo (exact) and a*b = the six partial products of weight
  * >= 2^-16 on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, two products per instruction; 32x32x16 on the 64 / 128-column
  * tiles) with fp32 accumulation - as close to the exact sum as the fp32 FMA chain

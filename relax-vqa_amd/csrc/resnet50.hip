@@ -380,7 +380,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
         return RELAX_OK;
     };
 
-    if (h->gemm.precision >= 2) {   // (3 = f16x2 covers the plain GEMMs of the ViT only: the convolutions run bf16x6)
+    if (h->gemm.precision >= 2) {   // (3 = f16x2: layer3 / layer4 and the 3x3 convolutions of layer1 / layer2 on fp16 planes - "rn_h2", "rn_h2_early" - the rest bf16x6)
         // bf16x6.  conv1 7x7/2 (raw) straight from the uint8 fragments (conv1_x6.hip: preprocess, im2col, split and contraction in one
         // kernel, the 16-pixel sums of the tap's spatial mean formed in its epilogue); from the max-pool on, every convolution input
         // travels as split planes written by its producer
