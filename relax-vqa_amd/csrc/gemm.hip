@@ -690,10 +690,11 @@ int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const
     d.Kpad = ((KH * KW * Cin + 31) / 32) * 32;
     d.bias = bias; d.residual = residual; d.out = out; d.act = act;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (h->gemm.precision == 3 && Cin % 32 == 0 && d.Kpad == KH * KW * Cin && KH * KW <= 32 && Cout % 256 == 0 && (KH * KW > 1 || pad == 0)) {
-        // operator-level entry under "f16x2" (the geometries of ResNet-50's layer3 / layer4): the input becomes fp16 planes with one scale per
-        // IMAGE from its measured maximum, the weights with one per output row; both conversions happen here (the model driver keeps the
-        // planes and derives the scales from bounds: gemm_h2.hip)
+    // operator-level entry under "f16x2": the input becomes fp16 planes with one scale per IMAGE from its measured maximum, the weights with one per
+    // output row; both conversions happen here (the model drivers keep the planes and derive the scales from bounds: gemm_h2.hip, resnet50.hip)
+    const bool h2_wide = Cin % 32 == 0 && Cout % 256 == 0 && (KH * KW > 1 || pad == 0);                       // ResNet-50 layer3 / layer4: gemm_h3
+    const bool h2_narrow = h->gemm.rn_h2_early && Cin % 16 == 0 && KH * KW > 1 && Cout % 64 == 0 && Cout % 256 != 0 && d.Kpad >= 256;   // the 3x3s of layer1 / layer2: gemm_x6<H2>
+    if (h->gemm.precision == 3 && d.Kpad == KH * KW * Cin && KH * KW <= 32 && (h2_wide || h2_narrow)) {
         const size_t a_bytes = (size_t)Nimg * H * W * Cin * 4, w_bytes = (size_t)Cout * d.Kpad * 4;
         const size_t a_al = (a_bytes + 255) & ~(size_t)255, w_al = (w_bytes + 255) & ~(size_t)255, i_al = ((size_t)Nimg * 4 + 255) & ~(size_t)255;
         RELAX_TRY(ensure_buf(h, h->sp3_ws, a_al + w_al + 3 * i_al + (size_t)Cout * 4 + 256));
@@ -707,29 +708,14 @@ int relax_op_conv2d_nhwc(relax_handle* h, const float* in, const float* w, const
         RELAX_TRY(launch_h2_image_scales(h, amax, 1.f, nullptr, 0.f, nullptr, 0.f, sc, inv, Nimg, s));
         RELAX_TRY(launch_to_h2(h, in, Cin, As, (int64_t)Nimg * H * W, Cin, 1.f, sc, s, H * W));
         RELAX_TRY(launch_to_h2_rows(h, w, d.Kpad, Ws, Cout, d.Kpad, cs, s));
-        GemmDescH2 g{};
-        g.a = As; g.w = Ws; g.colscale = cs; g.bias = bias; g.residual = residual; g.out = out;
-        g.M = Nimg * d.Ho * d.Wo; g.N = Cout; g.K = d.Kpad; g.act = act;
-        g.pixels = 1; g.Nimg = Nimg; g.H = H; g.W = W; g.Cin = Cin; g.Ho = d.Ho; g.Wo = d.Wo; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
-        g.rows_per_img = d.Ho * d.Wo; g.img_in_inv = inv;
-        return launch_gemm_h2(h, g, s);
-    }
-    if (h->gemm.precision == 3 && h->gemm.rn_h2_early && Cin % 16 == 0 && d.Kpad == KH * KW * Cin && KH * KW > 1 && KH * KW <= 32 && Cout % 64 == 0 &&
-        Cout % 256 != 0 && d.Kpad >= 256) {
-        // ... and the geometries of the 3x3 convolutions of layer1 / layer2: the four-wave f16x2 form of gemm_x6.hip, same conversions
-        const size_t a_bytes = (size_t)Nimg * H * W * Cin * 4, w_bytes = (size_t)Cout * d.Kpad * 4;
-        const size_t a_al = (a_bytes + 255) & ~(size_t)255, w_al = (w_bytes + 255) & ~(size_t)255, i_al = ((size_t)Nimg * 4 + 255) & ~(size_t)255;
-        RELAX_TRY(ensure_buf(h, h->sp3_ws, a_al + w_al + 3 * i_al + (size_t)Cout * 4 + 256));
-        char* As = static_cast<char*>(h->sp3_ws.p);
-        char* Ws = As + a_al;
-        unsigned* amax = reinterpret_cast<unsigned*>(Ws + w_al);
-        float* sc = reinterpret_cast<float*>(Ws + w_al + i_al);
-        float* inv = reinterpret_cast<float*>(Ws + w_al + 2 * i_al);
-        float* cs = reinterpret_cast<float*>(Ws + w_al + 3 * i_al);
-        RELAX_TRY(launch_image_absmax(h, in, (int64_t)H * W * Cin, Nimg, amax, s));
-        RELAX_TRY(launch_h2_image_scales(h, amax, 1.f, nullptr, 0.f, nullptr, 0.f, sc, inv, Nimg, s));
-        RELAX_TRY(launch_to_h2(h, in, Cin, As, (int64_t)Nimg * H * W, Cin, 1.f, sc, s, H * W));
-        RELAX_TRY(launch_to_h2_rows(h, w, d.Kpad, Ws, Cout, d.Kpad, cs, s));
+        if (h2_wide) {
+            GemmDescH2 g{};
+            g.a = As; g.w = Ws; g.colscale = cs; g.bias = bias; g.residual = residual; g.out = out;
+            g.M = Nimg * d.Ho * d.Wo; g.N = Cout; g.K = d.Kpad; g.act = act;
+            g.pixels = 1; g.Nimg = Nimg; g.H = H; g.W = W; g.Cin = Cin; g.Ho = d.Ho; g.Wo = d.Wo; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+            g.rows_per_img = d.Ho * d.Wo; g.img_in_inv = inv;
+            return launch_gemm_h2(h, g, s);
+        }
         ConvDescX6 x{};
         x.in = As; x.in_h2 = 1; x.colscale = cs; x.img_in_inv = inv; x.Nimg = Nimg; x.H = H; x.W = W; x.Cin = Cin; x.Ho = d.Ho; x.Wo = d.Wo;
         x.KH = KH; x.KW = KW; x.stride = stride; x.pad = pad;
