@@ -547,6 +547,7 @@ int relax_op_attention(relax_handle* h, const float* qkv, float* out, int Nimg, 
     if (!h) return RELAX_ERR_INVALID;
     RELAX_REQUIRE(h, qkv && out, "relax_op_attention: NULL operand");
     RELAX_HIP_CHECK(h, hipSetDevice(h->device));
+    if (h->gemm.precision == 3 && h->gemm.att_h2) return launch_attention_h2_op(h, qkv, out, Nimg, heads, static_cast<hipStream_t>(stream));
     if (h->gemm.precision >= 2) return launch_attention_x6(h, qkv, out, nullptr, Nimg, heads, static_cast<hipStream_t>(stream));
     return launch_attention(h, qkv, out, Nimg, heads, static_cast<hipStream_t>(stream));
 }

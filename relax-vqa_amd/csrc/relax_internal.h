@@ -174,6 +174,7 @@ struct VitBlockW {
     // f16x2: static power-of-two scales of the activation tensors that travel as fp16 planes (host_logic.h: from bounds that hold
     // for every input): LayerNorm 1 output, attention output, LayerNorm 2 output, GELU(fc1) output
     float s_ln1 = 1.f, s_att = 1.f, s_ln2 = 1.f, s_hid = 1.f;
+    float s_qkv = 1.f;   // ... and the whole qkv output (attention_h2.hip reads q, k, v as planes)
 };
 
 struct VitW {
@@ -249,6 +250,8 @@ struct GemmOptions {
                              // box_solve_fused (M through HBM) - same bits, the A/B switch of a test
     int rn_h2 = 1;         // "rn_h2": under "gemm_precision" 3, ResNet-50's layer3 / layer4 (the matrix-pipe-bound third of its time) run f16x2 with
                            // per-image scales; 0 = the whole network on bf16x6 (the A/B switch of a test)
+    int att_h2 = 1;        // "att_h2": under "gemm_precision" 3 the ViT's attention runs on fp16 planes too (attention_h2.hip: the qkv GEMM writes planes,
+                           // three products, no conversion passes); 0 = attention_x6 on the fp32 qkv output (three bf16 planes, six products)
     int rn_h2_early = 1;   // "rn_h2_early": with "rn_h2", the 3x3 convolutions of layer1 / layer2 (the MFMA-bound launches of those layers) run f16x2 too,
                            // on the four-wave tiles of gemm_x6.hip (conv1 writes its output as fp16 planes with the image's Hoelder scale); 0 = bf16x6 there
     int fp32_rows = 1;     // "x6_fp32_rows": bf16x6 contractions onto 64 / 128 columns take fp32 activation rows and split them in the K loop
@@ -332,6 +335,9 @@ int launch_layernorm_h2(relax_handle* h, const float* x, const float* g, const f
 // out_planes: split planes (out_h2_scale == 0) or two fp16 planes scaled by out_h2_scale (> 0)
 int launch_attention_x6(relax_handle* h, const float* qkv, float* out, void* out_planes, int Nimg, int heads, hipStream_t s,
                         float out_h2_scale = 0.f);
+// attention on the fp16 planes the qkv GEMM wrote (attention_h2.hip): qkv_planes [Nimg*197][3*dim*4 B] of qkv * s_qkv -> out_planes [..][dim*4 B] of out * out_scale
+int launch_attention_h2(relax_handle* h, const void* qkv_planes, float s_qkv, void* out_planes, float out_scale, int Nimg, int heads, hipStream_t s);
+int launch_attention_h2_op(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s);   // fp32 in / out (relax_op_attention)
 int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
                            int Nimg, int H, int W, int C, hipStream_t s);
 int launch_bn_relu_maxpool_sp3(relax_handle* h, const float* x, const float* scale, const float* shift, void* y_sp3,

@@ -281,6 +281,8 @@ int relax_load_vit(relax_handle* h, const float* const* tensors, const char* con
             // attention output = convex combinations of the V rows of qkv(LayerNorm1(x)): columns 2 dim .. 3 dim of the qkv Linear
             b.s_att = host::h2_scale_for_bound(host::linear_of_layernorm_bound(host_of(p + "attn.qkv.weight", (int64_t)3 * dim * dim),
                                                                                host_of(p + "attn.qkv.bias", 3 * dim), g1, b1, dim, 2 * dim, 3 * dim));
+            b.s_qkv = host::h2_scale_for_bound(host::linear_of_layernorm_bound(host_of(p + "attn.qkv.weight", (int64_t)3 * dim * dim),
+                                                                               host_of(p + "attn.qkv.bias", 3 * dim), g1, b1, dim, 0, 3 * dim));
             // |GELU(x)| <= |x|, x = fc1(LayerNorm2(.))
             b.s_hid = host::h2_scale_for_bound(host::linear_of_layernorm_bound(host_of(p + "mlp.fc1.weight", (int64_t)4 * dim * dim),
                                                                                host_of(p + "mlp.fc1.bias", 4 * dim), g2, b2, dim, 0, 4 * dim));
@@ -347,8 +349,13 @@ int relax_vit_features(relax_handle* h, const uint8_t* frags, int N, float* toke
         RELAX_HIP_CHECK(h, hipGetLastError());
         for (const VitBlockW& b : v.blocks) {
             RELAX_TRY(launch_layernorm_h2(h, Xx, b.ln1_g, b.ln1_b, Ys, b.s_ln1, rows, dim, kLnEps, s));
-            RELAX_TRY(gemm(Ys, b.qkv, nullptr, QKVx, nullptr, 0.f, rows, 0));
-            RELAX_TRY(launch_attention_x6(h, QKVx, nullptr, Ys, N, v.heads, s, b.s_att));   // output straight into fp16 planes
+            if (h->gemm.att_h2) {   // q, k, v leave the GEMM as fp16 planes (the same 4 bytes per value) and attention reads them as they are
+                RELAX_TRY(gemm(Ys, b.qkv, nullptr, nullptr, QKVx, b.s_qkv, rows, 0));
+                RELAX_TRY(launch_attention_h2(h, QKVx, b.s_qkv, Ys, b.s_att, N, v.heads, s));
+            } else {
+                RELAX_TRY(gemm(Ys, b.qkv, nullptr, QKVx, nullptr, 0.f, rows, 0));
+                RELAX_TRY(launch_attention_x6(h, QKVx, nullptr, Ys, N, v.heads, s, b.s_att));   // output straight into fp16 planes
+            }
             RELAX_TRY(gemm(Ys, b.proj, Xx, Xx, nullptr, 0.f, rows, 0));                     // x += proj(attn)
             RELAX_TRY(launch_layernorm_h2(h, Xx, b.ln2_g, b.ln2_b, Ys, b.s_ln2, rows, dim, kLnEps, s));
             RELAX_TRY(gemm(Ys, b.fc1, nullptr, nullptr, Hs, b.s_hid, rows, 2));              // GELU(erf) -> fp16 planes

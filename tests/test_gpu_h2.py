@@ -285,6 +285,39 @@ def test_extreme_inputs_cannot_overflow_the_static_scales():
             assert_close(tokens, ref.astype(np.float32), "extreme inputs, regular weights")
 
 
+@pytest.mark.parametrize("n_img,heads,scale", [(1, 3, 1.0), (3, 12, 1.0), (2, 6, 4.0), (40, 12, 2.0), (5, 12, 0.02)])
+def test_attention_under_f16x2(n_img, heads, scale):
+    """softmax(q k^T / 8) v on two fp16 planes with three partial products (csrc/attention_h2.hip: K and V by LDS-DMA straight into the
+    fragment images, V read with the transposing LDS read) against fp64, beside the fp32-MFMA kernel and bf16x6: scale 4 makes logits of
+    +-60 (near one-hot rows), 0.02 nearly uniform rows of tiny values; 40 x 12 = 480 items > 256 workgroups exercises the persistent loop.
+    The gate is the review's: error no larger than the exact-fp32 path's."""
+    eng = engine()
+    dim = heads * 64
+    qkv = _rand(n_img * 197, 3 * dim, seed=17, scale=scale)
+    t = qkv.double().reshape(n_img, 197, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    attn = ((t[0] @ t[1].transpose(-2, -1)) * 64 ** -0.5).softmax(dim=-1)
+    ref = (attn @ t[2]).transpose(1, 2).reshape(n_img * 197, dim)
+    eng.set_precision("fp32")
+    e32 = (eng.op_attention(qkv.cuda(), n_img, heads).cpu().double() - ref).abs()
+    eng.set_precision("bf16x6")
+    e6 = (eng.op_attention(qkv.cuda(), n_img, heads).cpu().double() - ref).abs()
+    eng.set_precision("f16x2")
+    assert eng.get_option("att_h2") == 1
+    got = eng.op_attention(qkv.cuda(), n_img, heads)
+    assert torch.equal(got, eng.op_attention(qkv.cuda(), n_img, heads))
+    assert_close(got, ref.float().numpy(), f"f16x2 attention n={n_img} heads={heads}")
+    e2 = (got.cpu().double() - ref).abs()
+    print(f"\nattention {n_img}x{heads} scale {scale}: mean err fp32 {e32.mean().item():.3e} bf16x6 {e6.mean().item():.3e} f16x2 {e2.mean().item():.3e}; "
+          f"max fp32 {e32.max().item():.3e} bf16x6 {e6.max().item():.3e} f16x2 {e2.max().item():.3e}")
+    assert e2.mean().item() <= 1.05 * e32.mean().item() + 1e-12 and e2.max().item() <= 1.5 * e32.max().item() + 1e-12
+    try:
+        eng.set_option("att_h2", 0)    # the A/B switch: attention_x6 under gemm_precision 3
+        old = eng.op_attention(qkv.cuda(), n_img, heads)
+    finally:
+        eng.set_option("att_h2", 1)
+    assert_close(old, ref.float().numpy(), "attention_x6 under f16x2 (att_h2 = 0)")
+
+
 # ---- ResNet-50 under f16x2: layer3 / layer4 on fp16 planes with per-image scales ------------------------------------------------------------
 from oracle import resnet50_ref  # noqa: E402
 from tests.gpu_common import rn50_weights  # noqa: E402
