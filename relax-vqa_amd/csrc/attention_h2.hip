@@ -151,23 +151,25 @@ __global__ __launch_bounds__(AH_THREADS) void attention_h2(const char* __restric
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef AH_READ_K
-        // sacc[kt][r] * alpha = score(query li, key kt*32 + (r&3) + 8*(r>>2) + 4*half) * log2(e)
+        // sacc[kt][r] * alpha = score(query li, key kt*32 + (r&3) + 8*(r>>2) + 4*half) * log2(e); only the last key tile holds padding keys.
+        // e = exp2(score - max): one fma + one v_exp_f32 per score (alpha > 0, so the maximum is taken on the raw sums).  (The 2^14 of the
+        // probability planes is NOT folded into the exponent: an argument near 14 has an ulp of 1e-6, and nearly uniform rows lost a digit.)
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < AH_KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                sacc[kt][r] = key >= AH_NTOK ? -INFINITY : sacc[kt][r] * alpha;
+                if (kt == AH_KT - 1 && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= AH_NTOK) sacc[kt][r] = -INFINITY;
                 mx = fmaxf(mx, sacc[kt][r]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float shift = -mx * alpha;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < AH_KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], alpha, shift));
                 sacc[kt][r] = e;
                 sum += e;
             }
@@ -289,7 +291,7 @@ __global__ void ah_op_scalars(const unsigned* __restrict__ amax, float* __restri
     tab[0] = s;
     tab[1] = 1.f / s;
     tab[2] = (float)(0.125 * 1.44269504088896341 / ((double)s * (double)s));   // alpha
-    tab[3] = (float)((double)s / ((double)s * 16384.0));                        // out_mul (output scale = s)
+    tab[3] = 1.f / 16384.f;                                                     // out_mul = output scale / (s 2^14), the output scale being s
 }
 
 __global__ __launch_bounds__(256) void ah_from_h2(const char* __restrict__ y, float* __restrict__ x, int K, int64_t total8, const float* __restrict__ inv) {
