@@ -18,6 +18,9 @@
 // f(key & 15) (a bit permutation: b0 = k2, b1 = k0, b2 = k3, b3 = k1), applied on the SOURCE offset of the DMA: the 16 lanes of a
 // ds_read_b128 group (keys {0-3, 12-15, 20-27} ...) and the 32 lanes of a transposed read (4 keys x 2 chunks x 4 column groups) then
 // hit distinct banks.  Rows 197 .. 223 lie beyond the buffer resource and arrive as zeros with every item.
+// Measured and not kept: issue priority for the first wave of each SIMD-sharing pair (waves w, w + 4), so that its softmax would run under
+// the partner's MFMAs: 633 against 625 us per layer and 1024 images.  The 2^14 of the probability planes folded into the exponent: an
+// argument near 14 has an ulp of 1e-6 and nearly uniform rows lose a digit (the device test caught it).
 #include "relax_internal.h"
 #include "h2.h"
 
