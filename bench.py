@@ -330,7 +330,7 @@ def main():
     x6 = precision in ("bf16x6", "f16x2")      # the split-operand kernels (under f16x2 the convolutions and attention stay bf16x6)
     if h2:
         assert eng.get_option("h2_form") == 1  # (three products for K >= 256: every f16x2 launch of these workloads; H2_EXECUTED below)
-        assert eng.get_option("rn_h2") == 1 and eng.get_option("rn_h2_early") == 1
+        assert eng.get_option("rn_h2") == 1 and eng.get_option("rn_h2_early") == 1 and eng.get_option("att_h2") == 1
 
     def barrier():
         if world > 1:
@@ -598,9 +598,9 @@ def flow_stage_record(prof, elapsed_s, traffic_per_clip=None):
                                "avg_launch_us": it_ms * 1e3 / max(it_n, 1), "time_share_of_step": it_ms * 1e-3 / elapsed_s}}
     return rec
 H2_EXECUTED = 3.0   # fp16 MFMA products per fp32 product in gemm_h3 at K >= 256 ("h2_form" 1): A[lo] B[hi], A[hi] B[lo], A[hi] B[hi]
-DTYPE_TEXT = {"f16x2": "f32 (fp32-grade split-operand arithmetic, fp32 accumulate: the ViT GEMMs, ResNet-50's layer3 / layer4 and the 3x3 convolutions of "
-                       "its layer1 / layer2 on fp32 operands as 2 fp16 planes x a power-of-two scale, 3 partial products on the fp16 MFMA [f16x2]; "
-                       "ResNet-50's stem, the 1x1 convolutions of layer1 / layer2 and attention on 3 bf16 planes, 6 partial products on the bf16 MFMA [bf16x6])",
+DTYPE_TEXT = {"f16x2": "f32 (fp32-grade split-operand arithmetic, fp32 accumulate: the whole ViT (GEMMs and attention), ResNet-50's layer3 / layer4 and the 3x3 "
+                       "convolutions of its layer1 / layer2 on fp32 operands as 2 fp16 planes x a power-of-two scale, 3 partial products on the fp16 MFMA "
+                       "[f16x2]; ResNet-50's stem and the 1x1 convolutions of layer1 / layer2 on 3 bf16 planes, 6 partial products on the bf16 MFMA [bf16x6])",
               "fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into two bf16 terms, fp32 accumulate; reduced precision)",
               "bf16x6": "f32 (fp32 operands as 3 bf16 planes, 6 partial products on the bf16 MFMA, fp32 accumulate: fp32-grade)"}
 
