@@ -15,13 +15,19 @@
 //   * the accumulators go straight to the NHWC fp32 output (a register of a 32x32 tile is 32 consecutive channels of one pixel),
 //     and the 16-pixel group sums of the fused spatial mean (tap 0 of the layer stack) are formed in registers.
 // Columns 21 .. 31 of a padded filter row read whatever follows in the patch (finite values) against ZERO weights.
+// H2 ("f16x2", with "rn_h2_early"): the same kernel on two fp16 planes - the patch values x 2^13 (|normalised pixel| <= 2.64: a static
+// scale) split in registers, the weights as planes with one power-of-two scale per filter, the three partial products al bh, ah bl, ah bh
+// on v_mfma_f32_32x32x16_f16 with the two small ones in accumulators of their own (gemm_x6.hip, H2), half the matrix instructions.
 #include "relax_internal.h"
 #include "sp3.h"
+#include "h2.h"
 
 namespace relax {
 
 typedef float c1_floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 c1_f16x8 __attribute__((ext_vector_type(8)));
+[[maybe_unused]] constexpr float kC1PatchScale = 8192.f;   // H2: 2.64 * 2^13 = 21.6 k < 65504
 typedef float c1_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int C1_HW = 224, C1_OW = 112, C1_OPIX = C1_OW * C1_OW;   // 12544 = 49 * 256
@@ -64,9 +70,13 @@ __device__ inline void conv1_put4(float* prow, int d, unsigned v, bool valid, co
 constexpr int C1_ROW_DW = C1_HW * 3 / 4;                   // 168 dwords per image row
 [[maybe_unused]] constexpr int C1_LOADS = (C1_PROWS * C1_ROW_DW + 511) / 512;   // 5 dwords per thread and tile
 
+template <bool H2>
 __global__ __launch_bounds__(512) void conv1_x6(const uint8_t* __restrict__ frags, const char* __restrict__ w_sp3, float* __restrict__ out,
-                                                float* __restrict__ gap, int n_tiles) {
+                                                float* __restrict__ gap, int n_tiles, const float* __restrict__ w_inv) {
 #if __HIP_DEVICE_COMPILE__
+    constexpr int CH = H2 ? kH2ChunkBytes : kChunkBytes;          // bytes of a 16-deep chunk of a weight row (two fp16 / three bf16 planes)
+    constexpr int UPR = C1_CHUNKS * CH / 16;                      // 16-byte units per weight row
+    constexpr int WROW = C1_CHUNKS * CH + 16;                     // (+16: conflict-free ds_read_b128 across rows, both forms)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wl = smem;
     float* patch0 = reinterpret_cast<float*>(smem + C1_W_BYTES);
@@ -76,10 +86,9 @@ __global__ __launch_bounds__(512) void conv1_x6(const uint8_t* __restrict__ frag
 
     // weights: 64 rows x 84 16-byte units, rows padded to C1_WROW bytes; both patch buffers start as zeros (their 3-pixel side
     // borders and the slack are never written again)
-    for (int u = tid; u < 64 * (C1_CHUNKS * 6); u += 512) {
-        const int n = u / (C1_CHUNKS * 6), q = u - n * (C1_CHUNKS * 6);
-        *reinterpret_cast<sp3_u32x4*>(wl + n * C1_WROW + q * 16) =
-            *reinterpret_cast<const sp3_u32x4*>(w_sp3 + ((int64_t)n * (C1_CHUNKS * 6) + q) * 16);
+    for (int u = tid; u < 64 * UPR; u += 512) {
+        const int n = u / UPR, q = u - n * UPR;
+        *reinterpret_cast<sp3_u32x4*>(wl + n * WROW + q * 16) = *reinterpret_cast<const sp3_u32x4*>(w_sp3 + ((int64_t)n * UPR + q) * 16);
     }
     for (int i = tid; i < 2 * C1_PATCH_FLOATS; i += 512) patch0[i] = 0.f;
     float* lut = patch0 + 2 * C1_PATCH_FLOATS;
@@ -138,9 +147,9 @@ __global__ __launch_bounds__(512) void conv1_x6(const uint8_t* __restrict__ frag
         const int p = p0 + wave * 32 + r;                  // this lane's output pixel (A rows of the wave's 32x64 block)
         const int y = p / C1_OW, x = p - y * C1_OW;
         const float* arow = patch + (2 * (y - y0)) * C1_PROW + 6 * x + 8 * half;
-        c1_floatx16 acc[2];
+        c1_floatx16 acc[2], accs[2];   // (accs: H2's small products)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; accs[0][i] = 0.f; accs[1][i] = 0.f; }
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) {
 #pragma unroll
@@ -148,15 +157,34 @@ __global__ __launch_bounds__(512) void conv1_x6(const uint8_t* __restrict__ frag
                 const float* a = arow + ky * C1_PROW + 16 * jc;
                 const c1_f32x2 a0 = *reinterpret_cast<const c1_f32x2*>(a), a1 = *reinterpret_cast<const c1_f32x2*>(a + 2),
                                a2 = *reinterpret_cast<const c1_f32x2*>(a + 4), a3 = *reinterpret_cast<const c1_f32x2*>(a + 6);
+                const int chunk = ky * 2 + jc;
+                if constexpr (H2) {
+                    h2_u32x4 ah, al;
+                    split2_x8((h2_f32x4){a0.x, a0.y, a1.x, a1.y} * kC1PatchScale, (h2_f32x4){a2.x, a2.y, a3.x, a3.y} * kC1PatchScale, ah, al);
+                    const c1_f16x8 Ah = __builtin_bit_cast(c1_f16x8, ah), Al = __builtin_bit_cast(c1_f16x8, al);
+                    c1_f16x8 Bh[2], Bl[2];
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        const char* wp = wl + (cb * 32 + r) * WROW + chunk * CH + half * 16;
+                        Bh[cb] = *reinterpret_cast<const c1_f16x8*>(wp);
+                        Bl[cb] = *reinterpret_cast<const c1_f16x8*>(wp + 32);
+                    }
+                    accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh[0], accs[0], 0, 0, 0);
+                    accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh[1], accs[1], 0, 0, 0);
+                    accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[0], accs[0], 0, 0, 0);
+                    accs[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[1], accs[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[1], acc[1], 0, 0, 0);
+                    continue;
+                }
                 sp3_u32x4 ah, am, al;
                 split3_x8((sp3_f32x4){a0.x, a0.y, a1.x, a1.y}, (sp3_f32x4){a2.x, a2.y, a3.x, a3.y}, ah, am, al);
                 const c1_bf16x8 Ah = __builtin_bit_cast(c1_bf16x8, ah), Am = __builtin_bit_cast(c1_bf16x8, am),
                                 Al = __builtin_bit_cast(c1_bf16x8, al);
-                const int chunk = ky * 2 + jc;
                 c1_bf16x8 Bh[2], Bm[2], Bl[2];
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
-                    const char* wp = wl + (cb * 32 + r) * C1_WROW + chunk * kChunkBytes + half * 16;
+                    const char* wp = wl + (cb * 32 + r) * WROW + chunk * CH + half * 16;
                     Bh[cb] = *reinterpret_cast<const c1_bf16x8*>(wp);
                     Bm[cb] = *reinterpret_cast<const c1_bf16x8*>(wp + 32);
                     Bl[cb] = *reinterpret_cast<const c1_bf16x8*>(wp + 64);
@@ -178,6 +206,10 @@ __global__ __launch_bounds__(512) void conv1_x6(const uint8_t* __restrict__ frag
         }
         // acc[cb][i]: channel cb*32 + r of pixel  32*wave + (i & 3) + 8 * (i >> 2) + 4 * half
         const int64_t pix0 = (int64_t)img * C1_OPIX + p0 + wave * 32;
+        if constexpr (H2) {   // the scales are powers of two: exact
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[cb] = (acc[cb] + accs[cb]) * (w_inv[cb * 32 + r] * (1.f / kC1PatchScale));
+        }
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
@@ -222,21 +254,52 @@ int make_conv1_x6_weights(relax_handle* h, const float* w_packed, int kpad, void
     return rc;
 }
 
-// frags uint8 [N,224,224,3] BGR -> out fp32 [N,112,112,64] (raw conv1), gap_groups [N*784][64] (16-pixel sums) or null
-int launch_conv1_x6(relax_handle* h, const uint8_t* frags, const void* w_sp3, float* out, float* gap_groups, int N, hipStream_t s) {
+// the same weights as two fp16 planes [64][224 * 4 B] with one power-of-two scale per filter (w_inv_out [64]: the inverse scales)
+int make_conv1_h2_weights(relax_handle* h, const float* w_packed, int kpad, void** w_h2_out, float** w_inv_out, std::vector<void*>& allocs) {
+    float *tmp = nullptr, *inv = nullptr;
+    void* q = nullptr;
+    if (hipMalloc(&tmp, sizeof(float) * 64 * C1_K) != hipSuccess || hipMalloc(&q, (size_t)64 * C1_K * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&inv), sizeof(float) * 64) != hipSuccess) {
+        if (tmp) (void)hipFree(tmp);
+        if (q) (void)hipFree(q);
+        set_error(h, "resnet50: hipMalloc of the conv1 fp16-plane weights failed");
+        return RELAX_ERR_NOMEM;
+    }
+    allocs.push_back(q);
+    allocs.push_back(inv);
+    hipLaunchKernelGGL(conv1_repack, dim3((64 * C1_K + 255) / 256), dim3(256), 0, nullptr, w_packed, kpad, tmp);
+    int rc = launch_to_h2_rows(h, tmp, C1_K, q, 64, C1_K, inv, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess && rc == RELAX_OK) {
+        set_error(h, "resnet50: conv1 weight conversion failed");
+        rc = RELAX_ERR_HIP;
+    }
+    (void)hipFree(tmp);
+    *w_h2_out = q;
+    *w_inv_out = inv;
+    return rc;
+}
+
+// frags uint8 [N,224,224,3] BGR -> out fp32 [N,112,112,64] (raw conv1), gap_groups [N*784][64] (16-pixel sums) or null.
+// w_inv != null: `w` holds fp16 planes (make_conv1_h2_weights) and the kernel runs its f16x2 form
+int launch_conv1_x6(relax_handle* h, const uint8_t* frags, const void* w_sp3, float* out, float* gap_groups, int N, hipStream_t s, const float* w_inv) {
     RELAX_REQUIRE(h, frags && w_sp3 && out && N > 0, "conv1_x6: bad arguments");
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_x6), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_LDS));
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_x6<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_LDS));
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_x6<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_LDS));
         attr_set[h->device] = true;
     }
     const int n_tiles = N * (C1_OPIX / C1_TILE);
     const double flops = 2.0 * N * (double)C1_OPIX * 64.0 * 147.0;
     const double bytes = (double)N * (C1_HW * C1_HW * 3 + (double)C1_OPIX * 64 * 4);
     int span;
-    RELAX_TRY(prof_begin(h, s, 2, flops, &span, bytes));
-    hipLaunchKernelGGL(conv1_x6, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), C1_LDS, s, frags, static_cast<const char*>(w_sp3), out, gap_groups,
-                       n_tiles);
+    RELAX_TRY(prof_begin(h, s, w_inv ? 5 : 2, flops, &span, bytes));
+    if (w_inv)
+        hipLaunchKernelGGL(conv1_x6<true>, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), C1_LDS, s, frags, static_cast<const char*>(w_sp3), out,
+                           gap_groups, n_tiles, w_inv);
+    else
+        hipLaunchKernelGGL(conv1_x6<false>, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), C1_LDS, s, frags, static_cast<const char*>(w_sp3), out,
+                           gap_groups, n_tiles, static_cast<const float*>(nullptr));
     if (hipGetLastError() != hipSuccess) { prof_abort(h, span); set_error(h, "conv1_x6: launch failed"); return RELAX_ERR_HIP; }
     RELAX_TRY(prof_end(h, s, span));
     return RELAX_OK;

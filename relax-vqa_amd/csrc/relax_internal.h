@@ -305,7 +305,9 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s);
 int launch_to_sp3(relax_handle* h, const float* x, int64_t ld, void* y, int64_t rows, int K, hipStream_t s);
 // conv1_x6.hip: ResNet-50 conv1 on the bf16x6 arithmetic, straight from the uint8 fragments
 int make_conv1_x6_weights(relax_handle* h, const float* w_packed, int kpad, void** w_sp3_out, std::vector<void*>& allocs);
-int launch_conv1_x6(relax_handle* h, const uint8_t* frags, const void* w_sp3, float* out, float* gap_groups, int N, hipStream_t s);
+int launch_conv1_x6(relax_handle* h, const uint8_t* frags, const void* w_sp3, float* out, float* gap_groups, int N, hipStream_t s,
+                    const float* w_inv = nullptr);   // w_inv: `w_sp3` holds fp16 planes and the f16x2 form runs
+int make_conv1_h2_weights(relax_handle* h, const float* w_packed, int kpad, void** w_h2_out, float** w_inv_out, std::vector<void*>& allocs);
 inline int launch_gemm_x6(relax_handle* h, const void* A_sp3, const void* W_sp3, const float* bias, const float* residual,
                           float* out, void* out_sp3, int M, int N, int K, int act, hipStream_t s) {
     ConvDescX6 d{};

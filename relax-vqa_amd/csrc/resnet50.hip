@@ -252,6 +252,7 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
     }
     // split planes for the bf16x6 kernels (made on the device from the packed fp32 copies): conv1 in its own K layout ...
     rc = make_conv1_x6_weights(h, rn.conv1.w, rn.conv1.Kpad, &rn.conv1.w_sp3, rn.allocs);
+    if (rc == RELAX_OK) rc = make_conv1_h2_weights(h, rn.conv1.w, rn.conv1.Kpad, &rn.conv1.w_h2, &rn.conv1.w_inv, rn.allocs);
     if (rc != RELAX_OK) { free_resnet(h); return rc; }
     // ... every other convolution as [Cout][K] rows
     for (Bottleneck& blk : rn.blocks) {
@@ -385,7 +386,9 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
         // kernel, the 16-pixel sums of the tap's spatial mean formed in its epilogue); from the max-pool on, every convolution input
         // travels as split planes written by its producer
         float* gap0 = T2 + kT2 * n;   // = the fp32 carving's gapws: free until the blocks carve the arena anew below
-        RELAX_TRY(launch_conv1_x6(h, frags, rn.conv1.w_sp3, bufA, layer_stack ? gap0 : nullptr, N, s));
+        const bool conv1_h2 = h->gemm.precision == 3 && h->gemm.rn_h2 && h->gemm.rn_h2_early && rn.conv1.w_h2;   // the stem on f16x2 as well
+        RELAX_TRY(launch_conv1_x6(h, frags, conv1_h2 ? rn.conv1.w_h2 : rn.conv1.w_sp3, bufA, layer_stack ? gap0 : nullptr, N, s,
+                                  conv1_h2 ? rn.conv1.w_inv : nullptr));
         if (layer_stack) RELAX_TRY(launch_gap_groups_finish(h, gap0, layer_stack, n_ls, 112 * 112, 64, RELAX_RN50_LAYER_STACK_DIM, s));
         if (taps_nchw && taps_nchw[0]) RELAX_TRY(launch_nhwc_to_nchw(h, bufA, taps_nchw[0], N, 112 * 112, 64, s));
         float* f32a = bufB;                                   // block outputs as fp32, where something needs them (ping-pong with f32b)
