@@ -519,9 +519,9 @@ def main():
                            "bf16x6": "gemm_x6 + conv1_x6 (six bf16 partial products per fp32 product on v_mfma_f32_16x16x32_bf16 / 32x32x16; achieved = EXECUTED bf16 flops = 6 x algorithmic, "
                                      "peak = dense bf16 MFMA)",
                            "f16x2": "gemm_h3 (f16x2: three fp16 partial products per fp32 product on v_mfma_f32_16x16x32_f16 - the ViT GEMMs and the "
-                                    "convolutions of ResNet-50's layer3 / layer4) and gemm_x6<H2> (the same products on v_mfma_f32_32x32x16_f16 - the 3x3 "
-                                    "convolutions of layer1 / layer2) + gemm_x6 + conv1_x6 (bf16x6: six bf16 partial products - ResNet-50's "
-                                    "stem and the 1x1 convolutions of layer1 / layer2); achieved = EXECUTED 16-bit MFMA flops of both "
+                                    "convolutions of ResNet-50's layer3 / layer4) and gemm_x6<H2> / conv1_x6<H2> (the same products on v_mfma_f32_32x32x16_f16 - the 3x3 "
+                                    "convolutions of layer1 / layer2, the stem) + gemm_x6 (bf16x6: six bf16 partial products - the 1x1 "
+                                    "convolutions of layer1 / layer2); achieved = EXECUTED 16-bit MFMA flops of both "
                                     "families (3 x / 6 x their algorithmic flops) over their summed launch time, peak = dense bf16 / fp16 MFMA (the same rate)"}[precision],
                 "achieved": executed, "peak": FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -598,9 +598,9 @@ def flow_stage_record(prof, elapsed_s, traffic_per_clip=None):
                                "avg_launch_us": it_ms * 1e3 / max(it_n, 1), "time_share_of_step": it_ms * 1e-3 / elapsed_s}}
     return rec
 H2_EXECUTED = 3.0   # fp16 MFMA products per fp32 product in gemm_h3 at K >= 256 ("h2_form" 1): A[lo] B[hi], A[hi] B[lo], A[hi] B[hi]
-DTYPE_TEXT = {"f16x2": "f32 (fp32-grade split-operand arithmetic, fp32 accumulate: the whole ViT (GEMMs and attention), ResNet-50's layer3 / layer4 and the 3x3 "
-                       "convolutions of its layer1 / layer2 on fp32 operands as 2 fp16 planes x a power-of-two scale, 3 partial products on the fp16 MFMA "
-                       "[f16x2]; ResNet-50's stem and the 1x1 convolutions of layer1 / layer2 on 3 bf16 planes, 6 partial products on the bf16 MFMA [bf16x6])",
+DTYPE_TEXT = {"f16x2": "f32 (fp32-grade split-operand arithmetic, fp32 accumulate: the whole ViT (GEMMs and attention), ResNet-50's stem, layer3 / layer4 and "
+                       "the 3x3 convolutions of layer1 / layer2 on fp32 operands as 2 fp16 planes x a power-of-two scale, 3 partial products on the fp16 MFMA "
+                       "[f16x2]; the 1x1 convolutions of ResNet-50's layer1 / layer2 (HBM-bound) on 3 bf16 planes, 6 partial products on the bf16 MFMA [bf16x6])",
               "fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into two bf16 terms, fp32 accumulate; reduced precision)",
               "bf16x6": "f32 (fp32 operands as 3 bf16 planes, 6 partial products on the bf16 MFMA, fp32 accumulate: fp32-grade)"}
 

@@ -73,7 +73,7 @@ int relax_reserve(relax_handle* h, int max_images);
  * batch (csrc/gemm_h2.hip, csrc/h2.h, tests/test_gpu_h2.py).  It covers the plain GEMMs with N % 256 == 0 (the whole ViT-B/16;
  * relax_op_gemm), the convolutions of ResNet-50's layer3 / layer4 (relax_op_conv2d_nhwc with Cin % 32 == 0, Cout % 256 == 0) and the
  * 3x3 convolutions of its layer1 / layer2 (K x K filters onto 64 / 128 channels, K >= 256: v_mfma_f32_32x32x16_f16 on the four-wave
- * tiles of csrc/gemm_x6.hip, the two small products in an accumulator of their own) and the ViT's attention (csrc/attention_h2.hip;
+ * tiles of csrc/gemm_x6.hip, the two small products in an accumulator of their own), its stem (csrc/conv1_x6.hip) and the ViT's attention (csrc/attention_h2.hip;
  * relax_op_attention); everything else runs as under 2.  0 = exact fp32 products (v_mfma_f32_32x32x2_f32); 2 = "bf16x6" (fp32-grade):
  * every fp32 operand is held as three bf16 numbers hi + mid + lo (exact) and a*b = the six partial products of weight
  * >= 2^-16 on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, two products per instruction; 32x32x16 on the 64 / 128-column
@@ -92,7 +92,7 @@ int relax_reserve(relax_handle* h, int max_images);
  * "h2_form" (default 1): 1 = the f16x2 loop with 32-deep K steps and three products for K >= 256; 0 = 16-deep steps, four products
  * ("h2_stages" = 3 or 4 LDS stages, same bits); 2 = 32-deep steps, four products at every K.  "rn_h2" (default 1): under
  * "gemm_precision" 3 ResNet-50's layer3 / layer4 run f16x2; 0 = the whole network on bf16x6 (the A/B switch of tests/test_gpu_h2.py).
- * "rn_h2_early" (default 1): with "rn_h2", the 3x3 convolutions of layer1 / layer2 run f16x2 as well (four-wave tiles); 0 = bf16x6 there.
+ * "rn_h2_early" (default 1): with "rn_h2", the stem and the 3x3 convolutions of layer1 / layer2 run f16x2 as well; 0 = bf16x6 there.
  * "att_h2" (default 1): under "gemm_precision" 3 the ViT's attention runs on fp16 planes too (csrc/attention_h2.hip: the qkv GEMM writes planes,
  * three partial products, K / V by LDS-DMA into the fragment images); 0 = the bf16x6 attention kernel on an fp32 qkv output (A/B switch).
  * "debug_poison" (test mode, default 0): every workspace request fills the buffer with 0xFF bytes

@@ -252,7 +252,7 @@ struct GemmOptions {
                            // per-image scales; 0 = the whole network on bf16x6 (the A/B switch of a test)
     int att_h2 = 1;        // "att_h2": under "gemm_precision" 3 the ViT's attention runs on fp16 planes too (attention_h2.hip: the qkv GEMM writes planes,
                            // three products, no conversion passes); 0 = attention_x6 on the fp32 qkv output (three bf16 planes, six products)
-    int rn_h2_early = 1;   // "rn_h2_early": with "rn_h2", the 3x3 convolutions of layer1 / layer2 (the MFMA-bound launches of those layers) run f16x2 too,
+    int rn_h2_early = 1;   // "rn_h2_early": with "rn_h2", the stem and the 3x3 convolutions of layer1 / layer2 (the MFMA-bound launches in front of layer3) run f16x2 too,
                            // on the four-wave tiles of gemm_x6.hip (conv1 writes its output as fp16 planes with the image's Hoelder scale); 0 = bf16x6 there
     int fp32_rows = 1;     // "x6_fp32_rows": bf16x6 contractions onto 64 / 128 columns take fp32 activation rows and split them in the K loop
                            // (ResNet-50 layer1 / layer2 block outputs travel as fp32); 0 = split planes everywhere (same bits, more bytes: the A/B switch of a test)
