@@ -13,8 +13,9 @@ One step = one pass of the hot path over one clip per rank, frames already resid
      per-clip mean -> [19779]; N > 1: RCCL all-gather of the per-clip vectors
 Synthetic frames and deterministic random-init weights of the named architectures (no network here).
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
-(the bf16x6 contraction kernel gemm_x6: fp32-grade products on the bf16 matrix cores, timed live with HIP events on the
-launch stream) and `cpu_baseline` (the CPU oracle, reference-faithful schedule, on a bounded sample of the same workload).
+(under the default arithmetic, f16x2, the plain split-plane GEMM gemm_h3<false,false,false> - the ViT's 49 GEMMs per pass: fp32-grade
+products on the fp16 matrix cores, timed live with HIP events on the launch stream; `frac` = ALGORITHMIC FLOPs / time / peak, the pipe's
+executed rate beside it as `pipe_busy_frac`; every contraction launch together under `all_contractions`) and `cpu_baseline` (the CPU oracle, reference-faithful schedule, on a bounded sample of the same workload).
 The exact-fp32-MFMA path (`--precision fp32`) is measured beside the headline as `exact_fp32_mode`.
 The default N = 1 run also times a few steps of the other BASELINE configurations (`other_workloads`: config 2, the config-4
 clip shape, the config-5 recipe at 2160p) so that the driver's record carries them, not only builder-run files.
@@ -122,6 +123,10 @@ def hbm_traffic_per_launch(workload, clips_per_step, precision):
     return None
 
 
+DOMINANT_KERNEL_MATCH = "relax::gemm_h3<false,false,false>"   # the plain f16x2 GEMM (three products): the ViT's 49 GEMMs per pass
+DOMINANT_TRAFFIC = None     # (bytes per launch, launches) of that kernel alone, set by measure_hbm_traffic
+
+
 FLOW_KERNELS = ("relax::flow_", "relax::poly_expansion", "relax::pyramid_fused", "relax::gauss", "relax::resize_linear_f32", "relax::update_matrices_k",
                 "relax::box_solve_fused", "relax::mag_minmax")
 
@@ -144,6 +149,7 @@ def measure_hbm_traffic(workload, clips_per_step, precision, split_k):
         return None, "this run is itself being profiled", None
     tmp = tempfile.mkdtemp(prefix="relax_pmc_", dir="/tmp")
     tot, flow_tot, launches = {}, {}, 0
+    dom_tot, dom_launches = {}, 0
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
@@ -155,23 +161,31 @@ def measure_hbm_traffic(workload, clips_per_step, precision, split_k):
             if res.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode}): {res.stderr[-300:]}", None
             total, flow_total, ids = 0.0, 0.0, set()
+            dom_total, dom_ids = 0.0, set()
             for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
                 if r["Counter_Name"] != counter:
                     continue
-                if any(k in r["Kernel_Name"] for k in ("relax::gemm_x6", "relax::conv1_x6", "relax::gemm_h2", "relax::gemm_h3")):
+                if any(k in r["Kernel_Name"] for k in ("relax::gemm_x6", "relax::conv1_x6", "relax::gemm_h2", "relax::gemm_h3", "relax::rn_block", "relax::stem_pool")):
                     total += float(r["Counter_Value"])
                     ids.add(r["Dispatch_Id"])
+                    if DOMINANT_KERNEL_MATCH in r["Kernel_Name"].replace(" ", ""):
+                        dom_total += float(r["Counter_Value"])
+                        dom_ids.add(r["Dispatch_Id"])
                 elif any(k in r["Kernel_Name"] for k in FLOW_KERNELS):
                     flow_total += float(r["Counter_Value"])
             tot[counter] = total * 1024.0          # KiB -> bytes
             flow_tot[counter] = flow_total * 1024.0
             launches = len(ids)
+            dom_tot[counter] = dom_total * 1024.0
+            dom_launches = len(dom_ids)
         if not launches:
             return None, "no contraction dispatch in the PMC pass", None
         flow_per_clip = (2.0 * flow_tot["FETCH_SIZE"] + flow_tot["WRITE_SIZE"]) / (2 * clips_per_step) if flow_tot["WRITE_SIZE"] > 0 else None
+        global DOMINANT_TRAFFIC
+        DOMINANT_TRAFFIC = ((2.0 * dom_tot["FETCH_SIZE"] + dom_tot["WRITE_SIZE"]) / dom_launches, dom_launches) if dom_launches else None
         return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / launches, (
             f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, one child pass each (1 warm-up + 1 step), "
-            f"(2 x FETCH_SIZE + WRITE_SIZE) over the {launches} gemm_x6 / conv1_x6 / gemm_h3 dispatches of the pass"), flow_per_clip
+            f"(2 x FETCH_SIZE + WRITE_SIZE) over the {launches} contraction dispatches of the pass (gemm_h3 / gemm_x6 / conv1_x6 / the fused ResNet blocks)"), flow_per_clip
     except subprocess.TimeoutExpired:
         return None, "a rocprofv3 pass did not finish in 150 s", None
     finally:
@@ -239,10 +253,11 @@ def main():
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra measurement of the other precision (exact fp32)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the extra pinned-host-to-device measurement")
     ap.add_argument("--precision", default="f16x2", choices=["fp32", "bf16x3", "bf16x6", "f16x2"],
-                    help="arithmetic of the contraction kernels for the headline loop.  f16x2 (default): the plain GEMMs with N %% 256 == 0 "
-                         "(the whole ViT) take fp32 operands as two fp16 planes of a power-of-two multiple of themselves, three (K >= 256) or "
-                         "four partial products on the fp16 MFMA, fp32 accumulate; the convolutions and attention run bf16x6: fp32 operands as "
-                         "three bf16 planes, six partial products.  Both fp32-grade: error against fp64 no larger than the fp32 FMA chain's "
+                    help="arithmetic of the contraction kernels for the headline loop.  f16x2 (default): fp32 operands as two fp16 planes of a "
+                         "power-of-two multiple of themselves, three (K >= 256) or four partial products on the fp16 MFMA, fp32 accumulate - the "
+                         "whole ViT (GEMMs and attention) and ResNet-50's stem, 3x3 convolutions, layer3 / layer4 (and the fused blocks of layer1 / "
+                         "layer2 where enabled); what has no f16x2 kernel runs bf16x6: fp32 operands as three bf16 planes, six partial products.  "
+                         "Both fp32-grade: error against fp64 no larger than the fp32 FMA chain's "
                          "(tests/test_gpu_h2.py, tests/test_gpu_x6.py).  bf16x6: that arithmetic everywhere; fp32: exact fp32 MFMA; bf16x3: "
                          "lower precision, never the headline")
     ap.add_argument("--clips-per-step", type=int, default=0,
@@ -327,7 +342,7 @@ def main():
     precision = eng.precision()          # what the ENGINE computes in (read back from the library, not the flag)
     assert precision == args.precision, (precision, args.precision)
     x3, h2 = precision == "bf16x3", precision == "f16x2"
-    x6 = precision in ("bf16x6", "f16x2")      # the split-operand kernels (under f16x2 the convolutions and attention stay bf16x6)
+    x6 = precision in ("bf16x6", "f16x2")      # the split-operand kernels (under f16x2 only the launches without an f16x2 kernel stay bf16x6)
     if h2:
         assert eng.get_option("h2_form") == 1  # (three products for K >= 256: every f16x2 launch of these workloads; H2_EXECUTED below)
         assert eng.get_option("rn_h2") == 1 and eng.get_option("rn_h2_early") == 1 and eng.get_option("att_h2") == 1
@@ -385,7 +400,8 @@ def main():
         elapsed = time.perf_counter() - t0
         prof = {"gemm": eng.profile_read(3 if x6 else 0), "frag": eng.profile_read(1), "gemm_bytes": eng.profile_read(4 if x6 else 2),
                 "flow": eng.profile_read(5), "flow_stage": eng.profile_read(6), "other": eng.profile_read(0 if x6 else 3),
-                "h2": eng.profile_read(7), "h2_bytes": eng.profile_read(8)}
+                "h2": eng.profile_read(7), "h2_bytes": eng.profile_read(8),
+                "dom": eng.profile_read(9), "dom_bytes": eng.profile_read(10)}
         eng.profile_enable(False)
         return elapsed, out, prof
 
@@ -465,12 +481,7 @@ def main():
             t_ms = g_ms + q_ms
             rec = {"value": 3 * b_o / e_o, "unit": "clips/s", "ms_per_step": e_o / 3 * 1e3, "clips_per_step": b_o, "steps": 3,
                    "feature_dim": dim_o,
-                   "roofline": {"bound": "mfma", "kernel": "gemm_x6 + conv1_x6 (bf16x6)" + (" + gemm_h3 (f16x2)" if q_n else ""), "unit": "TFLOP/s",
-                                "peak": BF16_MATRIX_PEAK_TFLOPS,
-                                "achieved": (6 * g_flops + H2_EXECUTED * q_flops) / (t_ms * 1e-3) / 1e12,
-                                "frac": (6 * g_flops + H2_EXECUTED * q_flops) / (t_ms * 1e-3) / 1e12 / BF16_MATRIX_PEAK_TFLOPS,
-                                "algorithmic_tflops": (g_flops + q_flops) / (t_ms * 1e-3) / 1e12,
-                                "kernel_time_share_of_step": t_ms * 1e-3 / e_o}}
+                   "roofline": contraction_roofline(g_ms, g_flops, q_ms, q_flops, 6.0, e_o, prof_o.get("dom"))}
             fs = flow_stage_record(prof_o, e_o)
             if fs is not None:
                 rec["roofline_flow_stage"] = fs
@@ -512,38 +523,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload_text(args.workload), "clips_per_step_per_gpu": B, "pairs_per_clip": T,
                        "feature_dim": feat_dim, "parallelism": f"clip-sharded dp{world}, RCCL all-gather of per-clip vectors"},
-            "roofline": {
-                "bound": "mfma",
-                "kernel": {"fp32": "conv_gemm_f32 (fp32 implicit-GEMM conv / GEMM, v_mfma_f32_32x32x2_f32)",
-                           "bf16x3": "conv_gemm_f32<..., bf16x3> (3 x v_mfma_f32_32x32x16_bf16 per fp32 product; achieved = EXECUTED flops = 3 x algorithmic)",
-                           "bf16x6": "gemm_x6 + conv1_x6 (six bf16 partial products per fp32 product on v_mfma_f32_16x16x32_bf16 / 32x32x16; achieved = EXECUTED bf16 flops = 6 x algorithmic, "
-                                     "peak = dense bf16 MFMA)",
-                           "f16x2": "gemm_h3 (f16x2: three fp16 partial products per fp32 product on v_mfma_f32_16x16x32_f16 - the ViT GEMMs and the "
-                                    "convolutions of ResNet-50's layer3 / layer4) and gemm_x6<H2> / conv1_x6<H2> (the same products on v_mfma_f32_32x32x16_f16 - the 3x3 "
-                                    "convolutions of layer1 / layer2, the stem) + gemm_x6 (bf16x6: six bf16 partial products - the 1x1 "
-                                    "convolutions of layer1 / layer2); achieved = EXECUTED 16-bit MFMA flops of both "
-                                    "families (3 x / 6 x their algorithmic flops) over their summed launch time, peak = dense bf16 / fp16 MFMA (the same rate)"}[precision],
-                "achieved": executed, "peak": FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": executed / (FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS),
-                "algorithmic_tflops": achieved,
-                "algorithmic_frac": achieved / (FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS),
-                "frac_note": "frac = executed matrix-pipe FLOPs / the dense 16-bit MFMA peak (how busy the pipe is); algorithmic_frac = the fp32 "
-                             "FLOPs of the contractions (2 x MAC) / the same peak (what the arithmetic costs: 3 or 6 pipe products per fp32 product)",
-                "families": {"f16x2": {"launches": h2_launches, "ms_per_step": h2_ms / args.steps,
-                                       "algorithmic_tflops": h2_flops / (h2_ms * 1e-3) / 1e12 if h2_ms > 0 else None, "executed_per_algorithmic": H2_EXECUTED},
-                             "bf16x6" if x6 else precision: {"launches": x6_launches, "ms_per_step": x6_ms / args.steps,
-                                                             "algorithmic_tflops": x6_flops / (x6_ms * 1e-3) / 1e12 if x6_ms > 0 else None,
-                                                             "executed_per_algorithmic": mult}},
-                "traffic": traffic, "traffic_note": traffic_note,
-                "algorithmic_bytes_per_launch": gemm_alg_bytes / max(gemm_launches, 1),
-                "launches": gemm_launches, "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
-                "algorithmic_gflop_per_launch": gemm_flops / max(gemm_launches, 1) / 1e9,
-                "kernel_time_share_of_step": gemm_ms * 1e-3 / elapsed,
-                "other_contraction_kernel": {"what": "contraction launches on the other kernel family (none under bf16x6 since conv1 has its own "
-                                                     "bf16x6 kernel, conv1_x6, counted with gemm_x6 above)" if x6 else None,
-                                             "ms_per_step": other_ms / args.steps, "launches": other_launches},
-            },
+            "roofline": headline_roofline(precision, x6, x6_ms, x6_flops, x6_launches, h2_ms, h2_flops, h2_launches, mult, gemm_alg_bytes, elapsed,
+                                          prof["dom"], prof["dom_bytes"], traffic, traffic_note, other_ms, other_launches, args.steps),
             "roofline_fragment_stage": {
                 "bound": "hbm", "kernel": "patch_score_aligned<pair> (fused absdiff + 16x16 patch sums)",
                 "achieved": frag_bytes / (frag_ms * 1e-3) / 1e9 if frag_ms > 0 else 0.0, "peak": HBM_PEAK_GBPS,
@@ -571,6 +552,79 @@ def main():
     if world > 1:
         rdist.barrier()
         dist.destroy_process_group()
+
+
+KERNEL_TEXT = {
+    "fp32": "conv_gemm_f32 (fp32 implicit-GEMM conv / GEMM, v_mfma_f32_32x32x2_f32)",
+    "bf16x3": "conv_gemm_f32<..., bf16x3> (3 x v_mfma_f32_32x32x16_bf16 per fp32 product)",
+    "bf16x6": "gemm_x6 + conv1_x6 (six bf16 partial products per fp32 product on v_mfma_f32_16x16x32_bf16 / 32x32x16)",
+    "f16x2": "every contraction launch: gemm_h3 (f16x2: three fp16 partial products per fp32 product on v_mfma_f32_16x16x32_f16 - the ViT GEMMs, ResNet-50's "
+             "layer3 / layer4), the f16x2 kernels of ResNet-50's stem, layer1 and layer2 (v_mfma_f32_32x32x16_f16) and what is left on gemm_x6 (bf16x6, six products)"}
+FRAC_NOTE = ("frac = achieved / peak with achieved = ALGORITHMIC fp32 FLOPs (2 x MAC of the contraction) / launch time (SURVEY 8(d)); pipe_busy_frac = the 16-bit "
+             "matrix-pipe FLOPs actually executed (3 per fp32 product under f16x2, 6 under bf16x6) / the same peak: how busy the pipe is, not what the kernel delivers")
+
+
+def contraction_roofline(x6_ms, x6_flops, h2_ms, h2_flops, x6_mult, elapsed_s, dom=None, peak=None):
+    """{bound, achieved, peak, frac, ...} of all contraction launches of a timed region: achieved = algorithmic TFLOP/s over their summed
+    launch time; the executed (pipe) rate beside it."""
+    peak = peak or BF16_MATRIX_PEAK_TFLOPS
+    t_ms = x6_ms + h2_ms
+    alg = (x6_flops + h2_flops) / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+    exe = (x6_mult * x6_flops + H2_EXECUTED * h2_flops) / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+    rec = {"bound": "mfma", "kernel": "all contraction launches (f16x2 + bf16x6 families)" if h2_ms > 0 else "all contraction launches", "unit": "TFLOP/s", "peak": peak,
+           "achieved": alg, "frac": alg / peak, "executed_tflops": exe, "pipe_busy_frac": exe / peak,
+           "kernel_time_share_of_step": t_ms * 1e-3 / elapsed_s}
+    if dom is not None and dom[2]:
+        rec["dominant_kernel"] = dominant_record(dom, None, elapsed_s, None)
+    return rec
+
+
+def dominant_record(dom, dom_bytes, elapsed_s, traffic):
+    """gemm_h3<false,false,false> alone (span kind 6: the plain f16x2 GEMMs = the ViT's): recomputable from profiles/*_kernel_stats.csv."""
+    d_ms, d_flops, d_n = dom
+    alg = d_flops / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
+    rec = {"kernel": "gemm_h3<false,false,false> (the plain f16x2 GEMM: the ViT's 49 GEMMs per pass, three fp16 products per fp32 product)",
+           "launches": d_n, "avg_launch_us": d_ms * 1e3 / max(d_n, 1), "algorithmic_gflop_per_launch": d_flops / max(d_n, 1) / 1e9,
+           "achieved": alg, "unit": "TFLOP/s", "peak": BF16_MATRIX_PEAK_TFLOPS, "frac": alg / BF16_MATRIX_PEAK_TFLOPS,
+           "executed_tflops": H2_EXECUTED * alg, "pipe_busy_frac": H2_EXECUTED * alg / BF16_MATRIX_PEAK_TFLOPS,
+           "time_share_of_step": d_ms * 1e-3 / elapsed_s}
+    if dom_bytes is not None:
+        rec["algorithmic_bytes_per_launch"] = dom_bytes[1] / max(d_n, 1)
+    if traffic is not None:
+        rec["traffic"] = traffic[0]
+        rec["traffic_dispatches_in_pmc_pass"] = traffic[1]
+        if dom_bytes is not None and dom_bytes[1] > 0:
+            rec["traffic_over_algorithmic"] = traffic[0] / (dom_bytes[1] / max(d_n, 1))
+    return rec
+
+
+def headline_roofline(precision, x6, x6_ms, x6_flops, x6_launches, h2_ms, h2_flops, h2_launches, mult, alg_bytes, elapsed_s, dom, dom_bytes,
+                      traffic, traffic_note, other_ms, other_launches, steps):
+    """The bench line's `roofline`.  Under f16x2 with a ViT in the workload the dominant kernel is gemm_h3<false,false,false> and the
+    top-level figures are THAT kernel's (algorithmic FLOPs per launch / its average launch time, measured live with HIP events on the
+    launch stream); `all_contractions` holds the aggregate over every contraction launch of both families."""
+    peak = FP32_MATRIX_PEAK_TFLOPS if precision == "fp32" else BF16_MATRIX_PEAK_TFLOPS
+    allc = contraction_roofline(x6_ms, x6_flops, h2_ms, h2_flops, mult, elapsed_s, None, peak)
+    n_all = x6_launches + h2_launches
+    allc.update({"kernel": KERNEL_TEXT[precision], "launches": n_all, "avg_launch_us": (x6_ms + h2_ms) * 1e3 / max(n_all, 1),
+                 "algorithmic_gflop_per_launch": (x6_flops + h2_flops) / max(n_all, 1) / 1e9,
+                 "algorithmic_bytes_per_launch": alg_bytes / max(n_all, 1), "traffic": traffic, "traffic_note": traffic_note,
+                 "families": {"f16x2": {"launches": h2_launches, "ms_per_step": h2_ms / steps,
+                                        "algorithmic_tflops": h2_flops / (h2_ms * 1e-3) / 1e12 if h2_ms > 0 else None, "executed_per_algorithmic": H2_EXECUTED},
+                              "bf16x6" if x6 else precision: {"launches": x6_launches, "ms_per_step": x6_ms / steps,
+                                                              "algorithmic_tflops": x6_flops / (x6_ms * 1e-3) / 1e12 if x6_ms > 0 else None,
+                                                              "executed_per_algorithmic": mult}},
+                 "other_contraction_kernel": {"ms_per_step": other_ms / steps, "launches": other_launches}})
+    if dom[2] and dom[0] > 0.5 * (x6_ms + h2_ms):       # one kernel holds most of the contraction time: the line is about it
+        rec = dominant_record(dom, dom_bytes, elapsed_s, DOMINANT_TRAFFIC)
+        rec["bound"] = "mfma"
+        rec.setdefault("traffic", None)
+        rec["frac_note"] = FRAC_NOTE
+        rec["kernel_time_share_of_step"] = rec["time_share_of_step"]
+        rec["all_contractions"] = allc
+        return rec
+    allc["frac_note"] = FRAC_NOTE
+    return allc
 
 
 FLOW_KERNEL = ("flow_iteration (one Farneback iteration per launch: matrix entries from the two polynomial expansions and the flow, 15x15 box "

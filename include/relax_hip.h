@@ -258,7 +258,8 @@ int relax_segment_mean(relax_handle* h, const float* src, int64_t src_stride, in
  * kernel is bracketed by HIP events on the caller's stream.  relax_profile_read synchronises those events and
  * returns totals since the last enable: kind 0 = fp32 / bf16x3 contraction launches (work = algorithmic FLOPs), kind 1 =
  * patch score (work = bytes), kind 2 = kind 0 again with work = algorithmic HBM bytes (operands and results touched once),
- * kind 3 / 4 = the same two views of the bf16x6 contraction launches, kind 7 / 8 = those of the f16x2 launches, kind 5 = flow_iteration, the dominant kernel of the
+ * kind 3 / 4 = the same two views of the bf16x6 contraction launches, kind 7 / 8 = those of the f16x2 launches, kind 9 / 10 = those of the
+ * plain f16x2 GEMMs alone (gemm_h3 without the convolution form: the ViT's GEMMs, the dominant kernel of the headline), kind 5 = flow_iteration, the dominant kernel of the
  * Farneback stage (one launch per iteration; work = algorithmic bytes: 56 per pixel, level and iteration), kind 6 = the whole
  * Farneback stage of a relax_optical_flow chunk, first launch to last (work = the algorithmic bytes of all its kernels: every
  * kernel's inputs read once and outputs written once; launches = chunks). */

@@ -297,15 +297,18 @@ int relax_profile_enable(relax_handle* h, int on) {
 
 int relax_profile_read(relax_handle* h, int kind, double* total_ms, double* total_work, int64_t* launches) {
     if (!h) return RELAX_ERR_INVALID;
-    RELAX_REQUIRE(h, kind >= 0 && kind <= 8, "relax_profile_read: kind must be 0..8");
+    RELAX_REQUIRE(h, kind >= 0 && kind <= 10, "relax_profile_read: kind must be 0..10");
     RELAX_TRY(prof_drain(h));
     // read kind -> (span kind, which total): 2 and 4 return the algorithmic HBM bytes of the contraction launches
-    static const int span_of[9] = {0, 1, 0, 2, 2, 3, 4, 5, 5};
+    // (7 / 8: every f16x2 launch = span kinds 5 + 6; 9 / 10: the plain f16x2 GEMMs alone = span kind 6)
+    static const int span_of[11] = {0, 1, 0, 2, 2, 3, 4, 5, 5, 6, 6};
     const int k = span_of[kind];
-    const bool bytes = kind == 2 || kind == 4 || kind == 8;
-    if (total_ms) *total_ms = h->prof.total_ms[k];
-    if (total_work) *total_work = bytes ? h->prof.total_bytes[k] : h->prof.total_work[k];
-    if (launches) *launches = h->prof.launches[k];
+    const bool bytes = kind == 2 || kind == 4 || kind == 8 || kind == 10;
+    const Profiler& p = h->prof;
+    const bool both = kind == 7 || kind == 8;
+    if (total_ms) *total_ms = p.total_ms[k] + (both ? p.total_ms[6] : 0.0);
+    if (total_work) *total_work = bytes ? p.total_bytes[k] + (both ? p.total_bytes[6] : 0.0) : p.total_work[k] + (both ? p.total_work[6] : 0.0);
+    if (launches) *launches = p.launches[k] + (both ? p.launches[6] : 0);
     return RELAX_OK;
 }
 

@@ -1059,6 +1059,8 @@ int launch_gemm_h2(relax_handle* h, const GemmDescH2& d, hipStream_t s) {
     RELAX_REQUIRE(h, p.K % 16 == 0 && p.N % 256 == 0, "f16x2 gemm: K=%d must be a multiple of 16 and N=%d of 256", p.K, p.N);
     RELAX_REQUIRE(h, (int64_t)p.K * 4 * 256 < kH2MaxRecords, "f16x2 gemm: K=%d too large", p.K);
     RELAX_REQUIRE(h, d.a && d.w && d.colscale && (d.out || d.out_h2 || d.gap_groups), "f16x2 gemm: missing operand / no output requested");
+    // (the running maximum is an integer atomicMax on float BITS: ordered only for non-negative values, i.e. behind a ReLU - as gemm_x6.hip requires)
+    RELAX_REQUIRE(h, !d.amax_out || d.act == 1, "f16x2 gemm: amax_out needs act == 1 (ReLU): the bit-ordered maximum is valid for non-negative outputs only");
     RELAX_REQUIRE(h, !d.out_h2 || d.img_out_scale || (d.out_scale > 0.f && d.out_scale < 3.0e38f), "f16x2 gemm: the plane output needs its scale");
     auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     RELAX_REQUIRE(h, aligned16(d.a) && aligned16(d.w) && aligned16(d.colscale) && aligned16(d.bias) && aligned16(d.residual) && aligned16(d.out) &&
@@ -1069,7 +1071,7 @@ int launch_gemm_h2(relax_handle* h, const GemmDescH2& d, hipStream_t s) {
     const double bytes = 4.0 * ((conv ? (double)d.Nimg * d.H * d.W * d.Cin : (double)p.M * p.K) + (double)p.N * p.K) +
                          (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_h2 ? 4.0 : 0.0) + (d.residual ? 4.0 : 0.0));
     int span;
-    RELAX_TRY(prof_begin(h, s, 5, flops, &span, bytes));
+    RELAX_TRY(prof_begin(h, s, conv ? 5 : 6, flops, &span, bytes));   // (kind 6: the plain GEMMs - the ViT - alone: the dominant kernel of the headline)
     // "h2_form": 1 (default) = 32-k steps with three products for K >= 256 and four below (and 16-k steps for K % 32 != 0);
     // 0 = 16-k steps, four products ("h2_stages" LDS stages); 2 = 32-k steps, four products at every K
     int rc;

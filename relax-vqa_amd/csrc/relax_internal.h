@@ -218,8 +218,8 @@ struct Profiler {
     std::vector<ProfSpan> spans;
     std::vector<hipEvent_t> pool;
     // span kinds: 0 fp32 / bf16x3 contraction, 1 patch score, 2 bf16x6 contraction, 3 Farneback iteration kernel, 4 the whole Farneback stage,
-    // 5 f16x2 contraction (gemm_h2.hip)
-    static constexpr int kKinds = 6;
+    // 5 f16x2 contraction, convolution form (gemm_h2.hip, gemm_x6<H2>, conv1_x6<H2>, the fused blocks), 6 f16x2 plain GEMMs (the ViT's: the dominant kernel)
+    static constexpr int kKinds = 7;
     double total_ms[kKinds] = {};
     double total_work[kKinds] = {};
     double total_bytes[kKinds] = {};

@@ -74,13 +74,25 @@ class _PinnedGate:
         self.cap = int(cap)
         self.in_use = 0
         self.peak = 0
+        self.closed = False
         self._next = 0
         self._served = set()
         self._cv = threading.Condition()
 
     def start_pass(self):
+        """A new pass: no loader of an earlier pass is alive any more (the pass's `finally` shut its pool down and handed every buffer
+        back), so whatever a failed pass left in the books is dropped here rather than shrinking the budget for good."""
         with self._cv:
             self._next, self._served = 0, set()
+            self.in_use = 0
+            self.closed = False
+            self._cv.notify_all()
+
+    def close(self):
+        """The pass is over (or is being torn down after an error in the driver thread): nobody will hand bytes back any more, so a
+        loader still waiting for its turn must not wait forever - acquire raises from now on."""
+        with self._cv:
+            self.closed = True
             self._cv.notify_all()
 
     def _advance(self, seq):
@@ -91,10 +103,16 @@ class _PinnedGate:
                 self._next += 1
         self._cv.notify_all()
 
-    def acquire(self, seq, n):
+    def acquire(self, seq, n, own=0):
+        """own: bytes the asking clip holds already (a loader that calls `alloc` more than once): they do not count against "nothing
+        at all is held", or a clip larger than the cap would wait for itself."""
         with self._cv:
-            while not ((seq is None or seq <= self._next) and (self.in_use == 0 or self.in_use + n <= self.cap)):
+            while not ((seq is None or seq <= self._next) and (self.in_use - own <= 0 or self.in_use + n <= self.cap)):
+                if self.closed:
+                    raise RuntimeError("the pass was torn down while this clip waited for pinned staging memory")
                 self._cv.wait(0.05)
+            if self.closed:
+                raise RuntimeError("the pass was torn down while this clip waited for pinned staging memory")
             self.in_use += n
             self.peak = max(self.peak, self.in_use)
             if seq is not None:
@@ -106,7 +124,7 @@ class _PinnedGate:
 
     def release(self, n):
         with self._cv:
-            self.in_use -= n
+            self.in_use = max(self.in_use - n, 0)
             self._cv.notify_all()
 
 
@@ -121,6 +139,7 @@ class ClipStager:
     def __init__(self, device, world=1):
         self.device = device
         self.on_gpu = device.type == "cuda"
+        self.gated = self.on_gpu                     # the pinned budget applies (tests switch it on for a CPU stand-in)
         self._lock = threading.Lock()
         self._pinned_free = {}                       # nbytes -> [pinned flat uint8 tensors]
         self._pooled_bytes = 0
@@ -140,16 +159,25 @@ class ClipStager:
             self._turn = 0
 
     # ---- loader-thread side ------------------------------------------------------------------------------
-    def _take_pinned(self, n, seq=None):
+    def _take_pinned(self, n, seq=None, own=0):
         """A flat pinned uint8 buffer of n bytes, once the budget allows it (in clip order: _PinnedGate): from the pool, else a new
-        allocation - made by the CALLING (loader) thread, which runs on the CPUs of the GPU's NUMA node, so the pages land there."""
-        if self.on_gpu:                              # (a CPU 'device' uses the clips where they lie: nothing is pinned, nothing is budgeted)
-            self.gate.acquire(seq, n)
+        allocation - made by the CALLING (loader) thread, which runs on the CPUs of the GPU's NUMA node, so the pages land there.
+        Pooled (idle) and handed-out buffers count against ONE budget: before a new allocation, idle buffers of other sizes are
+        dropped until pool + in flight fit this rank's share again."""
+        if self.gated:                               # (a CPU 'device' uses the clips where they lie: nothing is pinned, nothing is budgeted)
+            self.gate.acquire(seq, n, own)
         with self._lock:
             free = self._pinned_free.get(n)
             buf = free.pop() if free else None
             if buf is not None:
                 self._pooled_bytes -= n
+            else:
+                for size in sorted(self._pinned_free, reverse=True):
+                    lst = self._pinned_free[size]
+                    while lst and self._pooled_bytes + self.gate.in_use > self.pool_limit_bytes:
+                        lst.pop()
+                        self._pooled_bytes -= size
+                        self.pinned_live_bytes -= size
         if buf is None:
             buf = torch.empty(n, dtype=torch.uint8, pin_memory=self.on_gpu)
             with self._lock:
@@ -157,10 +185,10 @@ class ClipStager:
                 self.pinned_peak_bytes = max(self.pinned_peak_bytes, self.pinned_live_bytes)
         return buf
 
-    def alloc_pinned(self, shape, seq=None):
+    def alloc_pinned(self, shape, seq=None, own=0):
         """-> (uint8 tensor of `shape` over pinned memory, buffer to hand back): what a loader decodes into (the `alloc` protocol)."""
         n = int(np.prod(shape))
-        buf = self._take_pinned(n, seq)
+        buf = self._take_pinned(n, seq, own)
         return buf.view(tuple(int(d) for d in shape)), buf
 
     def to_pinned(self, t, seq=None):
@@ -178,7 +206,7 @@ class ClipStager:
     def give_back(self, bufs):
         """Buffers whose copies have landed (or that were never used) go back to the pool - their bytes back to the budget -, up to this
         rank's share of the node's pinned budget; beyond it they are dropped (unpinned and freed)."""
-        if self.on_gpu:
+        if self.gated:
             for b in bufs:
                 if b is not None:
                     self.gate.release(b.numel())
@@ -186,7 +214,7 @@ class ClipStager:
             for b in bufs:
                 if b is None:
                     continue
-                if self._pooled_bytes + b.numel() <= self.pool_limit_bytes:
+                if self._pooled_bytes + self.gate.in_use + b.numel() <= self.pool_limit_bytes:
                     self._pinned_free.setdefault(b.numel(), []).append(b)
                     self._pooled_bytes += b.numel()
                 else:
@@ -398,6 +426,7 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         ("err", message).  Never raises.  Whatever happens, the clip's turn at the pinned budget is taken or given up (the clips
         behind it wait for that)."""
         seq, took = seq_of[i], [False]
+        handed, keep = [], [None]                       # pinned buffers this call's `alloc` gave out; the one the clip is returned in
 
         def my_turn():
             first, took[0] = not took[0], True
@@ -413,17 +442,12 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
                             return ("rows", np.ascontiguousarray(rows))
                     except Exception:                   # noqa: BLE001 - truncated / foreign file: recompute and overwrite it
                         pass
-            handed = []                                 # pinned buffers this call's `alloc` gave out
             if takes_alloc:
                 def alloc(shape):
-                    view, buf = stager.alloc_pinned(shape, my_turn())
+                    view, buf = stager.alloc_pinned(shape, my_turn(), own=sum(b.numel() for b in handed))
                     handed.append(buf)
                     return view.numpy()                 # (shares the pinned memory)
-                try:
-                    clip = get(i, alloc=alloc)
-                except Exception:
-                    stager.give_back(handed)
-                    raise
+                clip = get(i, alloc=alloc)
             else:
                 clip = get(i)
             _check_clip(clip)
@@ -431,15 +455,17 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
             if t.is_cuda or stager is None:
                 return ("clip", t, None)
             if handed and t.is_contiguous() and any(t.data_ptr() == b.data_ptr() for b in handed):
-                keep = next(b for b in handed if b.data_ptr() == t.data_ptr())
-                stager.give_back([b for b in handed if b is not keep])
-                return ("clip", t, keep)                # decoded in place: pinned already, nothing to stage
-            stager.give_back(handed)
+                keep[0] = next(b for b in handed if b.data_ptr() == t.data_ptr())
+                return ("clip", t, keep[0])             # decoded in place: pinned already, nothing to stage
             t, buf = stager.to_pinned(t.contiguous(), my_turn())
             return ("clip", t, buf)
         except Exception as e:                          # noqa: BLE001 - the contract: the clip fails, the run goes on
             return ("err", f"{type(e).__name__}: {e}")
         finally:
+            # every exit - a loader that raised, a clip that fails _check_clip, a loader that returned a device tensor or a copy: the
+            # buffers `alloc` handed out go back to the budget, except the one the returned clip lives in
+            if handed:
+                stager.give_back([b for b in handed if b is not keep[0]])
             if stager is not None and not took[0]:
                 stager.gate.skip(seq)
 
@@ -546,8 +572,27 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         if stager is not None:
             stager.reap(wait=True)
     finally:
+        # teardown, also when something escaped the driver loop (a HIP error, a stand-in engine, KeyboardInterrupt): loaders that wait
+        # for pinned memory nobody will hand back must not keep pool.shutdown - and so the exception, and so the other ranks at the
+        # all-gather - waiting: close the gate first (their acquire raises -> an "err" result), then collect what is still held
+        if stager is not None:
+            stager.gate.close()
         if pool is not None:
             pool.shutdown(wait=True, cancel_futures=True)
+        if stager is not None:
+            left = []
+            for futs in futures.values():               # loaded but never consumed: their pinned buffers
+                for f in futs:
+                    if f.done() and not f.cancelled() and f.exception() is None:
+                        r = f.result()
+                        if r[0] == "clip" and r[2] is not None:
+                            left.append(r[2])
+            futures.clear()
+            try:
+                stager.reap(wait=True)
+            except Exception:                           # noqa: BLE001 - a dead device: drop the records, the buffers are garbage-collected
+                stager._landing = []
+            stager.give_back(left)
         if restore_split is not None:
             engine.set_option("gemm_split_k", restore_split)
     matrix = rdist.gather_clip_vectors(local, n_clips, rank, world, group)

@@ -128,8 +128,8 @@ class RelaxEngine:
         values (hi + mid + lo, exact) and a*b = the six partial products of weight >= 2^-16 on the bf16 MFMA with fp32
         accumulation - as close to the exact result as the fp32 FMA chain at 6/16 of its matrix cycles.  'f16x2' (fp32-grade): each
         fp32 operand as two fp16 values of a power-of-two multiple of itself (22 bits; scales from bounds that hold for every input,
-        csrc/h2.h) and all four partial products in two fp16 MFMAs - the plain GEMMs with N % 256 == 0 (the whole ViT-B); convolutions
-        and attention run bf16x6 under it.  'bf16x3' (opt-in, lower precision): two bf16 values, three products, ~1e-5 norm-relative
+        csrc/h2.h), three partial products (four below K = 256) on the fp16 MFMA - the whole ViT-B (GEMMs and attention), ResNet-50's
+        stem, 3x3 convolutions and layer3 / layer4; the launches without an f16x2 kernel run bf16x6 under it.  'bf16x3' (opt-in, lower precision): two bf16 values, three products, ~1e-5 norm-relative
         (the parity bar is 1e-3)."""
         self.set_option("gemm_precision", self.PRECISIONS[mode])
 

@@ -338,6 +338,97 @@ def test_pinned_budget_is_granted_in_clip_order_and_never_locks_up():
     assert order == [k for k in range(12) if k not in skipped] and gate.in_use == 0 and gate.peak <= 250
 
 
+def _gated_engine(cap):
+    """A FakeEngine whose stager applies the pinned budget although the 'device' is the CPU (what a GPU run does; the buffers are
+    plain host memory here)."""
+    eng = FakeEngine()
+    st = dataset.ClipStager(eng.device, 1)
+    st.gated = True
+    st.pool_limit_bytes = cap
+    st.gate.cap = cap
+    eng._clip_stager = st
+    return eng, st
+
+
+def test_alloc_buffers_of_clips_that_fail_after_loading_go_back_to_the_budget():
+    """A loader that decodes into `alloc` memory and then returns something the driver refuses (a malformed clip, a copy, two
+    allocations) must not keep its bytes: after the pass nothing is in use, and a second pass over the same stager runs."""
+    _patched()
+    ids = [0, 1, 6, 2, 4, 6, 7, 8]                              # _clip(6) is malformed ([T,1,...]): _check_clip refuses it AFTER the decode
+
+    def loader(i, alloc):
+        c = np.asarray(_clip(ids[i]))
+        out = alloc(c.shape)
+        np.copyto(out, c)
+        if i == 3:                                              # a second allocation by the same clip, and a COPY returned: both go back
+            alloc(c.shape)
+            return out.copy()
+        return out
+
+    n_bytes = max(int(np.prod(np.asarray(_clip(k)).shape)) for k in ids)
+    eng, st = _gated_engine(9 * n_bytes)                        # (a CPU 'device' holds a batch's buffers until its compute is through - a GPU
+    for _ in range(2):                                          # hands them back as each copy lands -: room for prefetch + 1 batches)
+        got, errors = dataset.extract_dataset_clips(loader, len(ids), eng, clips_per_step=3, rank=0, world=1, prefetch=2, workers=3)
+        assert [i for i, _ in errors] == [2, 5]
+        assert st.gate.in_use == 0, "pinned bytes leaked"
+        assert not torch.isnan(got[[0, 1, 3, 4, 6, 7]]).any()
+    # a clip whose two allocations exceed the cap on their own does not wait for itself
+    gate = dataset._PinnedGate(100)
+    gate.start_pass()
+    gate.acquire(0, 80)
+    gate.acquire(None, 80, own=80)                              # (without `own` this would wait for in_use == 0 forever)
+    assert gate.in_use == 160
+    gate.close()
+    with pytest.raises(RuntimeError):
+        gate.acquire(1, 80)
+
+
+def test_an_exception_in_the_driver_thread_does_not_hang_on_loaders_waiting_for_pinned_memory():
+    """Something escapes the driver loop (here: the engine's rows_mean is missing when a resumed clip comes up ... a HIP error would
+    do the same) while loader threads wait at the gate for memory only the driver could hand back: the pass must raise, not hang,
+    and the next pass over the same stager starts with a clean budget."""
+    _patched()
+
+    class Boom(BaseException):
+        pass
+
+    class BadEngine(FakeEngine):
+        def clip_vectors(self, clips, **kw):
+            raise Boom("escapes `except Exception`")
+
+    def loader(i, alloc):
+        c = np.asarray(_clip(0))
+        out = alloc(c.shape)
+        np.copyto(out, c)
+        return out
+
+    n_bytes = int(np.prod(np.asarray(_clip(0)).shape))
+    eng = BadEngine()
+    st = dataset.ClipStager(eng.device, 1)
+    st.gated = True
+    st.pool_limit_bytes = st.gate.cap = 3 * n_bytes             # three clips' worth: the other loaders of the 12 wait at the gate
+    eng._clip_stager = st
+    done = []
+
+    def run():
+        try:
+            dataset.extract_dataset_clips(loader, 12, eng, clips_per_step=2, rank=0, world=1, prefetch=3, workers=4, ramp=False)
+        except Boom:
+            done.append("raised")
+
+    import threading
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout=20)
+    assert not th.is_alive(), "the pass hangs in pool.shutdown behind loaders waiting for pinned memory"
+    assert done == ["raised"]
+    good = FakeEngine()
+    good._clip_stager = st
+    st.pool_limit_bytes = st.gate.cap = 8 * n_bytes             # (a CPU 'device' keeps a batch's buffers until its compute is through)
+    got, errors = dataset.extract_dataset_clips(loader, 4, good, clips_per_step=2, rank=0, world=1, prefetch=2, workers=2)
+    assert not errors and st.gate.in_use == 0 and not torch.isnan(got).any()
+
+
 def test_host_placement_helpers(tmp_path, monkeypatch):
     """hostnode.py against a stand-in /sys tree: the GPU's NUMA node, that node's CPUs, the per-rank share of the pinned budget; and
     'do nothing' when the platform does not tell."""
