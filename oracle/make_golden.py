@@ -197,12 +197,15 @@ def golden_pooling(mfl, mrf, mfp, report):
     report["pooling"] = dict(ls=sha(ls_ref), pool=sha(pool_ref), vit=sha(vit_ref_a))
 
 
-def golden_vit(rv, report):
+def golden_vit(rv, report, only_outliers=False):
     device = torch.device("cpu")
-    # regular synthetic weights, and the adversarial set (attention logits of +-20: peaked softmax rows; LayerNorm gammas of
-    # mixed sign) - the reference's own VisionTransformer class computes the expected tokens for both
+    # regular synthetic weights, the adversarial set (attention logits of +-20: peaked softmax rows; LayerNorm gammas of
+    # mixed sign) and the outlier set (five residual-stream channels hundreds of times the median, LayerNorm gains up to 10 on
+    # them, a near-one-hot head: synth.vit_state_dict) - the reference's own VisionTransformer class computes the expected tokens
     for name, heads, n_img, adv in [("vit_tiny", 3, 2, False), ("vit_base", 12, 1, False), ("vit_tiny", 3, 2, True),
-                                    ("vit_base", 12, 1, True)]:
+                                    ("vit_base", 12, 1, True), ("vit_tiny", 3, 2, "outliers"), ("vit_base", 12, 1, "outliers")]:
+        if only_outliers and adv != "outliers":
+            continue
         sd_np = synth.vit_state_dict(name, 16, seed=11, adversarial=adv)
         gen = rv.VitGenerator(name, 16, device, evaluate=True, random=True, verbose=False)
         gen.model.load_state_dict(vit_ref.to_torch_state_dict(sd_np), strict=True)
@@ -215,7 +218,7 @@ def golden_vit(rv, report):
         mine = vit_ref.tokens(vit_ref.to_torch_state_dict(sd_np), frags, heads)
         err = float(np.abs(mine - tokens).max() / np.abs(tokens).max())
         assert err < 2e-6, (name, err)
-        tag = name + ("_adv" if adv else "")
+        tag = name + {False: "", True: "_adv", "outliers": "_out"}[adv]
         np.savez_compressed(os.path.join(GOLD, f"{tag}_tokens.npz"), frags=frags, tokens=tokens,
                             weight_probe=np.float64([float(np.sum(v.astype(np.float64))) for v in sd_np.values()]).sum())
         report["vit"][tag] = dict(tokens=sha(tokens), restatement_vs_reference_maxrel=err,
@@ -281,6 +284,14 @@ def golden_mlp_head(report):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--vit-outliers-only" in sys.argv:       # add the outlier-set fixtures to an existing tests/golden without touching the rest
+        with open(os.path.join(GOLD, "pin_report.json")) as f:
+            report = json.load(f)
+        golden_vit(import_reference_vit(), report, only_outliers=True)
+        with open(os.path.join(GOLD, "pin_report.json"), "w") as f:
+            json.dump(report, f, indent=1, sort_keys=True)
+        print(json.dumps(report["vit"], indent=1, sort_keys=True))
+        return
     report = dict(fragment_synthetic={}, fragment_png={}, pooling={}, vit={}, mlp_head={}, flow_png={},
                   numpy=np.__version__, torch=torch.__version__)
     mfl, mrf, mfp = import_reference_drivers()

@@ -19,10 +19,18 @@ def _rng(seed):
 def resnet50_state_dict(seed=7, adversarial=False):
     """fp32 numpy state dict with torchvision resnet50 key names (fc omitted:
     the reference computes fc but never reads it).
-    adversarial: a second weight set built to stress the BatchNorm / ReLU arithmetic - running variances log-uniform over
+    adversarial=True: a second weight set built to stress the BatchNorm / ReLU arithmetic - running variances log-uniform over
     [1e-3, 10] (eps = 1e-5 matters at the low end; the producing conv's rows are scaled by sqrt(var) so activations stay O(1)),
-    gammas of mixed sign (ReLU keeps the other half), larger running means and biases."""
-    g = _rng(seed + (1000 if adversarial else 0))
+    gammas of mixed sign (ReLU keeps the other half), larger running means and biases.
+    adversarial="outliers": a third set with the pathology of real checkpoints that the per-image Hoelder scales of the f16x2
+    layers must survive - in every stage ONE output channel of the first block (bn3 and downsample BatchNorm gammas x 60, positive
+    shift) is 50 - 100 x the others and rides the identity path through the stage, so max |x| of an image is set by one channel and
+    every other value of the tensor sits 6 - 7 binades below the scale's top; and a group of 16 channels per block's bn1 / bn2 is
+    dead (gamma ~ 0, shift -10: all-zero behind the ReLU)."""
+    outliers = isinstance(adversarial, str) and adversarial == "outliers"
+    if outliers:
+        adversarial = False
+    g = _rng(seed + (1000 if adversarial else 0) + (2000 if outliers else 0))
     sd = {}
     last_conv = [None]
 
@@ -62,18 +70,38 @@ def resnet50_state_dict(seed=7, adversarial=False):
                 conv(p + ".downsample.0", width * 4, cin, 1)
                 bn(p + ".downsample.1", width * 4)
             cin = width * 4
+    if outliers:
+        for layer, blocks, width, _stride in RESNET_STAGES:
+            hot = int(g.integers(0, width * 4))
+            for name in (f"layer{layer}.0.bn3", f"layer{layer}.0.downsample.1"):
+                sd[name + ".weight"][hot] = np.float32(abs(sd[name + ".weight"][hot]) * (240.0 if layer == 4 else 60.0))
+                sd[name + ".bias"][hot] = np.float32(4.0)
+            for b in range(blocks):
+                for bnk, c in ((f"layer{layer}.{b}.bn1", width), (f"layer{layer}.{b}.bn2", width)):
+                    d0 = int(g.integers(0, c // 16)) * 16
+                    sd[bnk + ".weight"][d0:d0 + 16] = np.float32(1e-3)
+                    sd[bnk + ".bias"][d0:d0 + 16] = np.float32(-10.0)
     return sd
 
 
 def vit_state_dict(name_model="vit_base", patch=16, seed=11, adversarial=False):
     """fp32 numpy state dict with DINO ViT key names.  Biases / LN affine are
     non-trivial on purpose so a missing bias add cannot pass parity.
-    adversarial: a second weight set for the softmax path - the q and k rows of every qkv matrix are scaled so attention
+    adversarial=True: a second weight set for the softmax path - the q and k rows of every qkv matrix are scaled so attention
     logits span about +-20 (peaked, near one-hot rows next to flat ones: the max subtraction and the exp2 of the attention
-    kernel work at their limits), LayerNorm gammas of mixed sign."""
+    kernel work at their limits), LayerNorm gammas of mixed sign.
+    adversarial="outliers": a third set with the pathology of real DINO / ViT checkpoints that the STATIC scales of the f16x2 path
+    (bounds over every possible input: csrc/h2.h, host_logic.cpp) must survive - five residual-stream channels carry values hundreds
+    of times the median (pos_embed of +-6 there, fc2 / proj rows x 20 and biases of +-3 writing into them in every block), the
+    LayerNorm gains and shifts on those channels go up to 10 and 5 (so the Cauchy-Schwarz bound behind a LayerNorm is set by five
+    of 768 channels and is 2^7 .. 2^10 loose for all the others), and head 0 of every block has its q / k rows x 4 (near-one-hot
+    softmax rows next to ordinary heads)."""
     cfg = {"vit_tiny": (192, 12, 3), "vit_small": (384, 12, 6), "vit_base": (768, 12, 12)}[name_model]
     dim, depth, _heads = cfg
-    g = _rng(seed + (1000 if adversarial else 0))
+    outliers = isinstance(adversarial, str) and adversarial == "outliers"
+    if outliers:
+        adversarial = False
+    g = _rng(seed + (1000 if adversarial else 0) + (2000 if outliers else 0))
 
     def nrm(shape, std):
         return (g.standard_normal(shape, dtype=np.float32) * np.float32(std))
@@ -103,6 +131,27 @@ def vit_state_dict(name_model="vit_base", patch=16, seed=11, adversarial=False):
         sd[p + "mlp.fc2.bias"] = nrm((dim,), 0.02)
     sd["norm.weight"] = g.uniform(0.5, 1.5, dim).astype(np.float32)
     sd["norm.bias"] = nrm((dim,), 0.1)
+    if outliers:
+        hot = np.sort(g.choice(dim, 5, replace=False))
+        hd = dim // _heads
+        # (a DC component per channel, the same sign for every token - what real checkpoints show - plus 10 % token-to-token variation)
+        sd["pos_embed"][..., hot] = (g.choice([-1.0, 1.0], (1, 1, 5)) * g.uniform(150.0, 250.0, (1, 197, 5))).astype(np.float32)
+        for i in range(depth):
+            p = f"blocks.{i}."
+            for w, b in (("attn.proj.weight", "attn.proj.bias"), ("mlp.fc2.weight", "mlp.fc2.bias")):
+                sd[p + w][hot] *= np.float32(20.0)
+                sd[p + b][hot] = (g.choice([-1.0, 1.0], 5) * g.uniform(5.0, 15.0, 5)).astype(np.float32)
+            for nk in ("norm1", "norm2"):
+                sd[p + nk + ".weight"][hot] = g.uniform(4.0, 10.0, 5).astype(np.float32)
+                sd[p + nk + ".bias"][hot] = (g.choice([-1.0, 1.0], 5) * g.uniform(2.0, 5.0, 5)).astype(np.float32)
+            # (the consumers read those channels with small weights, as trained networks do: the stream's other channels stay O(1))
+            sd[p + "attn.qkv.weight"][:, hot] *= np.float32(0.1)
+            sd[p + "mlp.fc1.weight"][:, hot] *= np.float32(0.1)
+            qkv = sd[p + "attn.qkv.weight"]
+            qkv[0:hd] *= np.float32(12.0)                   # q rows of head 0
+            qkv[dim:dim + hd] *= np.float32(12.0)           # k rows of head 0
+        sd["norm.weight"][hot] = g.uniform(4.0, 10.0, 5).astype(np.float32)
+        sd["norm.bias"][hot] = (g.choice([-1.0, 1.0], 5) * g.uniform(2.0, 5.0, 5)).astype(np.float32)
     return sd
 
 

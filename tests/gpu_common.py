@@ -26,7 +26,7 @@ def engine():
 
 def rn50_weights(adversarial=False):
     """The synthetic ResNet-50 weights (or the adversarial second set), loaded into the shared engine."""
-    key = "rn:adv" if adversarial else "rn"
+    key = "rn" + (f":{'adv' if adversarial is True else adversarial}" if adversarial else "")   # (False | True | "outliers")
     if key not in _weights:
         _weights[key] = synth.resnet50_state_dict(adversarial=adversarial)
     if _weights.get("rn_loaded") != key:
@@ -36,13 +36,21 @@ def rn50_weights(adversarial=False):
 
 
 def vit_weights(name, adversarial=False):
-    key = "vit:" + name + (":adv" if adversarial else "")
+    key = "vit:" + name + (f":{'adv' if adversarial is True else adversarial}" if adversarial else "")
     if key not in _weights:
         _weights[key] = synth.vit_state_dict(name, adversarial=adversarial)
     if _weights.get("vit_loaded") != key:
         engine().load_vit(_weights[key], name)
         _weights["vit_loaded"] = key
     return _weights[key]
+
+
+WEIGHT_SETS = [False, True, "outliers"]          # regular, adversarial, real-checkpoint pathology (synth.py)
+WEIGHT_SET_IDS = ["regular", "adversarial", "outliers"]
+
+
+def golden_tag(adversarial):
+    return {False: "", True: "_adv", "outliers": "_out"}[adversarial]
 
 
 def assert_close(got, want, what, rtol=RTOL, atol_frac=ATOL_FRAC):

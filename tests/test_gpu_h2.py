@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import fragment_ref, pooling_ref, vit_ref
-from tests.gpu_common import assert_close, engine, synth, vit_weights
+from tests.gpu_common import WEIGHT_SET_IDS, WEIGHT_SETS, assert_close, engine, golden_tag, synth, vit_weights
 
 pytestmark = pytest.mark.gpu
 
@@ -207,22 +207,25 @@ def _fragments(n, seed=0):
     return np.stack(frs)
 
 
-@pytest.mark.parametrize("adv", [False, True], ids=["regular", "adversarial"])
+@pytest.mark.parametrize("adv", WEIGHT_SETS, ids=WEIGHT_SET_IDS)
 def test_vit_base_matches_reference_golden_tokens_under_f16x2(golden_dir, h2, adv):
-    """The reference's own VisionTransformer outputs (tests/golden/vit_base{,_adv}_tokens.npz), regular weights and the adversarial
-    set (logits of +-20, large LayerNorm gains: the static bounds are tight there)."""
+    """The reference's own VisionTransformer outputs (tests/golden/vit_base{,_adv,_out}_tokens.npz): regular weights, the adversarial
+    set (logits of +-20, LayerNorm gains of mixed sign) and the outlier set (five residual-stream channels hundreds of times the
+    median with LayerNorm gains up to 10 on them: the static bounds are 2^7 - 2^10 loose for the other 763 channels)."""
     vit_weights("vit_base", adversarial=adv)
-    z = np.load(os.path.join(golden_dir, f"vit_base{'_adv' if adv else ''}_tokens.npz"))
+    z = np.load(os.path.join(golden_dir, f"vit_base{golden_tag(adv)}_tokens.npz"))
     tokens, pooled = h2.vit_features(torch.from_numpy(z["frags"]).cuda(), tokens=True, pooled=True)
     assert_close(tokens, z["tokens"], "vit_base tokens (f16x2) vs reference VisionTransformer")
     want = np.stack([pooling_ref.vit_pool_vector(t) for t in z["tokens"]])
     assert_close(pooled, want, "vit_base pooled (f16x2) vs reference process_video_feature")
 
 
-@pytest.mark.parametrize("adv", [False, True], ids=["regular", "adversarial"])
+@pytest.mark.parametrize("adv", WEIGHT_SETS, ids=WEIGHT_SET_IDS)
 def test_vit_base_error_against_fp64_is_no_larger_than_the_fp32_paths(adv):
     """12 blocks deep: tokens of the exact-fp32 path, of bf16x6 and of f16x2 against an fp64 run of the oracle (same fp32 weights and
-    inputs, all arithmetic in double).  The gate: f16x2 no further from fp64 than the fp32 FMA chain."""
+    inputs, all arithmetic in double).  The gate: f16x2 no further from fp64 than the fp32 FMA chain - on the outlier set also over
+    the QUIET channels alone (|token| < 10: the 763 channels the five outlier channels would otherwise hide in a norm), which is
+    where a loose static scale would show (values far below the scale's top keep an absolute, not a relative, error)."""
     sd = vit_weights("vit_base", adversarial=adv)
     eng = engine()
     frags = _fragments(3, seed=2)
@@ -236,9 +239,12 @@ def test_vit_base_error_against_fp64_is_no_larger_than_the_fp32_paths(adv):
         t2, _ = eng.vit_features(f, tokens=True, pooled=False)
         assert torch.equal(t, t2), f"{prec} is not deterministic"
         e = np.abs(t.cpu().numpy().astype(np.float64) - ref)
-        out[prec] = (np.linalg.norm(e) / np.linalg.norm(ref), e.max())
-    print("\nvit_base tokens vs fp64 (norm-rel, max abs): " + "  ".join(f"{k} {v[0]:.3e} {v[1]:.3e}" for k, v in out.items()))
+        quiet = np.abs(ref).max(axis=(0, 1)) < 10.0
+        out[prec] = (np.linalg.norm(e) / np.linalg.norm(ref), e.max(), np.linalg.norm(e[..., quiet]) / np.linalg.norm(ref[..., quiet]))
+    print(f"\nvit_base tokens ({WEIGHT_SET_IDS[WEIGHT_SETS.index(adv)]} weights) vs fp64 (norm-rel, max abs, norm-rel over the {int(quiet.sum())} quiet channels): "
+          + "  ".join(f"{k} {v[0]:.3e} {v[1]:.3e} {v[2]:.3e}" for k, v in out.items()))
     assert out["f16x2"][0] <= 1.1 * out["fp32"][0] and out["f16x2"][1] <= 1.5 * out["fp32"][1]
+    assert out["f16x2"][2] <= 1.1 * out["fp32"][2], "f16x2 loses to the fp32 chain on the channels outside the outliers"
 
 
 def test_vit_rows_do_not_depend_on_the_batch_under_f16x2(h2):
@@ -320,16 +326,17 @@ def test_attention_under_f16x2(n_img, heads, scale):
 
 # ---- ResNet-50 under f16x2: layer3 / layer4 on fp16 planes with per-image scales ------------------------------------------------------------
 from oracle import resnet50_ref  # noqa: E402
-from tests.gpu_common import rn50_weights  # noqa: E402
+from tests.gpu_common import rn50_weights  # noqa: E402,F811
 
 
-@pytest.mark.parametrize("adv", [False, True], ids=["regular", "adversarial"])
+@pytest.mark.parametrize("adv", WEIGHT_SETS, ids=WEIGHT_SET_IDS)
 def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
     """All 15 taps + both feature vectors with layer3 / layer4 on the f16x2 kernels ("rn_h2", the default under gemm_precision 3): inside
     the bar against the fp32 oracle, deterministic, and against an fp64 run of the oracle no further away than bf16x6 everywhere (x 1.25) and
     than torch-CPU fp32 - the reference's own arithmetic - on every tap.  Images of very different brightness share the batch: the scales are
     per image.  The adversarial set (BatchNorm variances 1e-3 .. 10: activations of very different size from layer to layer) exercises
-    the Hoelder bounds."""
+    the Hoelder bounds; the outlier set (one channel per stage 50 - 100 x the others, dead channel groups) makes the per-image maximum -
+    and so the scale - the business of ONE channel: the gate is then also taken over the other channels alone."""
     sd = rn50_weights(adversarial=adv)
     eng = engine()
     frags = _fragments(4)
@@ -366,6 +373,12 @@ def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
               f"torch CPU fp32 {ncpu:.3e}")
         assert n2 <= 1.25 * n6 + 1e-9 and n2 <= ncpu, name
         assert n2l <= 1.25 * n6 + 1e-9 and n2l <= ncpu, name
+        if adv == "outliers" and i > 0:     # the same gate without the hot channel (it carries most of a norm over all channels)
+            cm = np.abs(r).max(axis=(0, 2, 3))
+            q = cm < 0.25 * cm.max()
+            q2, q6, qcpu = (rel(np.asarray(a)[:, q], r[:, q]) for a in (taps2[i].cpu().numpy(), taps6[i].cpu().numpy(), ref_taps[name].numpy()))
+            print(f"{'':22s} without the hot channel(s) ({int(q.sum())} of {q.size}): f16x2 {q2:.3e}  bf16x6 {q6:.3e}  torch CPU fp32 {qcpu:.3e}")
+            assert q2 <= 1.25 * q6 + 1e-9 and q2 <= qcpu, name + " (quiet channels)"
         if i < 7:   # (layer2[3], the hand-over block, runs unsplit with its fp16-plane output: same kernel, possibly another K-slice order)
             assert torch.equal(taps2late[i], taps6[i]), f"{name}: without rn_h2_early layer1 / layer2 run the same kernels either way"
     assert_close(ls2, resnet50_ref.layer_stack_features(tsd, frags), "f16x2 layer-stack")

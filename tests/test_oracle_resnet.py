@@ -55,7 +55,7 @@ def _close(got, want, what):
     assert worst <= 1.0, f"{what}: max err/bound {worst:.3g} (norm-rel {np.linalg.norm(got - want) / np.linalg.norm(want):.2e})"
 
 
-@pytest.mark.parametrize("adversarial", [False, True])
+@pytest.mark.parametrize("adversarial", [False, True, "outliers"], ids=["regular", "adversarial", "outliers"])
 def test_every_tap_against_hooked_independent_implementation(adversarial):
     """All 15 layer-stack taps - the RAW conv1 output (hook on the embedder's convolution, before its BatchNorm), the 14 block
     outputs (hooks on encoder.stages[s].layers[b]) - and the avgpool vector, element-wise at 1e-5."""
@@ -81,7 +81,11 @@ def test_every_tap_against_hooked_independent_implementation(adversarial):
     for name in ("resnet50.layer3[4]", "resnet50.layer3[5]"):                    # untapped blocks still feed the tapped ones
         assert name in seen and name not in taps
     _close(avg.numpy(), out.pooler_output.numpy(), "avgpool")
-    if adversarial:   # the set does what it is for: low-variance channels and negative gammas are present and matter
+    if adversarial == "outliers":   # one channel per stage far above the others, dead channels behind the ReLU
+        for name, ratio in (("resnet50.layer1[0]", 50.0), ("resnet50.layer2[0]", 50.0), ("resnet50.layer3[0]", 20.0)):
+            cm = taps[name].abs().amax(dim=(0, 2, 3)).numpy()
+            assert cm.max() / np.median(cm) > ratio and (cm == 0).any(), name
+    elif adversarial:   # the set does what it is for: low-variance channels and negative gammas are present and matter
         v = np.concatenate([synth.resnet50_state_dict(seed=7, adversarial=True)[k].ravel() for k in ("bn1.running_var", "layer2.1.bn2.running_var")])
         assert v.min() < 3e-3 and v.max() > 3.0
 
