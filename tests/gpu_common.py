@@ -53,14 +53,22 @@ def golden_tag(adversarial):
     return {False: "", True: "_adv", "outliers": "_out"}[adversarial]
 
 
-def assert_close(got, want, what, rtol=RTOL, atol_frac=ATOL_FRAC):
+def assert_close(got, want, what, rtol=RTOL, atol_frac=ATOL_FRAC, channel_axis=None):
+    """channel_axis: the absolute floor of a channel is atol_frac x max(the tensor's mean magnitude, THAT CHANNEL's mean magnitude).  A
+    channel that runs a hundred times above the others (the outlier weight set) carries a hundred times their absolute rounding error,
+    in EVERY fp32 arithmetic - torch's own fp32 forward is 5e-4 away from an fp64 run there, where the floor of the tensor mean is 1e-4 -
+    and where such a channel passes through zero a relative bound has nothing to hold on to; the floor never tightens below the tensor's."""
     got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
     want = np.asarray(want)
     assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
     assert np.isfinite(got).all(), f"{what}: non-finite values"
     scale = float(np.abs(want).mean()) + 1e-30
     err = np.abs(got - want)
-    bound = rtol * np.abs(want) + atol_frac * scale
+    floor = atol_frac * scale
+    if channel_axis is not None:
+        axes = tuple(a for a in range(want.ndim) if a != channel_axis)
+        floor = np.maximum(floor, atol_frac * np.abs(want).mean(axis=axes, keepdims=True))
+    bound = rtol * np.abs(want) + floor
     worst = float((err / bound).max())
     assert worst <= 1.0, (f"{what}: max err/bound {worst:.3g}; max abs err {err.max():.3e}, "
                           f"mean |want| {scale:.3e}, norm-rel {np.linalg.norm(got - want) / np.linalg.norm(want):.3e}")

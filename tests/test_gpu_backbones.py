@@ -33,7 +33,7 @@ def test_resnet50_taps_and_features(each_precision, each_split_k, adversarial):
     tsd = resnet50_ref.to_torch_state_dict(sd)
     ref_taps, ref_avg = resnet50_ref.forward_taps(tsd, resnet50_ref.preprocess_bgr_u8(frags))
     for i, name in enumerate(pooling_ref.RESNET50_TAPS):      # every hooked activation, in tap order
-        assert_close(taps[i], ref_taps[name].numpy(), name)
+        assert_close(taps[i], ref_taps[name].numpy(), name, channel_axis=1)
     want_ls = resnet50_ref.layer_stack_features(tsd, frags)
     want_pool = resnet50_ref.pool_features(tsd, frags)
     off = 0

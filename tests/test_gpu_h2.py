@@ -365,7 +365,7 @@ def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
         return float(np.linalg.norm(np.asarray(a, dtype=np.float64) - r) / np.linalg.norm(r))
 
     for i, name in enumerate(pooling_ref.RESNET50_TAPS):
-        assert_close(taps2[i], ref_taps[name].numpy(), f"f16x2 {name}")
+        assert_close(taps2[i], ref_taps[name].numpy(), f"f16x2 {name}", channel_axis=1)
         r = ref64[name].numpy()
         n2, n6, ncpu = rel(taps2[i].cpu().numpy(), r), rel(taps6[i].cpu().numpy(), r), rel(ref_taps[name].numpy(), r)
         n2l = rel(taps2late[i].cpu().numpy(), r)
