@@ -227,6 +227,11 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     else if (k == "x6_fp32_rows") h->gemm.fp32_rows = value != 0;
     else if (k == "rn_h2") h->gemm.rn_h2 = value != 0;
     else if (k == "rn_h2_early") h->gemm.rn_h2_early = value != 0;
+    else if (k == "rn_fuse") h->gemm.rn_fuse = value != 0;
+    else if (k == "b2b_rows") {
+        RELAX_REQUIRE(h, value == 128 || value == 256, "relax_set_option: b2b_rows must be 128 or 256");
+        h->gemm.b2b_rows = value;
+    }
     else if (k == "att_h2") h->gemm.att_h2 = value != 0;
     else if (k == "h2_form") {
         RELAX_REQUIRE(h, value >= 0 && value <= 2, "relax_set_option: h2_form must be 0, 1 or 2");
@@ -269,6 +274,8 @@ int relax_get_option(relax_handle* h, const char* key, int* value) {
     else if (k == "x6_fp32_rows") *value = h->gemm.fp32_rows;
     else if (k == "rn_h2") *value = h->gemm.rn_h2;
     else if (k == "rn_h2_early") *value = h->gemm.rn_h2_early;
+    else if (k == "rn_fuse") *value = h->gemm.rn_fuse;
+    else if (k == "b2b_rows") *value = h->gemm.b2b_rows;
     else if (k == "att_h2") *value = h->gemm.att_h2;
     else if (k == "h2_stages") *value = h->gemm.h2_stages;
     else if (k == "h2_form") *value = h->gemm.h2_form;

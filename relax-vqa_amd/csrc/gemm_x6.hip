@@ -63,6 +63,15 @@
 #define X6_STAMPS_AFTER_LAUNCH(BM_, BN_, h_, p_, units_, s_)
 #endif
 
+// experiment switches of the back-to-back tail (tools/abl_r06 builds; the product compiles the defaults): B fragments of a whole pass
+// requested one pass ahead (measured slower: 16 spilled registers), timing-only ablations (bit 0 no fp32 stores, 1 no residual loads, 2 no conv3)
+#ifndef X6_B2B_PREFETCH_B
+#define X6_B2B_PREFETCH_B 0
+#endif
+#ifndef X6_B2B_ABL
+#define X6_B2B_ABL 0
+#endif
+
 namespace relax {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -123,6 +132,12 @@ struct X6Params {
     int tiles_m, tiles_n, ntiles, group_m;
     int full_tiles, nsplit;
     unsigned long long* stamps;   // diagnostic builds only (tools/abl/gemm_x6_stamps.hip); null in the product
+    // B2B (back to back): the conv3 of the block - h2 weights [N3][N*4 B] in the permuted K order, their inverse row scales, bias; the
+    // output-side fields above (residual, out, out_sp3, out_h2, gap, amax_out, out_rows, gap_rows) then describe the [M][N3] result
+    const char* w3;
+    const float* colscale3;
+    const float* bias3;
+    int N3;
 };
 
 __device__ inline int xcd_remap6(int b, int nwg) {
@@ -150,8 +165,8 @@ constexpr int64_t kMaxRecords = 0x7ffffff0;
 // (the loop body is rotated: one "region" = barrier .. next barrier = M1(k) + M0(k+1) is one basic block, which the compiler's
 // scheduler interleaves better than any order pinned by hand)
 // X = the operand with fewer fragments per wave (double-buffered in registers), Y = the other one (two halves).
-template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false, bool B2B = false>
+__global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8 (B2B on 128 rows: 3 x 4)
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (it has no __amdgpu_buffer_rsrc_t and emits no stub for a body that names it)
     constexpr int NW = WM * WN;
     constexpr int NT = NW * 64;
@@ -178,6 +193,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
     static_assert(!DUAL || !TAPS, "a second activation source goes with 1x1 contractions");
     static_assert(!AF32 || (!M16 && !TAPS && !DUAL), "fp32 activation rows: the plain-GEMM form of the four-wave tiles only");
     static_assert(!H2 || (!M16 && !DUAL && !AF32), "fp16 planes: the four-wave tiles only (the 256 x 256 tile of f16x2 is gemm_h3)");
+    static_assert(!B2B || (H2 && TAPS && (TM == 1 || TM == 2) && TN == 2 && WN == 1), "back to back: the f16x2 3x3 form on 4 x 1 waves of 32 or 64 rows x 64 columns");
     static_assert(STAGE % 1024 == 0 && A_BYTES % 1024 == 0, "stage regions are whole DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -449,7 +465,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
         const int pa = H2 ? (t == 0 ? 1 : 0) : t == 0 ? 2 : (t == 1 || t == 3) ? 1 : 0;                                 \
         const int pb = H2 ? (t == 1 ? 1 : 0) : t == 2 ? 2 : (t == 1 || t == 4) ? 1 : 0;                                 \
         _Pragma("unroll") for (int x = 0; x < XT; ++x) _Pragma("unroll") for (int y = 0; y < YH; ++y) {                 \
-            if (H2 && t < 2) {                                                                                          \
+            if (B2B && t < 2) { /* the TRANSPOSED tile (weights as the A operand): channels along the accumulator registers */ \
+                accs[H2 ? x : 0][H2 ? (half_) * YH + y : 0] =                                                           \
+                    X6_MFMA1(yf_[y][pb], xf[set_][x][pa], accs[H2 ? x : 0][H2 ? (half_) * YH + y : 0]);                 \
+            } else if (B2B) {                                                                                           \
+                acc[x][(half_) * YH + y] = X6_MFMA1(yf_[y][pb], xf[set_][x][pa], acc[x][(half_) * YH + y]);             \
+            } else if (H2 && t < 2) {                                                                                   \
                 if (SPLIT_B)                                                                                            \
                     accs[H2 ? x : 0][H2 ? (half_) * YH + y : 0] =                                                       \
                         X6_MFMA1(xf[set_][x][pa], yf_[y][pb], accs[H2 ? x : 0][H2 ? (half_) * YH + y : 0]);             \
@@ -646,6 +667,204 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_x6(const X6Params p) {  
             for (int j = 0; j < TN; ++j) acc[i][j] += accs[H2 ? i : 0][H2 ? j : 0];
     }
     __syncthreads();   // no DMA is in flight and every fragment is in registers: the stages become the epilogue staging
+
+    if constexpr (B2B) {
+        // ---- back to back: acc[x][y] holds the TRANSPOSED tile of the 3x3 convolution - lane (c, half) has pixel  (wm*TM + x)*32 + c  of the
+        // tile and the 16 channels  y*32 + 4*half + (r & 3) + 8*(r >> 2), r = 0 .. 15.  That is the A-operand layout of v_mfma_f32_32x32x16_f16
+        // for a contraction over channels in the order  k = 16q + 8h + e  <->  channel 16q + 4h + (e & 3) + 8 (e >> 2)  (the order w3 is packed
+        // in): bias, ReLU, ONE scale per pixel row from the row's own maximum (measured, batch-invariant: csrc/h2.h "operator level"), the split
+        // into two fp16 planes - all in registers -, and the tile is the A operand of the block's conv3 without leaving the CU.
+        const int c32 = lane & 31, half = lane >> 5;
+        constexpr int B2B_STG = NW * TM * 32 * 68 * 4 > 2 * STAGE ? NW * TM * 32 * 68 * 4 : 2 * STAGE;   // the waves' staging rows (TM * 32 x 68 floats each), over the two stages
+        float* rowinv = reinterpret_cast<float*>(smem + B2B_STG);              // [BM]: 1 / scale of every pixel row of the tile
+        unsigned* simg = reinterpret_cast<unsigned*>(smem + B2B_STG + 1024);   // two per-image maxima of the tile
+        if (tid < 2) simg[tid] = 0u;
+        u32x4 ah[TM][2 * TN], al[TM][2 * TN];
+#pragma unroll
+        for (int x = 0; x < TM; ++x) {
+            const int m = m0 + (wm * TM + x) * 32 + c32;
+            const float rs = p.img_in_inv[(m < p.M ? m : p.M - 1) / (p.Ho * p.Wo)];
+            float mx = 0.f;
+#pragma unroll
+            for (int y = 0; y < TN; ++y)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch0 = n0 + y * 32 + 4 * half + 8 * g;
+                    const f32x4 cs = *reinterpret_cast<const f32x4*>(p.colscale + ch0);
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + ch0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaxf(acc[x][y][4 * g + e] * (cs[e] * rs) + bb[e], 0.f);   // (cs * rs: powers of two, exact)
+                        acc[x][y][4 * g + e] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float sc = h2_scale_for(mx);
+            if (half == 0) rowinv[(wm * TM + x) * 32 + c32] = 1.f / sc;       // (a power of two: exact)
+#pragma unroll
+            for (int y = 0; y < TN; ++y)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    const f32x4 lo4 = {acc[x][y][8 * sub + 0], acc[x][y][8 * sub + 1], acc[x][y][8 * sub + 2], acc[x][y][8 * sub + 3]};
+                    const f32x4 hi4 = {acc[x][y][8 * sub + 4], acc[x][y][8 * sub + 5], acc[x][y][8 * sub + 6], acc[x][y][8 * sub + 7]};
+                    split2_x8(lo4 * sc, hi4 * sc, ah[x][2 * y + sub], al[x][2 * y + sub]);
+                }
+        }
+        // ---- conv3: [64 pixels of this wave] x [K = BN channels] x [N3 columns] in passes of 64 columns, B fragments straight from
+        // global memory (64 KB shared by every workgroup of the launch: L2 / L1 hits); four products (K < 256), one accumulator, smallest first
+        constexpr int LDC2 = 68;
+        float* stgw = reinterpret_cast<float*>(smem) + wave * (TM * 32 * LDC2);    // this wave's own 64 staging rows: no workgroup barrier in the passes
+        const int lr = lane >> 3, lc = (lane & 7) * 8;
+        const int img_first = m0 / (p.Ho * p.Wo);
+        const int r0 = wm * TM * 32;                                               // the wave's first row of the tile
+        float tmax0 = 0.f, tmax1 = 0.f;
+        const int64_t w3row = (int64_t)BN * 4;
+        // The memory operations of a wave complete in issue order (vmcnt), so the order below is the pipeline: the B fragments of pass p + 1
+        // are requested BEFORE the stores of pass p (a wait for them must not wait for those stores' acknowledgements); the residual rows
+        // come 32 at a time, requested while the accumulators are on their way through the LDS.  Residual, fp32 output and weights go
+        // through buffer resources: ONE offset register per lane for the whole tile (row lr, columns lc .. lc + 7 of the wave's rows), the
+        // pass / row-group part in a scalar; rows beyond M (beyond out_rows) read zeros (are not stored) by the resource's byte count.
+        const int npass = p.N3 / 64;
+        const int64_t wave_row0 = (int64_t)(m0 + r0) * p.N3 * 4;                 // byte offset of the wave's first row in an [M][N3] fp32 matrix
+        auto bytes_left = [&](int rows) {
+            const int64_t left = (int64_t)rows * p.N3 * 4 - wave_row0;
+            return (int)(left < 0 ? 0 : (left < kMaxRecords ? left : kMaxRecords));
+        };
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.residual)) + wave_row0, 0,
+                                                                                bytes_left(p.M), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (p.out ? wave_row0 : 0), 0,
+                                                                                p.out ? bytes_left(p.out_rows < p.M ? p.out_rows : p.M) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, (int)((int64_t)p.N3 * w3row), 0x00020000);
+        const int voff_row = (lr * p.N3 + lc) * 4;
+        const int voff_w3 = c32 * (int)w3row + half * 16;
+        f16x8 bh[X6_B2B_PREFETCH_B ? 2 * TN : 1][2], bl[X6_B2B_PREFETCH_B ? 2 * TN : 1][2];
+        u32x4 ra[4], rb[4];
+#define X6_B2B_LOAD_BQ(pass_, q_, slot_)                                                                                \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                  \
+        const int so_ = ((pass_) * 64 + nt * 32) * (int)w3row + (q_) * 64;                                              \
+        bh[slot_][nt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, voff_w3, so_, 0));       \
+        bl[slot_][nt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, voff_w3 + 32, so_, 0));  \
+    }
+#define X6_B2B_LOAD_B(pass_) _Pragma("unroll") for (int q = 0; q < 2 * TN; ++q) X6_B2B_LOAD_BQ(pass_, q, q)
+#define X6_B2B_LOAD_RES(pass_, it0_)                                                                                    \
+    _Pragma("unroll") for (int it = (it0_); it < (it0_) + 4; ++it) {                                                    \
+        const int so_ = (it * 8 * p.N3 + (pass_) * 64) * 4;                                                             \
+        if (X6_B2B_ABL & 2) { ra[it & 3] = (u32x4){0u, 0u, 0u, 0u}; rb[it & 3] = ra[it & 3]; continue; }                \
+        ra[it & 3] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff_row, so_, 0);                                   \
+        rb[it & 3] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff_row + 16, so_, 0);                              \
+    }
+#define X6_B2B_ROWS(it0_)                                                                                               \
+    _Pragma("unroll") for (int it = (it0_); it < (it0_) + 4; ++it) {                                                    \
+        const int row = it * 8 + lr;                                                                                    \
+        const int m = m0 + r0 + row;                                                                                    \
+        f32x4 va = *reinterpret_cast<const f32x4*>(stgw + row * LDC2 + lc);                                             \
+        f32x4 vb = *reinterpret_cast<const f32x4*>(stgw + row * LDC2 + lc + 4);                                         \
+        const float ri = rowinv[r0 + row];                                                                              \
+        va = va * (cs_a * ri) + b3_a;         /* (powers of two: exact) */                                              \
+        vb = vb * (cs_b * ri) + b3_b;                                                                                   \
+        va += __builtin_bit_cast(f32x4, ra[it & 3]);   /* (acc + bias) + residual: the order of the two-launch path */  \
+        vb += __builtin_bit_cast(f32x4, rb[it & 3]);                                                                    \
+        va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};                           \
+        vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};                           \
+        if (p.gap) {                                                                                                    \
+            *reinterpret_cast<f32x4*>(stgw + row * LDC2 + lc) = va;                                                     \
+            *reinterpret_cast<f32x4*>(stgw + row * LDC2 + lc + 4) = vb;                                                 \
+        }                                                                                                               \
+        if (!(X6_B2B_ABL & 1)) {                                                                                        \
+            const int so_ = (it * 8 * p.N3 + n0p) * 4;                                                                  \
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, va), rs_out, voff_row, so_, 0);            \
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb), rs_out, voff_row + 16, so_, 0);       \
+        }                                                                                                               \
+        if (m >= p.M) continue;                                                                                         \
+        if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N3 * 6), n0p + lc, va, vb);                    \
+        if (p.out_h2 || p.amax_out) {                                                                                   \
+            const int img = m / (p.Ho * p.Wo);                                                                          \
+            if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N3 * 4), n0p + lc, va, vb, p.img_out_scale[img]); \
+            const float mx = fmaxf(fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w)), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w))); \
+            if (img == img_first) tmax0 = fmaxf(tmax0, mx);      /* (a tile of 256 rows spans at most two images of >= 256 rows) */ \
+            else tmax1 = fmaxf(tmax1, mx);                                                                              \
+        }                                                                                                               \
+    }
+        if (X6_B2B_ABL & 4) return;
+        if (X6_B2B_PREFETCH_B) X6_B2B_LOAD_B(0);
+        for (int pass = 0; pass < npass; ++pass) {
+            const int n0p = pass * 64;
+            {
+                floatx16 c2[TM][2];
+#pragma unroll
+                for (int x = 0; x < TM; ++x)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) c2[x][nt][r] = 0.f;
+#pragma unroll
+                for (int q = 0; q < 2 * TN; ++q) {
+                    constexpr int slot = X6_B2B_PREFETCH_B ? -1 : 0;
+                    if (!X6_B2B_PREFETCH_B) X6_B2B_LOAD_BQ(pass, q, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int x = 0; x < TM; ++x)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                c2[x][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (t == 0 || t == 1) ? al[x][q] : ah[x][q]),
+                                                                                   (t == 0 || t == 2) ? bl[slot < 0 ? q : 0][nt] : bh[slot < 0 ? q : 0][nt], c2[x][nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int x = 0; x < TM; ++x)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) stgw[(x * 32 + 4 * half + (r & 3) + 8 * (r >> 2)) * LDC2 + nt * 32 + c32] = c2[x][nt][r];
+            }
+            const f32x4 cs_a = *reinterpret_cast<const f32x4*>(p.colscale3 + n0p + lc), cs_b = *reinterpret_cast<const f32x4*>(p.colscale3 + n0p + lc + 4);
+            const f32x4 b3_a = *reinterpret_cast<const f32x4*>(p.bias3 + n0p + lc), b3_b = *reinterpret_cast<const f32x4*>(p.bias3 + n0p + lc + 4);
+            if (X6_B2B_PREFETCH_B && pass + 1 < npass) X6_B2B_LOAD_B(pass + 1);
+            X6_B2B_LOAD_RES(pass, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local: this wave's stores have reached the LDS before its loads
+            __builtin_amdgcn_wave_barrier();
+            X6_B2B_ROWS(0);
+            if constexpr (TM == 2) {
+                X6_B2B_LOAD_RES(pass, 4);
+                X6_B2B_ROWS(4);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (p.gap) {   // sums over the four aligned 16-row groups of the wave's 64 rows, rows added in order (batch-invariant)
+#pragma unroll
+                for (int g = 0; g < TM * 2; ++g) {
+                    const int mg = m0 + r0 + g * 16;
+                    float t = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += stgw[(g * 16 + r) * LDC2 + lane];
+                    if (mg < p.gap_rows) p.gap[(int64_t)(mg >> 4) * p.N3 + n0p + lane] = t;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#undef X6_B2B_ROWS
+#undef X6_B2B_LOAD_RES
+#undef X6_B2B_LOAD_B
+#undef X6_B2B_LOAD_BQ
+        if (p.amax_out) {   // (workgroup-uniform) outputs are >= 0: integer max of the bits = float max, order-free
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                tmax0 = fmaxf(tmax0, __shfl_xor(tmax0, o));
+                tmax1 = fmaxf(tmax1, __shfl_xor(tmax1, o));
+            }
+            __syncthreads();
+            if (lane == 0) {
+                atomicMax(simg, __float_as_uint(tmax0));
+                atomicMax(simg + 1, __float_as_uint(tmax1));
+            }
+            __syncthreads();
+            if (tid < 2 && simg[tid] != 0u) atomicMax(p.amax_out + img_first + tid, simg[tid]);
+        }
+        X6_STAMP(3);
+        return;
+    }
 
     // ---- epilogue, staged through LDS in 64-row chunks (C/D map of the 32x32 MFMA: col = lane & 31,
     // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); a thread owns two groups of 4 columns, at lcA and lcB: bias / residual /
@@ -915,7 +1134,7 @@ __global__ __launch_bounds__(256) void splitk_finish_x6(const X6Params p) {
     if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lc, va, vb);
 }
 
-template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false, bool B2B = false>
 static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr int WG_PER_CU = NT == 256 ? 2 : 1;
@@ -936,19 +1155,41 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
         p.partial = static_cast<float*>(h->splitk_ws.p);
     }
     constexpr int CH = H2 ? kH2ChunkBytes : kChunkBytes;
-    constexpr size_t lds = ((M16 && !TAPS && !DUAL) ? 3 : 2) * (size_t)(BM * (AF32 ? 64 : CH) + BN * CH) + 1024;
+    // (B2B: the waves' own staging rows of the conv3 passes, 64 x 68 floats each, + the row scales + two maxima: 70.7 KB, two workgroups per CU)
+    constexpr size_t stages_lds = ((M16 && !TAPS && !DUAL) ? 3 : 2) * (size_t)(BM * (AF32 ? 64 : CH) + BN * CH);
+    constexpr size_t b2b_stg = (size_t)(WM * WN) * (BM / WM) * 68 * 4;     // the waves' own staging rows of the conv3 passes
+    constexpr size_t lds = B2B ? (b2b_stg > stages_lds ? b2b_stg : stages_lds) + 1024 + 64 : stages_lds + 1024;
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
-        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32, H2>),
+        RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32, H2, B2B>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[h->device] = true;
     }
     const int units = p.full_tiles + (p.ntiles - p.full_tiles) * p.nsplit;
     X6_STAMPS_BEFORE_LAUNCH(h, p, units);
-    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32, H2>), dim3(units), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32, H2, B2B>), dim3(units), dim3(NT), lds, s, p);
     X6_STAMPS_AFTER_LAUNCH(BM, BN, h, p, units, s);
     if (p.nsplit > 1)
         hipLaunchKernelGGL((splitk_finish_x6<BM, BN>), dim3(BM * BN / 8 / 256, p.ntiles - p.full_tiles), dim3(256), 0, s, p);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
+// K order of the back-to-back form (B2B above): wp[n][16q + 8h + e] = w[n][16q + 4h + (e & 3) + 8 (e >> 2)] - position (q, h, e) of an
+// MFMA A fragment holds the channel that accumulator register 8 (q & 1) + e of lane half h holds in the transposed tile of the 3x3
+__global__ __launch_bounds__(256) void b2b_permute_k_kernel(const float* __restrict__ w, float* __restrict__ wp, int K, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t n = i / K;
+    const int k = (int)(i - n * K);
+    const int q = k >> 4, hh = (k >> 3) & 1, e = k & 7;
+    wp[i] = w[n * K + 16 * q + 4 * hh + (e & 3) + 8 * (e >> 2)];
+}
+
+int launch_b2b_permute_k(relax_handle* h, const float* w, float* wp, int rows, int K, hipStream_t s) {
+    RELAX_REQUIRE(h, w && wp && rows > 0 && K % 16 == 0, "b2b_permute_k: bad arguments");
+    const int64_t total = (int64_t)rows * K;
+    hipLaunchKernelGGL(b2b_permute_k_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, wp, K, total);
     RELAX_HIP_CHECK(h, hipGetLastError());
     return RELAX_OK;
 }
@@ -975,6 +1216,11 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
     p.act = d.act;
     const bool taps = d.KH * d.KW > 1;
+    const bool b2b = d.w3 != nullptr;
+    p.w3 = static_cast<const char*>(d.w3); p.colscale3 = d.colscale3; p.bias3 = d.bias3; p.N3 = d.Cout3;
+    RELAX_REQUIRE(h, !b2b || (d.in_h2 && taps && d.Cout == 64 && d.Cout3 % 64 == 0 && d.Cout3 > 0 && d.colscale3 && d.bias3 && d.bias && d.act == 1 &&
+                              d.residual && !d.residual_sp3 && !d.in2 && (d.Ho * d.Wo) % 16 == 0 && d.Ho * d.Wo >= 256),
+                  "x6 conv: the back-to-back form needs the f16x2 3x3 onto 64 columns, ReLU, both biases, an fp32 residual and images of >= 256 pixels (a multiple of 16)");
     RELAX_REQUIRE(h, p.M > 0 && p.N > 0 && p.K > 0, "x6 conv/gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     RELAX_REQUIRE(h, d.Cin % 16 == 0, "x6 conv/gemm: Cin=%d must be a multiple of 16", d.Cin);
     RELAX_REQUIRE(h, p.N % 64 == 0, "x6 conv/gemm: N=%d must be a multiple of 64", p.N);
@@ -998,17 +1244,21 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, aligned16(d.in) && aligned16(d.w) && aligned16(d.bias) && aligned16(d.residual) && aligned16(d.residual_sp3) &&
                          aligned16(d.out) && aligned16(d.out_sp3) && aligned16(d.gap_groups) && aligned16(d.in2),
                   "x6 conv/gemm: every operand pointer must be 16-byte aligned");
-    const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * (double)p.N * (double)p.K;
+    const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * ((double)p.N * (double)p.K + (b2b ? (double)p.N * d.Cout3 : 0.0));
     // algorithmic HBM bytes: activation in (6 B per value), weights, outputs (+ residual), each touched once
+    const double n_out = b2b ? d.Cout3 : p.N;    // (back to back: the outputs and the residual are the conv3's)
     const double bytes = ((d.in_f32 || d.in_h2) ? 4.0 : 6.0) * ((double)d.Nimg * d.H * d.W * d.Cin) +
-                         (d.in_h2 ? 4.0 : 6.0) * ((double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) +
-                         (double)p.M * p.N * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.residual ? 4.0 : 0.0) + (d.residual_sp3 ? 6.0 : 0.0));
+                         (d.in_h2 ? 4.0 : 6.0) * ((double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) + (b2b ? 4.0 * p.N * d.Cout3 : 0.0) +
+                         (double)p.M * n_out * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.out_h2 ? 4.0 : 0.0) + (d.residual ? 4.0 : 0.0) + (d.residual_sp3 ? 6.0 : 0.0));
     int span;
     RELAX_TRY(prof_begin(h, s, d.in_h2 ? 5 : 2, flops, &span, bytes));   // (kind 5 = f16x2: three executed products per fp32 product)
     int rc;
     // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA); N = 128 / 64 layers: the same
     // loop on four waves, two workgroups per CU
-    if (d.in_h2)    // two fp16 planes on both sides: the 3x3 convolutions of layer1 / layer2 under f16x2
+    if (b2b)        // the 3x3 and the block's conv3 back to back (the 3x3's tile stays in registers); 128-row tiles, three workgroups per CU
+        rc = h->gemm.b2b_rows == 256 ? launch_x6_variant<256, 64, 4, 1, true, false, false, false, true, true>(h, p, s)
+                                     : launch_x6_variant<128, 64, 4, 1, true, false, false, false, true, true>(h, p, s);
+    else if (d.in_h2)    // two fp16 planes on both sides: the 3x3 convolutions of layer1 / layer2 under f16x2
         // (N = 128 on EIGHT waves of 64 x 64: the second accumulator does not fit the 128 x 64 wave tile of the four-wave form)
         rc = p.N % 128 == 0 ? launch_x6_variant<256, 128, 4, 2, true, false, false, false, true>(h, p, s)
                             : launch_x6_variant<256, 64, 4, 1, true, false, false, false, true>(h, p, s);

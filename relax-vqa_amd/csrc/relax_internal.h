@@ -98,6 +98,15 @@ struct ConvDescX6 {
     unsigned* amax_out;
     int act;                // 0 none, 1 relu, 2 gelu(erf)
     double flops;           // algorithmic FLOPs for the profiler (0 = 2*M*N*K)
+    // back-to-back form ("rn_fuse", with in_h2): the 3x3 convolution's output tile (bias + ReLU applied) never leaves the CU - it is the A
+    // operand of the block's conv3, a 1x1 onto Cout3 columns with K = Cout.  `bias` is then the 3x3's, act must be 1, and residual /
+    // out / out_rows / out_sp3 / out_h2 / img_out_scale / amax_out / gap_groups / gap_rows describe the conv3 output [M][Cout3]
+    // (ReLU behind the residual add).  w3: h2 weights [Cout3][Cout*4 B] whose K axis is in the accumulator order of the 3x3's
+    // transposed tile (launch_b2b_permute_k), colscale3 their inverse row scales, bias3 [Cout3].
+    const void* w3;
+    const float* colscale3;
+    const float* bias3;
+    int Cout3;
 };
 
 // h2 ("two fp16 planes", csrc/h2.h) operands of the f16x2 kernel (gemm_h2.hip): plain GEMM, N % 256 == 0
@@ -134,6 +143,8 @@ struct ConvW {          // one folded conv (+BN) of ResNet-50
     void* w_sp3 = nullptr;  // the same as split planes (bf16x6 kernel); conv1: [64][224], k = ky*32 + kx*3 + c (conv1_x6.hip)
     void* w_h2 = nullptr;   // layer3 / layer4: the same as two fp16 planes, row n scaled by 2^t_n (gemm_h2.hip)
     float* w_inv = nullptr; // [Cout]: 2^-t_n
+    void* w_h2p = nullptr;  // conv3 of a fused layer1 / layer2 block: fp16 planes with the K axis permuted for the back-to-back form (gemm_x6.hip, B2B)
+    float* w_invp = nullptr;
     float l1max = 0.f;      // max_n sum_k |W[n,k]| of the folded weights and max_n |bias[n]|: Hoelder bound of the outputs from the
     float bmax = 0.f;       // measured maximum of the inputs (per-image scales, gemm_h2.hip)
     float* bias = nullptr;  // device [Cout] (null for the raw conv1)
@@ -254,6 +265,10 @@ struct GemmOptions {
                            // three products, no conversion passes); 0 = attention_x6 on the fp32 qkv output (three bf16 planes, six products)
     int rn_h2_early = 1;   // "rn_h2_early": with "rn_h2", the stem and the 3x3 convolutions of layer1 / layer2 (the MFMA-bound launches in front of layer3) run f16x2 too,
                            // on the four-wave tiles of gemm_x6.hip (conv1 writes its output as fp16 planes with the image's Hoelder scale); 0 = bf16x6 there
+    int rn_fuse = 1;       // "rn_fuse": with "rn_h2_early", the blocks of layer1 / layer2 without a downsample branch run conv2 and conv3 back to back in ONE
+                           // launch (the 3x3's output tile stays in registers as the A operand of the 1x1: no write and re-read of it, conv3 on f16x2
+                           // with one scale per pixel row); 0 = two launches, conv3 on bf16x6 (the A/B switch of a test)
+    int b2b_rows = 128;    // "b2b_rows": rows per tile of the back-to-back launches: 128 (three workgroups of four waves per CU) or 256 (two) - same bits
     int fp32_rows = 1;     // "x6_fp32_rows": bf16x6 contractions onto 64 / 128 columns take fp32 activation rows and split them in the K loop
                            // (ResNet-50 layer1 / layer2 block outputs travel as fp32); 0 = split planes everywhere (same bits, more bytes: the A/B switch of a test)
     int debug_poison = 0;  // "debug_poison": fill every workspace with 0xFF bytes when it is requested (test mode: reads of unwritten workspace surface as NaN)
@@ -302,6 +317,7 @@ inline int launch_gemm(relax_handle* h, const float* A, const float* W, const fl
 
 // bf16x6 contraction kernel (gemm_x6.hip)
 int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s);
+int launch_b2b_permute_k(relax_handle* h, const float* w, float* wp, int rows, int K, hipStream_t s);   // gemm_x6.hip: K order of the back-to-back form
 int launch_to_sp3(relax_handle* h, const float* x, int64_t ld, void* y, int64_t rows, int K, hipStream_t s);
 // conv1_x6.hip: ResNet-50 conv1 on the bf16x6 arithmetic, straight from the uint8 fragments
 int make_conv1_x6_weights(relax_handle* h, const float* w_packed, int kpad, void** w_sp3_out, std::vector<void*>& allocs);

@@ -302,6 +302,37 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
             if (rc != RELAX_OK) { free_resnet(h); return rc; }
         }
     }
+    // ... the conv3 of the layer1 / layer2 blocks without a downsample branch once more as fp16 planes with the K axis in the order of the
+    // back-to-back form ("rn_fuse": gemm_x6.hip, B2B - the 3x3's transposed accumulator tile is the A operand)
+    for (size_t b = 0; b < kFirstH2Block && b < rn.blocks.size(); ++b) {
+        Bottleneck& blk = rn.blocks[b];
+        if (blk.has_down || blk.c3.Cin != 64) continue;        // (the four-wave form: 64-wide blocks)
+        const int K = blk.c3.Cin, Co = blk.c3.Cout;
+        float* perm = nullptr;
+        void* q = nullptr;
+        float* inv = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&perm), sizeof(float) * (size_t)Co * K) != hipSuccess ||
+            hipMalloc(&q, (size_t)Co * K * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&inv), sizeof(float) * (size_t)Co) != hipSuccess) {
+            if (perm) (void)hipFree(perm);
+            if (q) (void)hipFree(q);
+            set_error(h, "resnet50: hipMalloc of the back-to-back conv3 weights failed");
+            free_resnet(h);
+            return RELAX_ERR_NOMEM;
+        }
+        rn.allocs.push_back(q);
+        rn.allocs.push_back(inv);
+        rc = launch_b2b_permute_k(h, blk.c3.w, perm, Co, K, nullptr);
+        if (rc == RELAX_OK) rc = launch_to_h2_rows(h, perm, K, q, Co, K, inv, nullptr);
+        if (rc == RELAX_OK && hipDeviceSynchronize() != hipSuccess) rc = RELAX_ERR_HIP;
+        (void)hipFree(perm);
+        if (rc != RELAX_OK) {
+            set_error(h, "resnet50: building the back-to-back conv3 weights failed");
+            free_resnet(h);
+            return rc;
+        }
+        blk.c3.w_h2p = q;
+        blk.c3.w_invp = inv;
+    }
     // ... and, for the four blocks with a downsample branch, [conv3 | downsample] rows side by side
     for (Bottleneck& blk : rn.blocks) {
         if (!blk.has_down) continue;
@@ -540,6 +571,8 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 }
                 RELAX_TRY(launch_conv_x6(h, d, s));
             }
+            // "rn_fuse": conv2 and conv3 back to back in one launch (the 3x3's tile never leaves the CU; conv3 on f16x2 with one scale per pixel row)
+            const bool fuse = use_early && h->gemm.rn_fuse && !blk.has_down && !handover && blk.c3.w_h2p && cur_is_f32 && blk.c2.stride == 1 && H * H >= 256;
             if (handover || use_early) {
                 ConvDescX6 d2{};
                 d2.in = T1s; d2.Nimg = N; d2.H = H; d2.W = H; d2.Cin = blk.c2.Cin;
@@ -548,10 +581,20 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 d2.w = blk.c2.w_sp3; d2.Cout = blk.c2.Cout; d2.bias = blk.c2.bias; d2.out_sp3 = T2s; d2.act = 1;
                 if (use_early) { d2.in_h2 = 1; d2.w = blk.c2.w_h2; d2.colscale = blk.c2.w_inv; d2.img_in_inv = slot_inv(slot_t1); }
                 if (handover) d2.amax_out = slot_amax(slot_c2);
+                if (fuse) {
+                    d2.out_sp3 = nullptr;
+                    d2.w3 = blk.c3.w_h2p; d2.colscale3 = blk.c3.w_invp; d2.bias3 = blk.c3.bias; d2.Cout3 = Cout;
+                    d2.residual = cur32;
+                    d2.out = need32 ? out32 : nullptr; d2.out_rows = rows32;
+                    d2.out_sp3 = out_is_f32 ? nullptr : othersp;
+                    d2.gap_groups = fuse_mean ? gapws : nullptr; d2.gap_rows = n_ls * HWo;
+                    d2.amax_out = slot_o >= 0 ? slot_amax(slot_o) : nullptr;
+                }
                 RELAX_TRY(launch_conv_x6(h, d2, s));
             } else {
                 RELAX_TRY(run_conv_x6(h, blk.c2, T1s, N, H, H, nullptr, nullptr, T2s, 1, s));
             }
+            if (!fuse) {
             ConvDescX6 d{};
             d.in = T2s; d.Nimg = N; d.H = Ho; d.W = Ho; d.Cin = blk.c3.Cin; d.Ho = Ho; d.Wo = Ho;
             d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
@@ -580,6 +623,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 d.out_h2 = othersp; d.img_out_scale = slot_scale(slot_y); d.amax_out = slot_amax(slot_y);
             }
             RELAX_TRY(launch_conv_x6(h, d, s));
+            }
             if (handover) {
                 cur32 = need32 ? out32 : nullptr;
                 if (need32) out32 = out32 == f32a ? f32b : f32a;

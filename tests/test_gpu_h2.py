@@ -348,7 +348,11 @@ def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
     ls2, pool2, taps2 = eng.resnet50_features(f, taps=range(15))
     ls2b, pool2b = eng.resnet50_features(f)
     assert torch.equal(ls2, ls2b) and torch.equal(pool2, pool2b), "f16x2 ResNet-50 is not deterministic"
+    assert eng.get_option("rn_fuse") == 1
     try:
+        eng.set_option("rn_fuse", 0)          # conv2 and conv3 of the layer1 / layer2 blocks as two launches (conv3 on bf16x6)
+        _, _, taps2nofuse = eng.resnet50_features(f, taps=range(15))
+        eng.set_option("rn_fuse", 1)
         eng.set_option("rn_h2_early", 0)      # layer3 / layer4 only
         _, _, taps2late = eng.resnet50_features(f, taps=range(15))
         eng.set_option("rn_h2", 0)
@@ -356,6 +360,7 @@ def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
     finally:
         eng.set_option("rn_h2", 1)
         eng.set_option("rn_h2_early", 1)
+        eng.set_option("rn_fuse", 1)
     tsd = resnet50_ref.to_torch_state_dict(sd)
     ref_taps, _ = resnet50_ref.forward_taps(tsd, resnet50_ref.preprocess_bgr_u8(frags))
     sd64 = {k: v.double() for k, v in tsd.items()}
@@ -369,9 +374,11 @@ def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
         r = ref64[name].numpy()
         n2, n6, ncpu = rel(taps2[i].cpu().numpy(), r), rel(taps6[i].cpu().numpy(), r), rel(ref_taps[name].numpy(), r)
         n2l = rel(taps2late[i].cpu().numpy(), r)
-        print(f"{name:22s} vs fp64: f16x2 (3x3s of layers 1-2 + layers 3-4) {n2:.3e}  f16x2 layers 3-4 only {n2l:.3e}  bf16x6 everywhere {n6:.3e}  "
-              f"torch CPU fp32 {ncpu:.3e}")
+        n2u = rel(taps2nofuse[i].cpu().numpy(), r)
+        print(f"{name:22s} vs fp64: f16x2 (fused blocks + 3x3s of layers 1-2 + layers 3-4) {n2:.3e}  the same unfused {n2u:.3e}  f16x2 layers 3-4 only {n2l:.3e}  "
+              f"bf16x6 everywhere {n6:.3e}  torch CPU fp32 {ncpu:.3e}")
         assert n2 <= 1.25 * n6 + 1e-9 and n2 <= ncpu, name
+        assert n2u <= 1.25 * n6 + 1e-9 and n2u <= ncpu, name
         assert n2l <= 1.25 * n6 + 1e-9 and n2l <= ncpu, name
         if adv == "outliers" and i > 0:     # the same gate without the hot channel (it carries most of a norm over all channels)
             cm = np.abs(r).max(axis=(0, 2, 3))
@@ -383,6 +390,23 @@ def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
             assert torch.equal(taps2late[i], taps6[i]), f"{name}: without rn_h2_early layer1 / layer2 run the same kernels either way"
     assert_close(ls2, resnet50_ref.layer_stack_features(tsd, frags), "f16x2 layer-stack")
     assert_close(pool2, resnet50_ref.pool_features(tsd, frags), "f16x2 pool")
+
+
+def test_back_to_back_blocks_give_the_same_bits_on_both_tile_heights(h2):
+    """"b2b_rows": the fused conv2 -> conv3 launches on 128-row tiles (three workgroups per CU, the default) and on 256-row tiles: every
+    row's arithmetic is its own (one scale per pixel row, 16-row groups of the fused mean), so the features are the same bits."""
+    rn50_weights()
+    f = torch.from_numpy(_fragments(3, seed=5)).cuda()
+    assert h2.get_option("rn_fuse") == 1 and h2.get_option("b2b_rows") == 128
+    ls_a, pool_a, taps_a = h2.resnet50_features(f, taps=range(15))
+    try:
+        h2.set_option("b2b_rows", 256)
+        ls_b, pool_b, taps_b = h2.resnet50_features(f, taps=range(15))
+    finally:
+        h2.set_option("b2b_rows", 128)
+    assert torch.equal(ls_a, ls_b) and torch.equal(pool_a, pool_b)
+    for a, b in zip(taps_a, taps_b):
+        assert torch.equal(a, b)
 
 
 def test_resnet50_rows_do_not_depend_on_the_batch_under_f16x2(h2):
