@@ -71,6 +71,9 @@
 #ifndef X6_B2B_ABL
 #define X6_B2B_ABL 0
 #endif
+#ifndef X6_H2_STAGES
+#define X6_H2_STAGES 3
+#endif
 
 namespace relax {
 
@@ -186,7 +189,9 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
     constexpr int A_PIECES = A_BYTES / 1024;
     constexpr int PPW = (PIECES + NW - 1) / NW;   // pieces per wave (a wave short of real pieces issues dummy ones)
     constexpr int A_PPW = A_PIECES / NW;
-    constexpr int NSTG = (M16 && !TAPS && !DUAL) ? 3 : 2;   // LDS stages (three: the 16x16x32 loop of the plain GEMMs, see X6_REGION16; the implicit-GEMM and two-source forms would spill)
+    // LDS stages (three: the 16x16x32 loop of the plain GEMMs, see X6_REGION16 - its implicit-GEMM and two-source forms would spill -, and the
+    // f16x2 3x3 form, whose K loop waits for L2: a piece then has two steps to land instead of one, see X6_REGION3)
+    constexpr int NSTG = ((M16 && !TAPS && !DUAL) || (H2 && X6_H2_STAGES == 3)) ? 3 : 2;
     constexpr int DUMMY = NSTG * STAGE;           // 1 KiB nobody reads
     static_assert(ROWS % 32 == 0 && TM >= 1 && TN >= 1 && YT % 2 == 0 && A_PIECES % NW == 0, "tile / wave layout mismatch");
     static_assert(!M16 || (TM == 4 && TN == 2 && PPW <= 7), "the 16x16x32 loop is written for 128 x 64 per wave");
@@ -506,6 +511,26 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         }                                                                                                               \
     }
 
+    // The same region with THREE stages (H2): step k + 3 is requested in region k into the stage step k just left, and region k waits only for
+    // the pieces of step k + 1 - those of step k + 2, this wave's newest PPW, stay in flight (vmcnt counts in issue order).  st_ = k % 3.
+#define X6_REGION3(xs_, st_, has_next_, has_n2_, has_d_)                                                                \
+    {                                                                                                                   \
+        const char* sn_ = smem + (((st_) + 1) % 3) * STAGE;                                                             \
+        if (has_next_) {                                                                                                \
+            if (has_n2_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");                          \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+            __builtin_amdgcn_s_barrier();                                                                               \
+            if (has_d_) X6_ISSUE(st_);                                                                                  \
+            X6_READ_X((xs_) ^ 1, sn_);                                                                                  \
+            X6_READ_Y(yf0, 0, sn_);                                                                                     \
+        }                                                                                                               \
+        X6_MFMAS(xs_, yf1, 1);                                                                                          \
+        if (has_next_) {                                                                                                \
+            X6_READ_Y(yf1, 1, sn_);                                                                                     \
+            X6_MFMAS((xs_) ^ 1, yf0, 0);                                                                                \
+        }                                                                                                               \
+    }
+
     // ---- the same loop on v_mfma_f32_16x16x32_bf16 (M16).  The 32-deep K of that instruction takes TWO planes of a 16-deep
     // chunk: lanes with k group g = lane >> 4 < 2 read the halves of the first plane of a pair, g >= 2 those of the second, so
     //     A[lo|hi] B[hi|lo] = al bh + ah bl,   A[mid|hi] B[hi|mid] = am bh + ah bm,   A[hi|mid] B[hi|mid] = ah bh + am bm
@@ -635,6 +660,24 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
     X6_READ_Y(yf1, 1, smem);
     X6_MFMAS(0, yf0, 0);          // M0 of step 0
     int k = 0;
+    if constexpr (NSTG == 3) {   // six regions = one period of (register set, stage)
+        for (; k + 6 + 3 <= nk; k += 6) {
+            X6_REGION3(0, 0, true, true, true);
+            X6_REGION3(1, 1, true, true, true);
+            X6_REGION3(0, 2, true, true, true);
+            X6_REGION3(1, 0, true, true, true);
+            X6_REGION3(0, 1, true, true, true);
+            X6_REGION3(1, 2, true, true, true);
+        }
+        for (; k < nk; k += 6) {
+            X6_REGION3(0, 0, k + 1 < nk, k + 2 < nk, k + 3 < nk);
+            if (k + 1 < nk) X6_REGION3(1, 1, k + 2 < nk, k + 3 < nk, k + 4 < nk);
+            if (k + 2 < nk) X6_REGION3(0, 2, k + 3 < nk, k + 4 < nk, k + 5 < nk);
+            if (k + 3 < nk) X6_REGION3(1, 0, k + 4 < nk, k + 5 < nk, k + 6 < nk);
+            if (k + 4 < nk) X6_REGION3(0, 1, k + 5 < nk, k + 6 < nk, k + 7 < nk);
+            if (k + 5 < nk) X6_REGION3(1, 2, k + 6 < nk, k + 7 < nk, k + 8 < nk);
+        }
+    } else {
     // region k: has_next = step k+1 exists; has_d = step k+2 exists (its DMA is issued here)
     for (; k + 3 < nk; k += 2) {
         X6_REGION(0, true, true);
@@ -645,6 +688,8 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         if (k + 1 < nk) X6_REGION(1, k + 2 < nk, k + 3 < nk);
     }
     }
+    }
+#undef X6_REGION3
 #undef X6_REGION16
 #undef X6_MFMAS16
 #undef X6_READ_A16
@@ -1156,7 +1201,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     }
     constexpr int CH = H2 ? kH2ChunkBytes : kChunkBytes;
     // (B2B: the waves' own staging rows of the conv3 passes, 64 x 68 floats each, + the row scales + two maxima: 70.7 KB, two workgroups per CU)
-    constexpr size_t stages_lds = ((M16 && !TAPS && !DUAL) ? 3 : 2) * (size_t)(BM * (AF32 ? 64 : CH) + BN * CH);
+    constexpr size_t stages_lds = (((M16 && !TAPS && !DUAL) || (H2 && X6_H2_STAGES == 3)) ? 3 : 2) * (size_t)(BM * (AF32 ? 64 : CH) + BN * CH);
     constexpr size_t b2b_stg = (size_t)(WM * WN) * (BM / WM) * 68 * 4;     // the waves' own staging rows of the conv3 passes
     constexpr size_t lds = B2B ? (b2b_stg > stages_lds ? b2b_stg : stages_lds) + 1024 + 64 : stages_lds + 1024;
     static bool attr_set[kMaxDevices] = {};
@@ -1255,7 +1300,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     int rc;
     // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA); N = 128 / 64 layers: the same
     // loop on four waves, two workgroups per CU
-    if (b2b)        // the 3x3 and the block's conv3 back to back (the 3x3's tile stays in registers); 128-row tiles, three workgroups per CU
+    if (b2b)        // the 3x3 and the block's conv3 back to back (the 3x3's tile stays in registers)
         rc = h->gemm.b2b_rows == 256 ? launch_x6_variant<256, 64, 4, 1, true, false, false, false, true, true>(h, p, s)
                                      : launch_x6_variant<128, 64, 4, 1, true, false, false, false, true, true>(h, p, s);
     else if (d.in_h2)    // two fp16 planes on both sides: the 3x3 convolutions of layer1 / layer2 under f16x2

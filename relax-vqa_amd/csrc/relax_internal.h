@@ -268,7 +268,8 @@ struct GemmOptions {
     int rn_fuse = 1;       // "rn_fuse": with "rn_h2_early", the blocks of layer1 / layer2 without a downsample branch run conv2 and conv3 back to back in ONE
                            // launch (the 3x3's output tile stays in registers as the A operand of the 1x1: no write and re-read of it, conv3 on f16x2
                            // with one scale per pixel row); 0 = two launches, conv3 on bf16x6 (the A/B switch of a test)
-    int b2b_rows = 128;    // "b2b_rows": rows per tile of the back-to-back launches: 128 (three workgroups of four waves per CU) or 256 (two) - same bits
+    int b2b_rows = 256;    // "b2b_rows": rows per tile of the back-to-back launches: 256 (two workgroups of four waves per CU) or 128 (three: measured
+                           // slower, 2.49 against 2.13 ms per launch of layer1) - same bits
     int fp32_rows = 1;     // "x6_fp32_rows": bf16x6 contractions onto 64 / 128 columns take fp32 activation rows and split them in the K loop
                            // (ResNet-50 layer1 / layer2 block outputs travel as fp32); 0 = split planes everywhere (same bits, more bytes: the A/B switch of a test)
     int debug_poison = 0;  // "debug_poison": fill every workspace with 0xFF bytes when it is requested (test mode: reads of unwritten workspace surface as NaN)

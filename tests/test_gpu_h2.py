@@ -393,20 +393,20 @@ def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
 
 
 def test_back_to_back_blocks_give_the_same_bits_on_both_tile_heights(h2):
-    """"b2b_rows": the fused conv2 -> conv3 launches on 128-row tiles (three workgroups per CU, the default) and on 256-row tiles: every
+    """"b2b_rows": the fused conv2 -> conv3 launches on 128-row tiles (three workgroups per CU: measured slower, 2.49 against 2.13 ms per launch) and on 256-row tiles (the default): every
     row's arithmetic is its own (one scale per pixel row, 16-row groups of the fused mean), so the features are the same bits."""
     rn50_weights()
     f = torch.from_numpy(_fragments(3, seed=5)).cuda()
-    assert h2.get_option("rn_fuse") == 1 and h2.get_option("b2b_rows") == 128
+    assert h2.get_option("rn_fuse") == 1 and h2.get_option("b2b_rows") == 256
     ls_a, pool_a, taps_a = h2.resnet50_features(f, taps=range(15))
     try:
-        h2.set_option("b2b_rows", 256)
+        h2.set_option("b2b_rows", 128)
         ls_b, pool_b, taps_b = h2.resnet50_features(f, taps=range(15))
     finally:
-        h2.set_option("b2b_rows", 128)
+        h2.set_option("b2b_rows", 256)
     assert torch.equal(ls_a, ls_b) and torch.equal(pool_a, pool_b)
-    for a, b in zip(taps_a, taps_b):
-        assert torch.equal(a, b)
+    for i in range(15):
+        assert torch.equal(taps_a[i], taps_b[i]), i
 
 
 def test_resnet50_rows_do_not_depend_on_the_batch_under_f16x2(h2):
