@@ -60,10 +60,36 @@ int upload(relax_handle* h, const float* host, size_t n, float** dev, std::vecto
     return RELAX_OK;
 }
 
+// folds the finished spans at the front of the list into the totals (in order; stops at the first span that is still open or whose stop
+// event has not completed) and gives their events back to the pool
+static void prof_reap(relax_handle* h) {
+    Profiler& p = h->prof;
+    size_t n = 0;
+    while (n < p.spans.size() && p.spans[n].ended && hipEventQuery(p.spans[n].stop) == hipSuccess) {
+        ProfSpan& sp = p.spans[n];
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.start, sp.stop) == hipSuccess) {
+            p.total_ms[sp.kind] += ms;
+            p.total_work[sp.kind] += sp.work;
+            p.total_bytes[sp.kind] += sp.bytes;
+            p.launches[sp.kind] += 1;
+        }
+        p.pool.push_back(sp.start);
+        p.pool.push_back(sp.stop);
+        ++n;
+    }
+    (void)hipGetLastError();   // (hipErrorNotReady of the query that ended the loop is not an error of the caller)
+    if (n) {
+        p.spans.erase(p.spans.begin(), p.spans.begin() + (long)n);
+        p.span_base += (int)n;
+    }
+}
+
 int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_idx, double bytes) {
     *span_idx = -1;
     Profiler& p = h->prof;
     if (!p.on) return RELAX_OK;
+    if (p.spans.size() >= Profiler::kReapAt) prof_reap(h);
     ProfSpan sp;
     for (hipEvent_t* ev : {&sp.start, &sp.stop}) {
         if (!p.pool.empty()) {
@@ -76,21 +102,27 @@ int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_
     sp.work = work;
     sp.bytes = bytes;
     sp.kind = kind;
+    sp.ended = false;
     RELAX_HIP_CHECK(h, hipEventRecord(sp.start, s));
     RELAX_HIP_CHECK(h, hipEventRecord(sp.stop, s));     // re-recorded by prof_end; an error path that never gets there leaves an empty span, not an unrecorded event
     p.spans.push_back(sp);
-    *span_idx = static_cast<int>(p.spans.size()) - 1;
+    *span_idx = p.span_base + static_cast<int>(p.spans.size()) - 1;
     return RELAX_OK;
 }
 
 int prof_end(relax_handle* h, hipStream_t s, int span_idx) {
     if (span_idx < 0) return RELAX_OK;
-    RELAX_HIP_CHECK(h, hipEventRecord(h->prof.spans[span_idx].stop, s));
+    Profiler& p = h->prof;
+    const int pos = span_idx - p.span_base;
+    if (pos < 0 || pos >= static_cast<int>(p.spans.size())) return RELAX_OK;   // (the profiler was switched off and on in between)
+    RELAX_HIP_CHECK(h, hipEventRecord(p.spans[pos].stop, s));
+    p.spans[pos].ended = true;
     return RELAX_OK;
 }
 
 void prof_abort(relax_handle* h, int span_idx) {
     Profiler& p = h->prof;
+    span_idx -= p.span_base;
     if (span_idx < 0 || span_idx != static_cast<int>(p.spans.size()) - 1) return;
     p.pool.push_back(p.spans.back().start);
     p.pool.push_back(p.spans.back().stop);
@@ -110,6 +142,7 @@ static int prof_drain(relax_handle* h) {
         p.pool.push_back(sp.start);
         p.pool.push_back(sp.stop);
     }
+    p.span_base += static_cast<int>(p.spans.size());
     p.spans.clear();
     return RELAX_OK;
 }
@@ -280,6 +313,10 @@ int relax_get_option(relax_handle* h, const char* key, int* value) {
     else if (k == "h2_stages") *value = h->gemm.h2_stages;
     else if (k == "h2_form") *value = h->gemm.h2_form;
     else if (k == "debug_poison") *value = h->gemm.debug_poison;
+    // read-only counters (leak checks of a long pass): HIP events this handle owns (pooled + in spans), bytes of its workspaces in MiB
+    else if (k == "profile_events") *value = (int)(h->prof.pool.size() + 2 * h->prof.spans.size());
+    else if (k == "workspace_mib")
+        *value = (int)((h->arena.bytes + h->scratch.bytes + h->splitk_ws.bytes + h->sp3_ws.bytes + h->resize_ws.bytes + h->flow_ws.bytes + h->head_ws.bytes) >> 20);
     else {
         set_error(h, "relax_get_option: unknown option '%s'", key);
         return RELAX_ERR_INVALID;

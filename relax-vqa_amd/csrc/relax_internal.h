@@ -222,11 +222,15 @@ struct ProfSpan {
     double work;
     double bytes;  // algorithmic HBM bytes of the launch (contraction kernel), 0 otherwise
     int kind;
+    bool ended;    // prof_end has re-recorded `stop` (an open span - the Farneback stage around its kernels' spans - is never reaped)
 };
 
 struct Profiler {
     bool on = false;
-    std::vector<ProfSpan> spans;
+    std::vector<ProfSpan> spans;   // span_idx handed out by prof_begin = span_base + position here
+    int span_base = 0;             // spans reaped so far (prof_begin folds finished spans into the totals once kReapAt have piled up:
+                                   // a pass of thousands of clips with the profiler on keeps a bounded number of HIP events)
+    static constexpr size_t kReapAt = 2048;
     std::vector<hipEvent_t> pool;
     // span kinds: 0 fp32 / bf16x3 contraction, 1 patch score, 2 bf16x6 contraction, 3 Farneback iteration kernel, 4 the whole Farneback stage,
     // 5 f16x2 contraction, convolution form (gemm_h2.hip, gemm_x6<H2>, conv1_x6<H2>, the fused blocks), 6 f16x2 plain GEMMs (the ViT's: the dominant kernel)
