@@ -48,6 +48,12 @@
 #define H2_STAMPS_BEFORE_LAUNCH(h_, p_, units_)
 #define H2_STAMPS_AFTER_LAUNCH(h_, p_, units_, s_)
 #endif
+// hooks of the diagnostic build "h3b2b" (tools/build_ablations.sh; WRONG results, timing only - what a conv2 -> conv3 fusion of layer3 / layer4
+// could return at most): the 1x1 launches with a residual (the conv3s) never fetch their activation rows, the 3x3 launches never store planes
+#ifndef H3_ABL_NO_A
+#define H3_ABL_NO_A(taps_, perimg_, p_) false
+#define H3_ABL_NO_OUT_H2(taps_, p_) false
+#endif
 #ifndef H3_KSTEP
 #define H3_KSTEP(k_) (k_)   // the K step a DMA piece of a plain gemm_h3 reads (the diagnostic build can wrap it so that every piece hits L2)
 #endif
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
         const int off = (unit >> 1) * kH2ChunkBytes + (unit & 1) * 16;
         if (q >= 2) {
             voff[q] = (unsigned)((trow - BM) * (int)row_bytes + off);
-        } else if (m0 + trow >= p.M) {
+        } else if (m0 + trow >= p.M || H3_ABL_NO_A(TAPS, PERIMG, p)) {
             voff[q] = kH2OutOfRange;
         } else if (p.pixels) {
             const int m = m0 + trow;
@@ -871,7 +877,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcA) = va;
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcB) = vb;
             }
-            if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, os[it]);   // (planes: lcB = lcA + 4)
+            if (p.out_h2 && !H3_ABL_NO_OUT_H2(TAPS, p)) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, os[it]);   // (planes: lcB = lcA + 4)
             if (PERIMG && p.amax_out) {
                 // the largest output of this row segment (outputs are >= 0: these launches end in a ReLU), over the 32 lanes that share
                 // the row, into the image's slot: integer max of the bits = float max, order-free, so the maximum - and every scale

@@ -10,6 +10,10 @@
     (p_).stamps = static_cast<unsigned long long*>((h_)->scratch.p)
 #define H2_STAMPS_AFTER_LAUNCH(h_, p_, units_, s_) RELAX_TRY((h2_report_stamps(h_, p_, units_, s_)))
 
+#ifdef H3_B2B_BOUND   // (tools/build_ablations.sh h3b2b) WRONG results: the conv3 launches of layer3 / layer4 never fetch their A operand and the 3x3
+#define H3_ABL_NO_A(taps_, perimg_, p_) ((perimg_) && !(taps_) && ((p_).residual != nullptr || (p_).residual_h2 != nullptr))   // launches never store
+#define H3_ABL_NO_OUT_H2(taps_, p_) (taps_)                                                                                  // their planes
+#endif
 #ifdef H3_L2HIT   // (tools/build_ablations.sh h2l2hit) every K step of a plain gemm_h3 re-reads the first four: WRONG results, the K loop with
 #define H3_KSTEP(k_) ((k_) & 3)   // every DMA piece served by L2 - the bound of what prefetching into L2 could return
 #endif

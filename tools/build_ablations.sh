@@ -6,6 +6,8 @@
 #   tools/build_ablations.sh h2stamps       f16x2 kernel with per-phase cycle stamps (prints per launch, syncs)
 #   tools/build_ablations.sh h2l2hit        the same with every K step of a plain gemm_h3 re-reading the first four (WRONG results: the K loop with
 #                                           every DMA piece served by L2)
+#   tools/build_ablations.sh h3b2b          the f16x2 kernel with the conv3 launches of ResNet-50's layer3 / layer4 never fetching their A operand and the 3x3
+#                                           launches never storing their planes (WRONG results: the most a conv2 -> conv3 fusion there could return)
 #   tools/build_ablations.sh flowstamps     fused Farneback iteration with tick stamps per phase of a step (tools/flow_stamps.py prints them)
 #   tools/build_ablations.sh a6stamps       bf16x6 attention kernel with ticks per phase of an item (tools/attn_stamps.py prints them;
 #                                           overwrites the first floats of the fp32 output: timing only)
@@ -20,7 +22,7 @@ make -s
 mkdir -p ../../tools/abl
 CC="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-function"
 FLOWCC="$CC -fno-slp-vectorize -ffp-contract=off"   # as the Makefile builds flow.hip
-OBJS="api.o fragment.o flow.o resize.o gemm.o gemm_x6.o gemm_h2.o conv1_x6.o attention_x6.o layers.o resnet50.o vit.o head.o host_logic.o"
+OBJS="api.o fragment.o flow.o resize.o gemm.o gemm_x6.o gemm_h2.o conv1_x6.o attention_x6.o attention_h2.o layers.o resnet50.o vit.o head.o host_logic.o"
 link() {  # link <replaced object> <new object> <output name>
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 ${OBJS/$1/$2} -o ../../tools/abl/librelax_$3.so
 }
@@ -28,6 +30,7 @@ for n in "$@"; do
   case "$n" in
     x6stamps) $CC -I. -c ../../tools/abl/gemm_x6_stamps.hip -o /tmp/gemm_x6_stamps.o; link gemm_x6.o /tmp/gemm_x6_stamps.o x6stamps ;;
     h2stamps) $CC -I. -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_stamps.o; link gemm_h2.o /tmp/gemm_h2_stamps.o h2stamps ;;
+    h3b2b) $CC -I. -DH3_B2B_BOUND -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_b2b.o; link gemm_h2.o /tmp/gemm_h2_b2b.o h3b2b ;;
     h2l2hit) $CC -I. -DH3_L2HIT -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_l2hit.o; link gemm_h2.o /tmp/gemm_h2_l2hit.o h2l2hit ;;
     flowstamps) $FLOWCC -I. -c ../../tools/abl/flow_stamps.hip -o /tmp/flow_stamps.o; link flow.o /tmp/flow_stamps.o flowstamps ;;
     a6stamps) $CC -I. -c ../../tools/abl/attention_x6_stamps.hip -o /tmp/attention_x6_stamps.o; link attention_x6.o /tmp/attention_x6_stamps.o a6stamps ;;
