@@ -120,6 +120,13 @@ int prof_end(relax_handle* h, hipStream_t s, int span_idx) {
     return RELAX_OK;
 }
 
+void prof_set_work(relax_handle* h, int span_idx, double work) {
+    if (span_idx < 0) return;
+    Profiler& p = h->prof;
+    const int pos = span_idx - p.span_base;
+    if (pos >= 0 && pos < static_cast<int>(p.spans.size())) p.spans[pos].work = work;
+}
+
 void prof_abort(relax_handle* h, int span_idx) {
     Profiler& p = h->prof;
     span_idx -= p.span_base;

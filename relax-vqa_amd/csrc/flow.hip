@@ -1532,7 +1532,7 @@ static int flow_chunk(relax_handle* h, const uint8_t* orig, const uint8_t* next,
         RELAX_TRY(visualise(h, prev_flow, P, (int)HW, bgr_out, mm, s, true));
         stage_bytes += 11.0 * P * HW;              // the flow read, 3 bytes per pixel written
     }
-    if (stage_span >= 0) h->prof.spans[stage_span].work = stage_bytes;
+    prof_set_work(h, stage_span, stage_bytes);
     RELAX_TRY(prof_end(h, s, stage_span));
     return RELAX_OK;
 }

@@ -307,6 +307,7 @@ int upload(relax_handle* h, const float* host, size_t n, float** dev, std::vecto
 // profiling helpers: call around a launch; no-ops when profiling is off
 int prof_begin(relax_handle* h, hipStream_t s, int kind, double work, int* span_idx, double bytes = 0);
 int prof_end(relax_handle* h, hipStream_t s, int span_idx);
+void prof_set_work(relax_handle* h, int span_idx, double work);   // the work of an open span, known only at its end (span ids are not vector positions)
 void prof_abort(relax_handle* h, int span_idx);   // a launch failed between begin and end: drop the half-recorded span
 
 // contraction kernel launcher (gemm.hip)

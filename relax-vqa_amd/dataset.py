@@ -206,10 +206,13 @@ class ClipStager:
     def give_back(self, bufs):
         """Buffers whose copies have landed (or that were never used) go back to the pool - their bytes back to the budget -, up to this
         rank's share of the node's pinned budget; beyond it they are dropped (unpinned and freed)."""
+        shm = [b for b in bufs if b is not None and hasattr(b, "release")]   # clips of a loader-process pool: their segment goes back to its worker
+        for b in shm:
+            b.release()
+        bufs = [b for b in bufs if b is not None and not hasattr(b, "release")]
         if self.gated:
             for b in bufs:
-                if b is not None:
-                    self.gate.release(b.numel())
+                self.gate.release(b.numel())
         with self._lock:
             for b in bufs:
                 if b is None:
@@ -380,7 +383,7 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
     # the `alloc` protocol: a loader `clips(i, alloc=f)` asks f(shape) for the uint8 array it decodes into - pinned staging memory of
     # this rank's pool - and returns it (or a view of it): no pageable copy of the clip exists and nothing is copied on the host
     takes_alloc = False
-    if callable(clips) and stager is not None:
+    if callable(clips) and stager is not None and not hasattr(clips, "fetch"):      # (a LoaderProcessPool brings its own staging memory)
         try:
             takes_alloc = "alloc" in inspect.signature(clips).parameters
         except (TypeError, ValueError):
@@ -426,7 +429,7 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
         ("err", message).  Never raises.  Whatever happens, the clip's turn at the pinned budget is taken or given up (the clips
         behind it wait for that)."""
         seq, took = seq_of[i], [False]
-        handed, keep = [], [None]                       # pinned buffers this call's `alloc` gave out; the one the clip is returned in
+        handed, keep, shm = [], [None], [None]          # pinned buffers this call's `alloc` gave out; the one the clip is returned in; a pool's clip
 
         def my_turn():
             first, took[0] = not took[0], True
@@ -450,6 +453,13 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
                 clip = get(i, alloc=alloc)
             else:
                 clip = get(i)
+            if hasattr(clip, "release") and hasattr(clip, "tensor"):     # loaderpool.ShmClip: decoded by a loader PROCESS into shared memory the
+                shm[0] = clip                                            # parent has page-locked - copied from where it lies, handed back after
+                _check_clip(clip.tensor)
+                if stager is None or not stager.on_gpu:                  # (a CPU 'device' uses clips where they lie, until its compute is through:
+                    return ("clip", clip.tensor.clone(), None)           # the segment goes back to its worker now - `finally` below - not then)
+                keep[0] = clip
+                return ("clip", clip.tensor, clip)
             _check_clip(clip)
             t = clip if isinstance(clip, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(clip))
             if t.is_cuda or stager is None:
@@ -466,6 +476,8 @@ def extract_dataset_clips(clips, n_clips, engine, *, clips_per_step=16, resnet=T
             # buffers `alloc` handed out go back to the budget, except the one the returned clip lives in
             if handed:
                 stager.give_back([b for b in handed if b is not keep[0]])
+            if shm[0] is not None and shm[0] is not keep[0]:
+                shm[0].release()
             if stager is not None and not took[0]:
                 stager.gate.skip(seq)
 
