@@ -1,8 +1,9 @@
 """Loader PROCESSES for the dataset pass: the decode of a from-files run (sampling.load_clip_from_frames: Pillow PNG decode, np copies)
-tops out at about 975 decodes/s in ONE process however many loader threads it has (the GIL: profiles/r05_from_files_config4.json), a
-seventh of what one MI355X consumes at config 4.  This pool moves the decode into P worker processes that write every clip straight
-into shared memory which the parent has page-locked (hipHostRegister), so the clip still goes host -> device from where it was decoded,
-without a copy on the host:
+leaves the driver process.  P worker processes write every clip straight into shared memory which the parent has page-locked
+(hipHostRegister), so the clip still goes host -> device from where it was decoded, without a copy on the host.  (Measured,
+profiles/r06_from_files_config4.json: a 960 x 540 PNG costs 13.7 ms of a core; on the 16-CPU quota of a GPU box 16 processes reach
+1137 decodes/s against 964 of 16 loader threads - the wall there is CPU time, which round 5 had read as the GIL; a host with the
+cores - one MI355X consumes 7300 decodes/s at config 4 - needs processes to use them.)
 
     worker p:  clip = source(i, alloc)      alloc(shape) -> a numpy view of one of the worker's shared-memory segments
                -> ("ok", segment name, shape)                 (or ("err", message): the clip fails, the pass goes on)
