@@ -319,6 +319,8 @@ __global__ __launch_bounds__(256) void ah_from_h2(const char* __restrict__ y, fl
     *reinterpret_cast<ah_f32x4*>(dst + 4) = (ah_f32x4){o[4], o[5], o[6], o[7]};
 }
 
+// (operator level, tests: ONE scale from the maximum of the whole qkv tensor of the call - not batch-invariant, unlike the engine's ViT path,
+// which hands the kernel planes written with a static scale: csrc/h2.h)
 int launch_attention_h2_op(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s) {
     RELAX_REQUIRE(h, Nimg > 0 && heads > 0 && qkv && out, "attention_h2 (operator): Nimg=%d heads=%d", Nimg, heads);
     const int dim = heads * 64;

@@ -63,8 +63,9 @@
 #define X6_STAMPS_AFTER_LAUNCH(BM_, BN_, h_, p_, units_, s_)
 #endif
 
-// experiment switches of the back-to-back tail (tools/abl_r06 builds; the product compiles the defaults): B fragments of a whole pass
-// requested one pass ahead (measured slower: 16 spilled registers), timing-only ablations (bit 0 no fp32 stores, 1 no residual loads, 2 no conv3)
+// experiment switches of the back-to-back tail (tools/abl_r06 builds; the product compiles the defaults): B fragments of conv3 requested
+// per K chunk right before their MFMAs (0: the default, 2.07 ms per launch of layer1), a whole pass ahead (1: 16 spilled registers, 2.21 ms), or the
+// first half of the next pass ahead of this pass's stores and the second half at the pass's start (2: 14 spilled, 2.17 ms); timing-only ablations (bit 0 no fp32 stores, 1 no residual loads, 2 no conv3)
 #ifndef X6_B2B_PREFETCH_B
 #define X6_B2B_PREFETCH_B 0
 #endif
@@ -784,6 +785,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         const int voff_row = (lr * p.N3 + lc) * 4;
         const int voff_w3 = c32 * (int)w3row + half * 16;
         f16x8 bh[X6_B2B_PREFETCH_B ? 2 * TN : 1][2], bl[X6_B2B_PREFETCH_B ? 2 * TN : 1][2];
+        constexpr int QPRE = X6_B2B_PREFETCH_B == 2 ? TN : 2 * TN;   // chunks of the next pass requested ahead of this pass's stores (mode 2: the first half)
         u32x4 ra[4], rb[4];
 #define X6_B2B_LOAD_BQ(pass_, q_, slot_)                                                                                \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                  \
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         }                                                                                                               \
     }
         if (X6_B2B_ABL & 4) return;
-        if (X6_B2B_PREFETCH_B) X6_B2B_LOAD_B(0);
+        if (X6_B2B_PREFETCH_B) { _Pragma("unroll") for (int q = 0; q < QPRE; ++q) X6_B2B_LOAD_BQ(0, q, q); }
         for (int pass = 0; pass < npass; ++pass) {
             const int n0p = pass * 64;
             {
@@ -847,6 +849,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
                 for (int q = 0; q < 2 * TN; ++q) {
                     constexpr int slot = X6_B2B_PREFETCH_B ? -1 : 0;
                     if (!X6_B2B_PREFETCH_B) X6_B2B_LOAD_BQ(pass, q, 0);
+                    if (X6_B2B_PREFETCH_B == 2 && q == 0) { _Pragma("unroll") for (int q2 = QPRE; q2 < 2 * TN; ++q2) X6_B2B_LOAD_BQ(pass, q2, q2); }
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             }
             const f32x4 cs_a = *reinterpret_cast<const f32x4*>(p.colscale3 + n0p + lc), cs_b = *reinterpret_cast<const f32x4*>(p.colscale3 + n0p + lc + 4);
             const f32x4 b3_a = *reinterpret_cast<const f32x4*>(p.bias3 + n0p + lc), b3_b = *reinterpret_cast<const f32x4*>(p.bias3 + n0p + lc + 4);
-            if (X6_B2B_PREFETCH_B && pass + 1 < npass) X6_B2B_LOAD_B(pass + 1);
+            if (X6_B2B_PREFETCH_B && pass + 1 < npass) { _Pragma("unroll") for (int q = 0; q < QPRE; ++q) X6_B2B_LOAD_BQ(pass + 1, q, q); }
             X6_B2B_LOAD_RES(pass, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local: this wave's stores have reached the LDS before its loads
             __builtin_amdgcn_wave_barrier();

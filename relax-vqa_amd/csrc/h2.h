@@ -13,7 +13,10 @@
 //   ViT activations    one STATIC power of two per tensor from a bound that holds for every input (LayerNorm output: |z_i| <=
 //                      sqrt(dim - 1); GEMM outputs: Cauchy-Schwarz with the weight rows; attention output: a convex combination of
 //                      V rows; GELU(x): |GELU(x)| <= |x|): no data-dependent scale, so every row's bits are independent of the batch
-//   operator level     per row of A, from the row's own maximum (to_h2_rows): batch-invariant as well
+//   operator level     per row of A, from the row's own maximum (to_h2_rows): batch-invariant as well.  ONE exception: relax_op_attention
+//                      (attention_h2.hip, launch_attention_h2_op) takes one scale from the maximum of the WHOLE qkv tensor it is handed, so an
+//                      image's output bits there depend on what else is in the call - it is the test entry of the kernel; the engine's ViT
+//                      path feeds the same kernel planes written with the static Cauchy-Schwarz scale of the qkv GEMM (vit.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: variants of the f16x2 3x3 / back-to-back kernels (tools/abl_r06/*.so; "nophase2" gives WRONG results: timing only)
+# round 6: variants of the back-to-back kernel's tail (tools/abl_r06/librelax_<tag>.so, built by hand from gemm_x6.hip with -DX6_B2B_PREFETCH_B=<n>)
 : "${GRAFT_REPO_ROOT:=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 R=$GRAFT_REPO_ROOT
 cd $R
@@ -11,8 +11,5 @@ run() {  # run <tag> <lib or "">
   echo "== $1: $(python3 $R/tools/trace_order.py $f conv1_x6 | grep 'gemm_x6<256, [0-9]*, 4, [12], true' | awk '{printf "%s ", $2}')"
   cd $R
 }
-python -m pytest tests/test_gpu_h2.py tests/test_gpu_backbones.py tests/test_gpu_x6.py -m gpu -q -x -k "resnet50 or back_to_back or conv" 2>&1 | tail -3
-run product ""
-run stg2 stg2
-run nophase2 nophase2
-run product2 ""
+for t in "$@"; do run $t $t; done
+for t in "$@"; do run ${t}_again $t; done
