@@ -63,9 +63,11 @@
 #define X6_STAMPS_AFTER_LAUNCH(BM_, BN_, h_, p_, units_, s_)
 #endif
 
-// experiment switches of the back-to-back tail (tools/abl_r06 builds; the product compiles the defaults): B fragments of conv3 requested
-// per K chunk right before their MFMAs (0: the default, 2.07 ms per launch of layer1), a whole pass ahead (1: 16 spilled registers, 2.21 ms), or the
-// first half of the next pass ahead of this pass's stores and the second half at the pass's start (2: 14 spilled, 2.17 ms); timing-only ablations (bit 0 no fp32 stores, 1 no residual loads, 2 no conv3)
+// Hooks of the diagnostic builds tools/abl/gemm_x6_b2b_abl.hip (tools/build_ablations.sh b2babl / b2bpf / x6stg2), neutral here - the product
+// compiles these defaults: X6_B2B_ABL (timing-only ablations of the back-to-back tail: bit 0 no fp32 stores, 1 no residual loads, 2 no conv3),
+// X6_B2B_PREFETCH_B (same bits: conv3's B fragments requested per K chunk right before their MFMAs - 0, 2.07 ms per launch of layer1 -, a whole
+// pass ahead - 1: 16 spilled registers, 2.21 ms -, or half a pass ahead of this pass's stores - 2: 14 spilled, 2.17 ms), X6_H2_STAGES (same bits:
+// LDS stages of the f16x2 3x3 loop)
 #ifndef X6_B2B_PREFETCH_B
 #define X6_B2B_PREFETCH_B 0
 #endif

@@ -6,6 +6,8 @@
 #   tools/build_ablations.sh h2stamps       f16x2 kernel with per-phase cycle stamps (prints per launch, syncs)
 #   tools/build_ablations.sh h2l2hit        the same with every K step of a plain gemm_h3 re-reading the first four (WRONG results: the K loop with
 #                                           every DMA piece served by L2)
+#   tools/build_ablations.sh b2babl:<mask>  the back-to-back kernel of gemm_x6.hip without parts of its tail (1 no fp32 stores, 2 no residual loads, 4 no conv3 phase;
+#                                           WRONG results, timing only); b2bpf:<0|1|2> / x6stg2: same-bits variants (B-fragment prefetch mode; two LDS stages)
 #   tools/build_ablations.sh h3b2b          the f16x2 kernel with the conv3 launches of ResNet-50's layer3 / layer4 never fetching their A operand and the 3x3
 #                                           launches never storing their planes (WRONG results: the most a conv2 -> conv3 fusion there could return)
 #   tools/build_ablations.sh flowstamps     fused Farneback iteration with tick stamps per phase of a step (tools/flow_stamps.py prints them)
@@ -30,6 +32,9 @@ for n in "$@"; do
   case "$n" in
     x6stamps) $CC -I. -c ../../tools/abl/gemm_x6_stamps.hip -o /tmp/gemm_x6_stamps.o; link gemm_x6.o /tmp/gemm_x6_stamps.o x6stamps ;;
     h2stamps) $CC -I. -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_stamps.o; link gemm_h2.o /tmp/gemm_h2_stamps.o h2stamps ;;
+    b2babl:*) $CC -I. -DB2B_ABL_MASK=${n#b2babl:} -c ../../tools/abl/gemm_x6_b2b_abl.hip -o /tmp/gemm_x6_b2babl.o; link gemm_x6.o /tmp/gemm_x6_b2babl.o b2babl${n#b2babl:} ;;
+    b2bpf:*) $CC -I. -DB2B_PF_MODE=${n#b2bpf:} -c ../../tools/abl/gemm_x6_b2b_abl.hip -o /tmp/gemm_x6_b2bpf.o; link gemm_x6.o /tmp/gemm_x6_b2bpf.o b2bpf${n#b2bpf:} ;;
+    x6stg2) $CC -I. -DX6_STG2 -c ../../tools/abl/gemm_x6_b2b_abl.hip -o /tmp/gemm_x6_stg2.o; link gemm_x6.o /tmp/gemm_x6_stg2.o x6stg2 ;;
     h3b2b) $CC -I. -DH3_B2B_BOUND -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_b2b.o; link gemm_h2.o /tmp/gemm_h2_b2b.o h3b2b ;;
     h2l2hit) $CC -I. -DH3_L2HIT -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_l2hit.o; link gemm_h2.o /tmp/gemm_h2_l2hit.o h2l2hit ;;
     flowstamps) $FLOWCC -I. -c ../../tools/abl/flow_stamps.hip -o /tmp/flow_stamps.o; link flow.o /tmp/flow_stamps.o flowstamps ;;
