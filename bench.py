@@ -676,9 +676,10 @@ def flow_stage_record(prof, elapsed_s, traffic_per_clip=None):
                                "avg_launch_us": it_ms * 1e3 / max(it_n, 1), "time_share_of_step": it_ms * 1e-3 / elapsed_s}}
     return rec
 H2_EXECUTED = 3.0   # fp16 MFMA products per fp32 product in gemm_h3 at K >= 256 ("h2_form" 1): A[lo] B[hi], A[hi] B[lo], A[hi] B[hi]
-DTYPE_TEXT = {"f16x2": "f32 (fp32-grade split-operand arithmetic, fp32 accumulate: the whole ViT (GEMMs and attention), ResNet-50's stem, layer3 / layer4 and "
-                       "the 3x3 convolutions of layer1 / layer2 on fp32 operands as 2 fp16 planes x a power-of-two scale, 3 partial products on the fp16 MFMA "
-                       "[f16x2]; the 1x1 convolutions of ResNet-50's layer1 / layer2 (HBM-bound) on 3 bf16 planes, 6 partial products on the bf16 MFMA [bf16x6])",
+DTYPE_TEXT = {"f16x2": "f32 (fp32-grade split-operand arithmetic, fp32 accumulate: the whole ViT (GEMMs and attention), ResNet-50's stem, layer3 / layer4, "
+                       "the 3x3 convolutions of layer1 / layer2 and the conv3 of layer1's back-to-back blocks on fp32 operands as 2 fp16 planes x a power-of-two "
+                       "scale, 3 partial products (4 below K = 256) on the fp16 MFMA [f16x2]; the other 1x1 convolutions of ResNet-50's layer1 / layer2 (HBM-bound) "
+                       "on 3 bf16 planes, 6 partial products on the bf16 MFMA [bf16x6])",
               "fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into two bf16 terms, fp32 accumulate; reduced precision)",
               "bf16x6": "f32 (fp32 operands as 3 bf16 planes, 6 partial products on the bf16 MFMA, fp32 accumulate: fp32-grade)"}
 
