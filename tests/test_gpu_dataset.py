@@ -213,3 +213,19 @@ def test_bench_dataset_mode_two_ranks_on_one_gpu_equal_one_rank_bit_for_bit(tmp_
     assert a.shape == (7, 19779) and np.isfinite(a).all()
     assert np.array_equal(a, b), "sharding over two ranks changed the matrix"
     assert not np.array_equal(a[0], a[1]) and np.array_equal(a[0], a[3])      # 3 distinct clips, clip i = resident[i % 3]
+
+
+def test_loader_processes_feed_the_gpu_pass_and_give_the_thread_path_matrix(tmp_path):
+    """relax-vqa_amd/loaderpool.py on the GPU (as bench.py drives it: the pool is started before the process touches the device): clips
+    decoded by two worker processes into shared memory the rank page-locks, copied from there - the matrix equals the loader-thread
+    path's bit for bit, nothing is staged through a host copy, no segment stays in /dev/shm."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = [os.path.join(ROOT, "bench.py"), "--workload", "config4", "--dataset-clips", "24", "--clips-per-step", "8", "--warmup", "1",
+            "--resident-clips", "3", "--from-frame-files", str(tmp_path / "frames"), "--loader-workers-sweep", "4", "--loader-processes", "2"]
+    res = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    sweep = rec["from_frame_files"]["process_sweep"]
+    assert len(sweep) == 1 and sweep[0]["loader_processes_per_rank"] == 2
+    assert sweep[0]["matrix_equal_to_thread_path"] is True and sweep[0]["staged_bytes"] == 0 and sweep[0]["value"] > 0
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("relaxldr_")], "segments left behind"
