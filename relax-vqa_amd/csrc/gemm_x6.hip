@@ -201,7 +201,8 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
     static_assert(!DUAL || !TAPS, "a second activation source goes with 1x1 contractions");
     static_assert(!AF32 || (!M16 && !TAPS && !DUAL), "fp32 activation rows: the plain-GEMM form of the four-wave tiles only");
     static_assert(!H2 || (!M16 && !DUAL && !AF32), "fp16 planes: the four-wave tiles only (the 256 x 256 tile of f16x2 is gemm_h3)");
-    static_assert(!B2B || (H2 && TAPS && (TM == 1 || TM == 2) && TN == 2 && WN == 1), "back to back: the f16x2 3x3 form on 4 x 1 waves of 32 or 64 rows x 64 columns");
+    static_assert(!B2B || (H2 && TAPS && (TM == 1 || TM == 2) && TN == 2 && (WN == 1 || (WN == 2 && TM == 2))),
+                  "back to back: the f16x2 3x3 form on 4 x 1 waves of 32 or 64 rows x 64 columns, or on 4 x 2 waves of 64 x 64");
     static_assert(STAGE % 1024 == 0 && A_BYTES % 1024 == 0, "stage regions are whole DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -724,8 +725,12 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         // into two fp16 planes - all in registers -, and the tile is the A operand of the block's conv3 without leaving the CU.
         const int c32 = lane & 31, half = lane >> 5;
         constexpr int B2B_STG = NW * TM * 32 * 68 * 4 > 2 * STAGE ? NW * TM * 32 * 68 * 4 : 2 * STAGE;   // the waves' staging rows (TM * 32 x 68 floats each), over the two stages
-        float* rowinv = reinterpret_cast<float*>(smem + B2B_STG);              // [BM]: 1 / scale of every pixel row of the tile
-        unsigned* simg = reinterpret_cast<unsigned*>(smem + B2B_STG + 1024);   // two per-image maxima of the tile
+        // WN == 2 (128-wide blocks: layer2): a wave holds 64 of the 128 channels of its pixels.  conv3's K is split over the two waves of a
+        // pair (wm, 0), (wm, 1): each contracts ITS 64 channels - with its own scale per pixel row, from the maximum over its channels - over all
+        // N3 columns, both stage their partial tiles, and after a barrier each wave finishes 32 of the pair's 64 rows:
+        // (partial0 / scale0 + partial1 / scale1) * colscale + bias + residual, a fixed order.
+        float* rowinv = reinterpret_cast<float*>(smem + B2B_STG);              // [WN][BM]: 1 / scale of every pixel row of the tile (per K half)
+        unsigned* simg = reinterpret_cast<unsigned*>(smem + B2B_STG + WN * BM * 4);   // two per-image maxima of the tile
         if (tid < 2) simg[tid] = 0u;
         u32x4 ah[TM][2 * TN], al[TM][2 * TN];
 #pragma unroll
@@ -737,7 +742,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             for (int y = 0; y < TN; ++y)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int ch0 = n0 + y * 32 + 4 * half + 8 * g;
+                    const int ch0 = n0 + (wn * TN + y) * 32 + 4 * half + 8 * g;
                     const f32x4 cs = *reinterpret_cast<const f32x4*>(p.colscale + ch0);
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + ch0);
 #pragma unroll
@@ -749,7 +754,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float sc = h2_scale_for(mx);
-            if (half == 0) rowinv[(wm * TM + x) * 32 + c32] = 1.f / sc;       // (a power of two: exact)
+            if (half == 0) rowinv[wn * BM + (wm * TM + x) * 32 + c32] = 1.f / sc;       // (a power of two: exact)
 #pragma unroll
             for (int y = 0; y < TN; ++y)
 #pragma unroll
@@ -762,10 +767,15 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         // ---- conv3: [64 pixels of this wave] x [K = BN channels] x [N3 columns] in passes of 64 columns, B fragments straight from
         // global memory (64 KB shared by every workgroup of the launch: L2 / L1 hits); four products (K < 256), one accumulator, smallest first
         constexpr int LDC2 = 68;
-        float* stgw = reinterpret_cast<float*>(smem) + wave * (TM * 32 * LDC2);    // this wave's own 64 staging rows: no workgroup barrier in the passes
+        float* stgw = reinterpret_cast<float*>(smem) + wave * (TM * 32 * LDC2);    // this wave's own 64 staging rows (WN == 1: no workgroup barrier in the passes)
+        [[maybe_unused]] const float* stg0 = reinterpret_cast<const float*>(smem) + (wm * WN) * (TM * 32 * LDC2);       // WN == 2: the pair's two partial tiles
+        [[maybe_unused]] const float* stg1 = reinterpret_cast<const float*>(smem) + (wm * WN + 1) * (TM * 32 * LDC2);
+        float* stgf = WN == 1 ? stgw : const_cast<float*>(stg0);                   // where finished rows go back for the group sums
         const int lr = lane >> 3, lc = (lane & 7) * 8;
         const int img_first = m0 / (p.Ho * p.Wo);
-        const int r0 = wm * TM * 32;                                               // the wave's first row of the tile
+        const int r0 = wm * TM * 32;                                               // the pair's (wave's) first row of the tile
+        constexpr int RW = TM * 32 / WN;                                           // rows this wave finishes: 64, or 32 of the pair's 64
+        const int rw0 = wn * RW;                                                   // ... starting at this row of the 64
         float tmax0 = 0.f, tmax1 = 0.f;
         const int64_t w3row = (int64_t)BN * 4;
         // The memory operations of a wave complete in issue order (vmcnt), so the order below is the pipeline: the B fragments of pass p + 1
@@ -774,7 +784,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         // through buffer resources: ONE offset register per lane for the whole tile (row lr, columns lc .. lc + 7 of the wave's rows), the
         // pass / row-group part in a scalar; rows beyond M (beyond out_rows) read zeros (are not stored) by the resource's byte count.
         const int npass = p.N3 / 64;
-        const int64_t wave_row0 = (int64_t)(m0 + r0) * p.N3 * 4;                 // byte offset of the wave's first row in an [M][N3] fp32 matrix
+        const int64_t wave_row0 = (int64_t)(m0 + r0 + rw0) * p.N3 * 4;           // byte offset of the wave's first row in an [M][N3] fp32 matrix
         auto bytes_left = [&](int rows) {
             const int64_t left = (int64_t)rows * p.N3 * 4 - wave_row0;
             return (int)(left < 0 ? 0 : (left < kMaxRecords ? left : kMaxRecords));
@@ -791,7 +801,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         u32x4 ra[4], rb[4];
 #define X6_B2B_LOAD_BQ(pass_, q_, slot_)                                                                                \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                  \
-        const int so_ = ((pass_) * 64 + nt * 32) * (int)w3row + (q_) * 64;                                              \
+        const int so_ = ((pass_) * 64 + nt * 32) * (int)w3row + (wn * 2 * TN + (q_)) * 64;   /* (this wave's K half) */    \
         bh[slot_][nt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, voff_w3, so_, 0));       \
         bl[slot_][nt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, voff_w3 + 32, so_, 0));  \
     }
@@ -805,20 +815,29 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
     }
 #define X6_B2B_ROWS(it0_)                                                                                               \
     _Pragma("unroll") for (int it = (it0_); it < (it0_) + 4; ++it) {                                                    \
-        const int row = it * 8 + lr;                                                                                    \
+        const int row = rw0 + it * 8 + lr;                                                                              \
         const int m = m0 + r0 + row;                                                                                    \
-        f32x4 va = *reinterpret_cast<const f32x4*>(stgw + row * LDC2 + lc);                                             \
-        f32x4 vb = *reinterpret_cast<const f32x4*>(stgw + row * LDC2 + lc + 4);                                         \
-        const float ri = rowinv[r0 + row];                                                                              \
-        va = va * (cs_a * ri) + b3_a;         /* (powers of two: exact) */                                              \
-        vb = vb * (cs_b * ri) + b3_b;                                                                                   \
+        f32x4 va, vb;                                                                                                   \
+        if constexpr (WN == 1) {                                                                                        \
+            va = *reinterpret_cast<const f32x4*>(stgw + row * LDC2 + lc);                                               \
+            vb = *reinterpret_cast<const f32x4*>(stgw + row * LDC2 + lc + 4);                                           \
+            const float ri = rowinv[r0 + row];                                                                          \
+            va = va * (cs_a * ri) + b3_a;         /* (powers of two: exact) */                                          \
+            vb = vb * (cs_b * ri) + b3_b;                                                                               \
+        } else {                                                                                                        \
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg0 + row * LDC2 + lc), b0 = *reinterpret_cast<const f32x4*>(stg0 + row * LDC2 + lc + 4); \
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg1 + row * LDC2 + lc), b1 = *reinterpret_cast<const f32x4*>(stg1 + row * LDC2 + lc + 4); \
+            const float ri0 = rowinv[r0 + row], ri1 = rowinv[BM + r0 + row];                                            \
+            va = (a0 * (cs_a * ri0) + a1 * (cs_a * ri1)) + b3_a;   /* the two K halves in a fixed order */              \
+            vb = (b0 * (cs_b * ri0) + b1 * (cs_b * ri1)) + b3_b;                                                        \
+        }                                                                                                               \
         va += __builtin_bit_cast(f32x4, ra[it & 3]);   /* (acc + bias) + residual: the order of the two-launch path */  \
         vb += __builtin_bit_cast(f32x4, rb[it & 3]);                                                                    \
         va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};                           \
         vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};                           \
         if (p.gap) {                                                                                                    \
-            *reinterpret_cast<f32x4*>(stgw + row * LDC2 + lc) = va;                                                     \
-            *reinterpret_cast<f32x4*>(stgw + row * LDC2 + lc + 4) = vb;                                                 \
+            *reinterpret_cast<f32x4*>(stgf + row * LDC2 + lc) = va;                                                     \
+            *reinterpret_cast<f32x4*>(stgf + row * LDC2 + lc + 4) = vb;                                                 \
         }                                                                                                               \
         if (!(X6_B2B_ABL & 1)) {                                                                                        \
             const int so_ = (it * 8 * p.N3 + n0p) * 4;                                                                  \
@@ -872,26 +891,31 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             const f32x4 b3_a = *reinterpret_cast<const f32x4*>(p.bias3 + n0p + lc), b3_b = *reinterpret_cast<const f32x4*>(p.bias3 + n0p + lc + 4);
             if (X6_B2B_PREFETCH_B && pass + 1 < npass) { _Pragma("unroll") for (int q = 0; q < QPRE; ++q) X6_B2B_LOAD_BQ(pass + 1, q, q); }
             X6_B2B_LOAD_RES(pass, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local: this wave's stores have reached the LDS before its loads
-            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's stores have reached the LDS before its loads ...
+            if constexpr (WN == 1) __builtin_amdgcn_wave_barrier();
+            else __builtin_amdgcn_s_barrier();                   // ... and (WN == 2) the partner's partial tile is there too
             X6_B2B_ROWS(0);
-            if constexpr (TM == 2) {
+            if constexpr (RW == 64) {
                 X6_B2B_LOAD_RES(pass, 4);
                 X6_B2B_ROWS(4);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (p.gap) {   // sums over the four aligned 16-row groups of the wave's 64 rows, rows added in order (batch-invariant)
+            if (p.gap) {   // sums over the aligned 16-row groups of the rows this wave finished, rows added in order (batch-invariant)
 #pragma unroll
-                for (int g = 0; g < TM * 2; ++g) {
-                    const int mg = m0 + r0 + g * 16;
+                for (int g = 0; g < RW / 16; ++g) {
+                    const int mg = m0 + r0 + rw0 + g * 16;
                     float t = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) t += stgw[(g * 16 + r) * LDC2 + lane];
+                    for (int r = 0; r < 16; ++r) t += stgf[(rw0 + g * 16 + r) * LDC2 + lane];
                     if (mg < p.gap_rows) p.gap[(int64_t)(mg >> 4) * p.N3 + n0p + lane] = t;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
+            }
+            if constexpr (WN == 2) {                             // the partner has read this wave's partial tile: the next pass may overwrite it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
         }
 #undef X6_B2B_ROWS
@@ -1208,7 +1232,7 @@ static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     // (B2B: the waves' own staging rows of the conv3 passes, 64 x 68 floats each, + the row scales + two maxima: 70.7 KB, two workgroups per CU)
     constexpr size_t stages_lds = (((M16 && !TAPS && !DUAL) || (H2 && X6_H2_STAGES == 3)) ? 3 : 2) * (size_t)(BM * (AF32 ? 64 : CH) + BN * CH);
     constexpr size_t b2b_stg = (size_t)(WM * WN) * (BM / WM) * 68 * 4;     // the waves' own staging rows of the conv3 passes
-    constexpr size_t lds = B2B ? (b2b_stg > stages_lds ? b2b_stg : stages_lds) + 1024 + 64 : stages_lds + 1024;
+    constexpr size_t lds = B2B ? (b2b_stg > stages_lds ? b2b_stg : stages_lds) + (size_t)WN * BM * 4 + 64 : stages_lds + 1024;
     static bool attr_set[kMaxDevices] = {};
     if (!attr_set[h->device]) {
         RELAX_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6<BM, BN, WM, WN, TAPS, M16, DUAL, AF32, H2, B2B>),
@@ -1268,9 +1292,9 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     const bool taps = d.KH * d.KW > 1;
     const bool b2b = d.w3 != nullptr;
     p.w3 = static_cast<const char*>(d.w3); p.colscale3 = d.colscale3; p.bias3 = d.bias3; p.N3 = d.Cout3;
-    RELAX_REQUIRE(h, !b2b || (d.in_h2 && taps && d.Cout == 64 && d.Cout3 % 64 == 0 && d.Cout3 > 0 && d.colscale3 && d.bias3 && d.bias && d.act == 1 &&
+    RELAX_REQUIRE(h, !b2b || (d.in_h2 && taps && (d.Cout == 64 || d.Cout == 128) && d.Cout3 % 64 == 0 && d.Cout3 > 0 && d.colscale3 && d.bias3 && d.bias && d.act == 1 &&
                               d.residual && !d.residual_sp3 && !d.in2 && (d.Ho * d.Wo) % 16 == 0 && d.Ho * d.Wo >= 256),
-                  "x6 conv: the back-to-back form needs the f16x2 3x3 onto 64 columns, ReLU, both biases, an fp32 residual and images of >= 256 pixels (a multiple of 16)");
+                  "x6 conv: the back-to-back form needs the f16x2 3x3 onto 64 or 128 columns, ReLU, both biases, an fp32 residual and images of >= 256 pixels (a multiple of 16)");
     RELAX_REQUIRE(h, p.M > 0 && p.N > 0 && p.K > 0, "x6 conv/gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     RELAX_REQUIRE(h, d.Cin % 16 == 0, "x6 conv/gemm: Cin=%d must be a multiple of 16", d.Cin);
     RELAX_REQUIRE(h, p.N % 64 == 0, "x6 conv/gemm: N=%d must be a multiple of 64", p.N);
@@ -1305,7 +1329,9 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     int rc;
     // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA); N = 128 / 64 layers: the same
     // loop on four waves, two workgroups per CU
-    if (b2b)        // the 3x3 and the block's conv3 back to back (the 3x3's tile stays in registers)
+    if (b2b && d.Cout == 128)   // ... of a 128-wide block: eight waves, conv3's K split over the two column waves
+        rc = launch_x6_variant<256, 128, 4, 2, true, false, false, false, true, true>(h, p, s);
+    else if (b2b)   // the 3x3 and the block's conv3 back to back (the 3x3's tile stays in registers)
         rc = h->gemm.b2b_rows == 256 ? launch_x6_variant<256, 64, 4, 1, true, false, false, false, true, true>(h, p, s)
                                      : launch_x6_variant<128, 64, 4, 1, true, false, false, false, true, true>(h, p, s);
     else if (d.in_h2)    // two fp16 planes on both sides: the 3x3 convolutions of layer1 / layer2 under f16x2

@@ -306,7 +306,7 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
     // back-to-back form ("rn_fuse": gemm_x6.hip, B2B - the 3x3's transposed accumulator tile is the A operand)
     for (size_t b = 0; b < kFirstH2Block && b < rn.blocks.size(); ++b) {
         Bottleneck& blk = rn.blocks[b];
-        if (blk.has_down || blk.c3.Cin != 64) continue;        // (the four-wave form: 64-wide blocks)
+        if (blk.has_down || (blk.c3.Cin != 64 && blk.c3.Cin != 128)) continue;        // (64-wide blocks: the four-wave form; 128-wide: eight waves)
         const int K = blk.c3.Cin, Co = blk.c3.Cout;
         float* perm = nullptr;
         void* q = nullptr;
@@ -549,7 +549,10 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             // maximum, and block 6's output as fp32 + fp16 planes with its Hoelder scale + its maximum
             const bool handover = use_h2 && b + 1 == kFirstH2Block;
             const bool pre_handover = use_h2 && b + 2 == kFirstH2Block;
-            int slot_c2 = -1, slot_y = -1, slot_t1 = -1, slot_o = -1;
+            int slot_c2 = -1, slot_y = -1, slot_t1 = -1, slot_o = -1, slot_t1m = -1;
+            // "rn_fuse": conv2 and conv3 back to back in one launch (the 3x3's tile never leaves the CU; conv3 on f16x2 with one scale per pixel row)
+            const bool fuse = use_early && h->gemm.rn_fuse && !blk.has_down && blk.c3.w_h2p && cur_is_f32 && blk.c2.stride == 1 && H * H >= 256;
+            if (handover && fuse) slot_t1m = next_slot++;   // the MEASURED maximum of conv1's output: what the hand-over scale is bounded from (below)
             if (handover) { slot_c2 = next_slot++; slot_y = next_slot++; }
             if (use_early) slot_t1 = next_slot++;
             // the maximum of this block's output: the next block's conv1 scale (early), the residual term of the hand-over block
@@ -566,13 +569,12 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                     RELAX_TRY(launch_h2_image_scales(h, slot_amax(slot_xin), blk.c1.l1max, nullptr, 0.f, nullptr, blk.c1.bmax, slot_scale(slot_t1),
                                                      slot_inv(slot_t1), N, s));
                     d.out_h2 = T1s; d.img_out_scale = slot_scale(slot_t1);
+                    if (slot_t1m >= 0) d.amax_out = slot_amax(slot_t1m);
                 } else {
                     d.out_sp3 = T1s;
                 }
                 RELAX_TRY(launch_conv_x6(h, d, s));
             }
-            // "rn_fuse": conv2 and conv3 back to back in one launch (the 3x3's tile never leaves the CU; conv3 on f16x2 with one scale per pixel row)
-            const bool fuse = use_early && h->gemm.rn_fuse && !blk.has_down && !handover && blk.c3.w_h2p && cur_is_f32 && blk.c2.stride == 1 && H * H >= 256;
             if (handover || use_early) {
                 ConvDescX6 d2{};
                 d2.in = T1s; d2.Nimg = N; d2.H = H; d2.W = H; d2.Cin = blk.c2.Cin;
@@ -580,7 +582,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 d2.KH = blk.c2.KH; d2.KW = blk.c2.KW; d2.stride = blk.c2.stride; d2.pad = blk.c2.pad;
                 d2.w = blk.c2.w_sp3; d2.Cout = blk.c2.Cout; d2.bias = blk.c2.bias; d2.out_sp3 = T2s; d2.act = 1;
                 if (use_early) { d2.in_h2 = 1; d2.w = blk.c2.w_h2; d2.colscale = blk.c2.w_inv; d2.img_in_inv = slot_inv(slot_t1); }
-                if (handover) d2.amax_out = slot_amax(slot_c2);
+                if (handover && !fuse) d2.amax_out = slot_amax(slot_c2);
                 if (fuse) {
                     d2.out_sp3 = nullptr;
                     d2.w3 = blk.c3.w_h2p; d2.colscale3 = blk.c3.w_invp; d2.bias3 = blk.c3.bias; d2.Cout3 = Cout;
@@ -589,6 +591,16 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                     d2.out_sp3 = out_is_f32 ? nullptr : othersp;
                     d2.gap_groups = fuse_mean ? gapws : nullptr; d2.gap_rows = n_ls * HWo;
                     d2.amax_out = slot_o >= 0 ? slot_amax(slot_o) : nullptr;
+                    if (handover) {
+                        // the block's output leaves as fp16 planes with a per-image scale from a bound.  Two launches: Hoelder on conv3 with the
+                        // MEASURED maximum of conv2's output; back to back that tensor never exists, so it is bounded in turn from the measured
+                        // maximum of conv1's output:  |y| <= l1(c3) (l1(c2) max|t1| + b2) + b3 + max|x|  - one more L1-to-max ratio of looseness
+                        // (2^5 - 2^7 of fp16's 19 binades), still never compounding beyond this block
+                        RELAX_TRY(launch_h2_image_scales(h, slot_amax(slot_t1m), blk.c3.l1max * blk.c2.l1max, nullptr, 0.f, slot_amax(slot_prev_out),
+                                                         blk.c3.l1max * blk.c2.bmax + blk.c3.bmax, slot_scale(slot_y), slot_inv(slot_y), N, s));
+                        d2.out_sp3 = nullptr;
+                        d2.out_h2 = othersp; d2.img_out_scale = slot_scale(slot_y); d2.amax_out = slot_amax(slot_y);
+                    }
                 }
                 RELAX_TRY(launch_conv_x6(h, d2, s));
             } else {
