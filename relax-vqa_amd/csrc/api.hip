@@ -268,6 +268,7 @@ int relax_set_option(relax_handle* h, const char* key, int value) {
     else if (k == "rn_h2") h->gemm.rn_h2 = value != 0;
     else if (k == "rn_h2_early") h->gemm.rn_h2_early = value != 0;
     else if (k == "rn_fuse") h->gemm.rn_fuse = value != 0;
+    else if (k == "rn_c1_h2") h->gemm.rn_c1_h2 = value != 0;
     else if (k == "b2b_rows") {
         RELAX_REQUIRE(h, value == 128 || value == 256, "relax_set_option: b2b_rows must be 128 or 256");
         h->gemm.b2b_rows = value;
@@ -315,6 +316,7 @@ int relax_get_option(relax_handle* h, const char* key, int* value) {
     else if (k == "rn_h2") *value = h->gemm.rn_h2;
     else if (k == "rn_h2_early") *value = h->gemm.rn_h2_early;
     else if (k == "rn_fuse") *value = h->gemm.rn_fuse;
+    else if (k == "rn_c1_h2") *value = h->gemm.rn_c1_h2;
     else if (k == "b2b_rows") *value = h->gemm.b2b_rows;
     else if (k == "att_h2") *value = h->gemm.att_h2;
     else if (k == "h2_stages") *value = h->gemm.h2_stages;

@@ -126,6 +126,7 @@ struct X6Params {
     const float* img_out_scale;
     const float* colscale;   // H2: [N] inverse weight-row scales
     const float* img_in_inv; // H2: [images] inverse activation scales (image = row / (Ho*Wo))
+    const float* img_in_scale;   // H2 + AF32: [images] the scales themselves (the fp32 rows are split into planes inside the K loop)
     unsigned* amax_out;      // [images]: atomicMax of the bits of the (non-negative) outputs of each image, or null (image = row / (Ho*Wo))
     float* partial;          // split-K partial tiles
     int M, N, K;
@@ -200,7 +201,8 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
     static_assert(!M16 || (TM == 4 && TN == 2 && PPW <= 7), "the 16x16x32 loop is written for 128 x 64 per wave");
     static_assert(!DUAL || !TAPS, "a second activation source goes with 1x1 contractions");
     static_assert(!AF32 || (!M16 && !TAPS && !DUAL), "fp32 activation rows: the plain-GEMM form of the four-wave tiles only");
-    static_assert(!H2 || (!M16 && !DUAL && !AF32), "fp16 planes: the four-wave tiles only (the 256 x 256 tile of f16x2 is gemm_h3)");
+    static_assert(!H2 || (!M16 && !DUAL), "fp16 planes: the four-wave tiles only (the 256 x 256 tile of f16x2 is gemm_h3)");
+    static_assert(!(H2 && AF32) || !B2B, "fp32 rows split into fp16 planes in the loop: the 1x1 form");
     static_assert(!B2B || (H2 && TAPS && (TM == 1 || TM == 2) && TN == 2 && (WN == 1 || (WN == 2 && TM == 2))),
                   "back to back: the f16x2 3x3 form on 4 x 1 waves of 32 or 64 rows x 64 columns, or on 4 x 2 waves of 64 x 64");
     static_assert(STAGE % 1024 == 0 && A_BYTES % 1024 == 0, "stage regions are whole DMA pieces");
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
     for (int j = 0; j < PPW; ++j) {
         const int piece = wave + NW * j;
         int trow, unit_off;
-        if (H2) {
+        if (H2 && !(AF32 && j < A_PPW)) {
             // fp16 planes: 4 units per row as well, every row of the stage (activation rows, then weight rows); slot s of row r holds
             // the unit v = s ^ ((r >> 2) & 3) = (half v >> 1, plane v & 1) of the chunk, i.e. source bytes plane * 32 + half * 16: a lane's hi
             // and lo fragments sit where AF32 keeps the two fp32 units of its half (the same conflict-free reads)
@@ -428,6 +430,15 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
     // AF32: lane (r, h) reads the fp32 values k = 8h .. 8h+7 of row r as two 16-byte units and splits them into the three planes
     [[maybe_unused]] const int a32_0 = (wm * TM * 32 + r32) * 64 + ((((lane >> 5) * 2) ^ ((r32 >> 2) & 3)) << 4);
     [[maybe_unused]] const int a32_1 = (wm * TM * 32 + r32) * 64 + ((((lane >> 5) * 2 + 1) ^ ((r32 >> 2) & 3)) << 4);
+    // H2 + AF32: the scale of the image each of this lane's activation rows belongs to (row (wm*TM + i)*32 + r32 of the tile)
+    [[maybe_unused]] float asc[TM];
+    if constexpr (H2 && AF32) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 32 + r32;
+            asc[i] = p.img_in_scale[(m < p.M ? m : p.M - 1) / (p.Ho * p.Wo)];
+        }
+    }
     const int x_off = SPLIT_B ? a_off : b_off;
     const int y_off = SPLIT_B ? b_off : a_off;
 
@@ -439,11 +450,18 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
     {                                                                                                                   \
         const f32x4 v0_ = *reinterpret_cast<const f32x4*>((sp_) + a32_0 + (idx_) * 32 * 64);                            \
         const f32x4 v1_ = *reinterpret_cast<const f32x4*>((sp_) + a32_1 + (idx_) * 32 * 64);                            \
-        u32x4 h_, m_, l_;                                                                                               \
-        split3_x8(v0_, v1_, h_, m_, l_);                                                                                \
-        dst_[0] = __builtin_bit_cast(bf16x8, h_);                                                                       \
-        dst_[1] = __builtin_bit_cast(bf16x8, m_);                                                                       \
-        dst_[2] = __builtin_bit_cast(bf16x8, l_);                                                                       \
+        if constexpr (H2) {   /* two fp16 planes of x * (the image's scale): 22 bits, csrc/h2.h */                      \
+            u32x4 h_, l_;                                                                                               \
+            split2_x8(v0_ * asc[(idx_) < TM ? (idx_) : 0], v1_ * asc[(idx_) < TM ? (idx_) : 0], h_, l_);                \
+            dst_[0] = __builtin_bit_cast(bf16x8, h_);                                                                   \
+            dst_[1] = __builtin_bit_cast(bf16x8, l_);                                                                   \
+        } else {                                                                                                        \
+            u32x4 h_, m_, l_;                                                                                           \
+            split3_x8(v0_, v1_, h_, m_, l_);                                                                            \
+            dst_[0] = __builtin_bit_cast(bf16x8, h_);                                                                   \
+            dst_[1] = __builtin_bit_cast(bf16x8, m_);                                                                   \
+            dst_[NP - 1] = __builtin_bit_cast(bf16x8, l_);                                                              \
+        }                                                                                                               \
     }
 #define X6_READ_X(set_, sp_)                                                                                            \
     _Pragma("unroll") for (int x = 0; x < XT; ++x) {                                                                    \
@@ -1275,7 +1293,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     p.bias = d.bias; p.residual = d.residual; p.out = d.out; p.out_sp3 = static_cast<char*>(d.out_sp3);
     p.residual_sp3 = static_cast<const char*>(d.residual_sp3);
     p.out_h2 = static_cast<char*>(d.out_h2); p.img_out_scale = d.img_out_scale; p.amax_out = d.amax_out;
-    p.colscale = d.colscale; p.img_in_inv = d.img_in_inv;
+    p.colscale = d.colscale; p.img_in_inv = d.img_in_inv; p.img_in_scale = d.img_in_scale;
     p.gap = d.gap_groups;
     p.M = d.Nimg * d.Ho * d.Wo;
     p.N = d.Cout;
@@ -1311,6 +1329,9 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, !d.in2 || (!taps && d.stride == 1 && d.Cin2 % 16 == 0 && d.stride2 >= 1 && p.N % 256 == 0 &&
                                 (d.H2 - 1) / d.stride2 + 1 == d.Ho && (d.W2 - 1) / d.stride2 + 1 == d.Wo),
                   "x6 conv: a second activation source needs a 1x1 stride-1 first source, Cout %% 256 == 0 and a matching output grid");
+    const bool f32_h2 = d.in_f32 && d.img_in_scale != nullptr;   // fp32 rows split into fp16 planes in the K loop, weights as fp16 planes: three products
+    RELAX_REQUIRE(h, !f32_h2 || (d.colscale && d.img_in_inv && p.K >= 256 && !d.in_h2 && p.N % 128 == 0), "x6 conv: fp32 rows on f16x2 need the weights' inverse "
+                  "row scales, both per-image scale tables, K >= 256 (three products) and N %% 128 == 0");
     RELAX_REQUIRE(h, !d.in_f32 || (!taps && !d.in2 && d.stride == 1 && p.N % 256 != 0),
                   "x6 conv/gemm: fp32 activation rows go with a 1x1 stride-1 contraction of 64 or 128 (not a multiple of 256) output columns");
     // every operand is read / written in 16-byte units (LDS-DMA pieces, f32x4 bias / residual / output accesses, plane units)
@@ -1322,10 +1343,10 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     // algorithmic HBM bytes: activation in (6 B per value), weights, outputs (+ residual), each touched once
     const double n_out = b2b ? d.Cout3 : p.N;    // (back to back: the outputs and the residual are the conv3's)
     const double bytes = ((d.in_f32 || d.in_h2) ? 4.0 : 6.0) * ((double)d.Nimg * d.H * d.W * d.Cin) +
-                         (d.in_h2 ? 4.0 : 6.0) * ((double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) + (b2b ? 4.0 * p.N * d.Cout3 : 0.0) +
+                         ((d.in_h2 || f32_h2) ? 4.0 : 6.0) * ((double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) + (b2b ? 4.0 * p.N * d.Cout3 : 0.0) +
                          (double)p.M * n_out * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.out_h2 ? 4.0 : 0.0) + (d.residual ? 4.0 : 0.0) + (d.residual_sp3 ? 6.0 : 0.0));
     int span;
-    RELAX_TRY(prof_begin(h, s, d.in_h2 ? 5 : 2, flops, &span, bytes));   // (kind 5 = f16x2: three executed products per fp32 product)
+    RELAX_TRY(prof_begin(h, s, (d.in_h2 || f32_h2) ? 5 : 2, flops, &span, bytes));   // (kind 5 = f16x2: three executed products per fp32 product)
     int rc;
     // N % 256 == 0: one 8-wave workgroup per CU on a 256x256 tile (fewest staged bytes per MFMA); N = 128 / 64 layers: the same
     // loop on four waves, two workgroups per CU
@@ -1338,6 +1359,10 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
         // (N = 128 on EIGHT waves of 64 x 64: the second accumulator does not fit the 128 x 64 wave tile of the four-wave form)
         rc = p.N % 128 == 0 ? launch_x6_variant<256, 128, 4, 2, true, false, false, false, true>(h, p, s)
                             : launch_x6_variant<256, 64, 4, 1, true, false, false, false, true>(h, p, s);
+    else if (f32_h2)     // fp32 activation rows split into two fp16 planes in the K loop (the image's scale from its measured maximum), weights as planes
+        // (N = 128 on EIGHT waves of 64 x 64, as the 3x3 form: the second accumulator does not fit a 128 x 64 wave tile; the 64-column
+        // launches - layer1's conv1 - wait on memory either way and stay on bf16x6: their f16x2 instantiation spills)
+        rc = launch_x6_variant<256, 128, 4, 2, false, false, false, true, true>(h, p, s);
     else if (d.in_f32)   // fp32 activation rows, split in the K loop (ResNet-50: the block outputs of layer1 / layer2 travel as fp32)
         rc = p.N % 128 == 0 ? launch_x6_variant<256, 128, 2, 2, false, false, false, true>(h, p, s)
                             : launch_x6_variant<256, 64, 4, 1, false, false, false, true>(h, p, s);

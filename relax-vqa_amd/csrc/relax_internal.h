@@ -83,6 +83,9 @@ struct ConvDescX6 {
     int in_h2;
     const float* colscale;
     const float* img_in_inv;
+    // ... and with in_f32 (1x1, Cout = 64 / 128, K >= 256): `in` stays fp32 rows, `w` is fp16 planes; the rows are split into planes inside the K loop
+    // with image i's scale img_in_scale[i] (from its MEASURED maximum: launch_h2_image_scales with la = 1), img_in_inv = 1 / that
+    const float* img_in_scale;
     int out_rows, gap_rows; // rows below these limits get the fp32 output / the group sums (0 = all rows)
     bool no_split;          // never cut tail tiles along K (a launch whose bits must not depend on which outputs are requested)
     const float* bias;      // [Cout] or null
@@ -269,6 +272,8 @@ struct GemmOptions {
                            // three products, no conversion passes); 0 = attention_x6 on the fp32 qkv output (three bf16 planes, six products)
     int rn_h2_early = 1;   // "rn_h2_early": with "rn_h2", the stem and the 3x3 convolutions of layer1 / layer2 (the MFMA-bound launches in front of layer3) run f16x2 too,
                            // on the four-wave tiles of gemm_x6.hip (conv1 writes its output as fp16 planes with the image's Hoelder scale); 0 = bf16x6 there
+    int rn_c1_h2 = 1;      // "rn_c1_h2": with "rn_h2_early", the conv1 (1x1) of the layer1 / layer2 blocks whose input travels as fp32 rows runs f16x2 too: the rows
+                           // are split into two fp16 planes in the K loop with the image's scale (from its measured maximum); 0 = bf16x6 (three planes, six products)
     int rn_fuse = 1;       // "rn_fuse": with "rn_h2_early", the blocks of layer1 / layer2 without a downsample branch run conv2 and conv3 back to back in ONE
                            // launch (the 3x3's output tile stays in registers as the A operand of the 1x1: no write and re-read of it, conv3 on f16x2
                            // with one scale per pixel row); 0 = two launches, conv3 on bf16x6 (the A/B switch of a test)

@@ -283,7 +283,8 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
         Bottleneck& blk = rn.blocks[b];
         const bool early = b < kFirstH2Block;
         for (ConvW* c : {&blk.c1, &blk.c2, &blk.c3, &blk.down}) {
-            if (!c->w || (early && (c != &blk.c2 || c->Cin % 16 != 0 || c->Cout % 64 != 0 || c->Cout % 256 == 0))) continue;
+            // (early blocks: the 3x3 - and conv1, whose fp32 input rows are split in the K loop under "rn_c1_h2")
+            if (!c->w || (early && ((c != &blk.c2 && c != &blk.c1) || c->Cin % 16 != 0 || c->Cout % 64 != 0 || c->Cout % 256 == 0))) continue;
             const int K = c->KH * c->KW * c->Cin;
             void* q = nullptr;
             float* inv = nullptr;
@@ -565,6 +566,12 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 d.Nimg = N; d.H = H; d.W = H; d.Cin = blk.c1.Cin; d.Ho = H; d.Wo = H;
                 d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0;
                 d.w = blk.c1.w_sp3; d.Cout = blk.c1.Cout; d.bias = blk.c1.bias; d.act = 1;
+                if (use_early && cur_is_f32 && h->gemm.rn_c1_h2 && blk.c1.w_h2 && blk.c1.Cin >= 256 && blk.c1.Cout % 128 == 0) {   // (layer2: MFMA-bound on six products)
+                    // f16x2: the rows are split into fp16 planes in the K loop, with the image's scale from the MEASURED maximum of the block input
+                    const int sx = next_slot++;
+                    RELAX_TRY(launch_h2_image_scales(h, slot_amax(slot_xin), 1.f, nullptr, 0.f, nullptr, 0.f, slot_scale(sx), slot_inv(sx), N, s));
+                    d.w = blk.c1.w_h2; d.colscale = blk.c1.w_inv; d.img_in_scale = slot_scale(sx); d.img_in_inv = slot_inv(sx);
+                }
                 if (use_early) {   // fp16 planes for the f16x2 conv2, scaled by the image's bound
                     RELAX_TRY(launch_h2_image_scales(h, slot_amax(slot_xin), blk.c1.l1max, nullptr, 0.f, nullptr, blk.c1.bmax, slot_scale(slot_t1),
                                                      slot_inv(slot_t1), N, s));

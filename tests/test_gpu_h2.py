@@ -353,6 +353,9 @@ def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
         eng.set_option("rn_fuse", 0)          # conv2 and conv3 of the layer1 / layer2 blocks as two launches (conv3 on bf16x6)
         _, _, taps2nofuse = eng.resnet50_features(f, taps=range(15))
         eng.set_option("rn_fuse", 1)
+        eng.set_option("rn_c1_h2", 0)         # layer2's conv1 on bf16x6 (fp32 rows split into three bf16 planes) instead of two fp16 planes
+        _, _, taps2c1x6 = eng.resnet50_features(f, taps=range(15))
+        eng.set_option("rn_c1_h2", 1)
         eng.set_option("rn_h2_early", 0)      # layer3 / layer4 only
         _, _, taps2late = eng.resnet50_features(f, taps=range(15))
         eng.set_option("rn_h2", 0)
@@ -361,6 +364,7 @@ def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
         eng.set_option("rn_h2", 1)
         eng.set_option("rn_h2_early", 1)
         eng.set_option("rn_fuse", 1)
+        eng.set_option("rn_c1_h2", 1)
     tsd = resnet50_ref.to_torch_state_dict(sd)
     ref_taps, _ = resnet50_ref.forward_taps(tsd, resnet50_ref.preprocess_bgr_u8(frags))
     sd64 = {k: v.double() for k, v in tsd.items()}
@@ -379,6 +383,8 @@ def test_resnet50_every_tap_under_f16x2_and_error_against_fp64(adv):
               f"bf16x6 everywhere {n6:.3e}  torch CPU fp32 {ncpu:.3e}")
         assert n2 <= 1.25 * n6 + 1e-9 and n2 <= ncpu, name
         assert n2u <= 1.25 * n6 + 1e-9 and n2u <= ncpu, name
+        n2c = rel(taps2c1x6[i].cpu().numpy(), r)      # (layer2's conv1 back on bf16x6: the same gates)
+        assert n2c <= 1.25 * n6 + 1e-9 and n2c <= ncpu, f"{name}: {n2c:.3e}"
         assert n2l <= 1.25 * n6 + 1e-9 and n2l <= ncpu, name
         if adv == "outliers" and i > 0:     # the same gate without the hot channel (it carries most of a norm over all channels)
             cm = np.abs(r).max(axis=(0, 2, 3))
