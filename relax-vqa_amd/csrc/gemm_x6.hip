@@ -145,6 +145,7 @@ struct X6Params {
     const float* colscale3;
     const float* bias3;
     int N3;
+    int sp3_sub;   // B2B: 2 = out_sp3 holds only the pixels with even (oy, ox), compacted to [Nimg][Ho/2][Wo/2] rows (what a stride-2 consumer samples); 1 = all
 };
 
 __device__ inline int xcd_remap6(int b, int nwg) {
@@ -863,7 +864,17 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb), rs_out, voff_row + 16, so_, 0);       \
         }                                                                                                               \
         if (m >= p.M) continue;                                                                                         \
-        if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N3 * 6), n0p + lc, va, vb);                    \
+        if (p.out_sp3) {                                                                                                \
+            int64_t ms_ = m;                                                                                            \
+            bool keep_ = true;                                                                                          \
+            if (p.sp3_sub == 2) {   /* the stride-2 sample of the map, compacted */                                     \
+                const int img_ = m / (p.Ho * p.Wo), rem_ = m - img_ * (p.Ho * p.Wo);                                    \
+                const int oy_ = rem_ / p.Wo, ox_ = rem_ - oy_ * p.Wo;                                                   \
+                keep_ = ((oy_ | ox_) & 1) == 0;                                                                         \
+                ms_ = ((int64_t)img_ * (p.Ho >> 1) + (oy_ >> 1)) * (p.Wo >> 1) + (ox_ >> 1);                            \
+            }                                                                                                           \
+            if (keep_) store_sp3_x8(p.out_sp3 + ms_ * ((int64_t)p.N3 * 6), n0p + lc, va, vb);                           \
+        }                                                                                                               \
         if (p.out_h2 || p.amax_out) {                                                                                   \
             const int img = m / (p.Ho * p.Wo);                                                                          \
             if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N3 * 4), n0p + lc, va, vb, p.img_out_scale[img]); \
@@ -1309,7 +1320,8 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     p.act = d.act;
     const bool taps = d.KH * d.KW > 1;
     const bool b2b = d.w3 != nullptr;
-    p.w3 = static_cast<const char*>(d.w3); p.colscale3 = d.colscale3; p.bias3 = d.bias3; p.N3 = d.Cout3;
+    p.w3 = static_cast<const char*>(d.w3); p.colscale3 = d.colscale3; p.bias3 = d.bias3; p.N3 = d.Cout3; p.sp3_sub = d.sp3_sub == 2 ? 2 : 1;
+    RELAX_REQUIRE(h, d.sp3_sub != 2 || (b2b && d.out_sp3 && d.Ho % 2 == 0 && d.Wo % 2 == 0), "x6 conv: the stride-2 plane output goes with the back-to-back form and even maps");
     RELAX_REQUIRE(h, !b2b || (d.in_h2 && taps && (d.Cout == 64 || d.Cout == 128) && d.Cout3 % 64 == 0 && d.Cout3 > 0 && d.colscale3 && d.bias3 && d.bias && d.act == 1 &&
                               d.residual && !d.residual_sp3 && !d.in2 && (d.Ho * d.Wo) % 16 == 0 && d.Ho * d.Wo >= 256),
                   "x6 conv: the back-to-back form needs the f16x2 3x3 onto 64 or 128 columns, ReLU, both biases, an fp32 residual and images of >= 256 pixels (a multiple of 16)");
@@ -1344,7 +1356,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     const double n_out = b2b ? d.Cout3 : p.N;    // (back to back: the outputs and the residual are the conv3's)
     const double bytes = ((d.in_f32 || d.in_h2) ? 4.0 : 6.0) * ((double)d.Nimg * d.H * d.W * d.Cin) +
                          ((d.in_h2 || f32_h2) ? 4.0 : 6.0) * ((double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) + (b2b ? 4.0 * p.N * d.Cout3 : 0.0) +
-                         (double)p.M * n_out * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? 6.0 : 0.0) + (d.out_h2 ? 4.0 : 0.0) + (d.residual ? 4.0 : 0.0) + (d.residual_sp3 ? 6.0 : 0.0));
+                         (double)p.M * n_out * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? (d.sp3_sub == 2 ? 1.5 : 6.0) : 0.0) + (d.out_h2 ? 4.0 : 0.0) + (d.residual ? 4.0 : 0.0) + (d.residual_sp3 ? 6.0 : 0.0));
     int span;
     RELAX_TRY(prof_begin(h, s, (d.in_h2 || f32_h2) ? 5 : 2, flops, &span, bytes));   // (kind 5 = f16x2: three executed products per fp32 product)
     int rc;

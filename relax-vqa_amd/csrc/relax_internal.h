@@ -110,6 +110,8 @@ struct ConvDescX6 {
     const float* colscale3;
     const float* bias3;
     int Cout3;
+    int sp3_sub;            // back-to-back form: 2 = out_sp3 receives only the pixels with even (oy, ox), as compact [Nimg][Ho/2][Wo/2] rows - the sample the
+                            // next block's stride-2 downsample branch reads (the full map travels as fp32 rows); 0 / 1 = every pixel
 };
 
 // h2 ("two fp16 planes", csrc/h2.h) operands of the f16x2 kernel (gemm_h2.hip): plain GEMM, N % 256 == 0

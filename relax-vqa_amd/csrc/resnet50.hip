@@ -466,6 +466,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
         char* othersp = spb;
         float* out32 = f32a;
         bool cur_is_f32 = false;   // the current block input exists as fp32 rows only
+        const char* compact_in = nullptr;   // ... plus the planes of its stride-2 sample, compacted (what the previous block left for a downsample branch)
         int H = 56;
         for (size_t b = 0; b < rn.blocks.size(); ++b) {
             const Bottleneck& blk = rn.blocks[b];
@@ -477,7 +478,14 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             const bool is_last = b + 1 == rn.blocks.size();
             const bool fuse_mean = want_mean && HWo % 4 == 0;
             const bool pool_needs32 = is_last && pool && !pool_from_stack;
-            const bool out_is_f32 = h->gemm.fp32_rows && Cout <= 512 && !is_last && !rn.blocks[b + 1].has_down;
+            // "rn_fuse" (below): conv2 and conv3 back to back in one launch
+            const bool fuse = use_early && b < kFirstH2Block && h->gemm.rn_fuse && !blk.has_down && blk.c3.w_h2p && cur_is_f32 && blk.c2.stride == 1 && H * H >= 256;
+            // a layer's last block in front of a downsample block: its output travelled as three bf16 planes (6 B per value: the next block's conv1 and
+            // the second source of its conv3 read planes).  Back to back it leaves as fp32 rows like the others (conv1 splits in its K loop) PLUS the
+            // planes of the stride-2 sample only - all the downsample branch reads -, compacted: 4 + 1.5 bytes per value instead of 6, and conv1 reads 4
+            const bool next_down = !is_last && rn.blocks[b + 1].has_down;
+            const bool compact = fuse && next_down && b + 1 < kFirstH2Block && h->gemm.fp32_rows && Cout <= 512 && Ho % 2 == 0 && rn.blocks[b + 1].c2.stride == 2;
+            const bool out_is_f32 = h->gemm.fp32_rows && Cout <= 512 && !is_last && (!next_down || compact);
             const bool need32 = out_is_f32 || want_export || (want_mean && !fuse_mean) || pool_needs32;
             // fp32 rows: every image for the next block, an export or the pool images behind the layer-stack ones, else the
             // layer-stack images only
@@ -551,8 +559,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             const bool handover = use_h2 && b + 1 == kFirstH2Block;
             const bool pre_handover = use_h2 && b + 2 == kFirstH2Block;
             int slot_c2 = -1, slot_y = -1, slot_t1 = -1, slot_o = -1, slot_t1m = -1;
-            // "rn_fuse": conv2 and conv3 back to back in one launch (the 3x3's tile never leaves the CU; conv3 on f16x2 with one scale per pixel row)
-            const bool fuse = use_early && h->gemm.rn_fuse && !blk.has_down && blk.c3.w_h2p && cur_is_f32 && blk.c2.stride == 1 && H * H >= 256;
+            // ("rn_fuse", `fuse` above: the 3x3's tile never leaves the CU; conv3 on f16x2 with one scale per pixel row)
             if (handover && fuse) slot_t1m = next_slot++;   // the MEASURED maximum of conv1's output: what the hand-over scale is bounded from (below)
             if (handover) { slot_c2 = next_slot++; slot_y = next_slot++; }
             if (use_early) slot_t1 = next_slot++;
@@ -595,7 +602,8 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                     d2.w3 = blk.c3.w_h2p; d2.colscale3 = blk.c3.w_invp; d2.bias3 = blk.c3.bias; d2.Cout3 = Cout;
                     d2.residual = cur32;
                     d2.out = need32 ? out32 : nullptr; d2.out_rows = rows32;
-                    d2.out_sp3 = out_is_f32 ? nullptr : othersp;
+                    d2.out_sp3 = (compact || !out_is_f32) ? othersp : nullptr;
+                    d2.sp3_sub = compact ? 2 : 1;
                     d2.gap_groups = fuse_mean ? gapws : nullptr; d2.gap_rows = n_ls * HWo;
                     d2.amax_out = slot_o >= 0 ? slot_amax(slot_o) : nullptr;
                     if (handover) {
@@ -628,6 +636,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 // block's stride]: no fp32 copy of the branch is written and read back (layer1.0: 6.6 GB per 1024 images)
                 d.w = blk.c3d_w_sp3; d.bias = blk.c3d_bias;
                 d.in2 = cursp; d.H2 = H; d.W2 = H; d.Cin2 = blk.down.Cin; d.stride2 = blk.down.stride;
+                if (compact_in) { d.in2 = compact_in; d.H2 = Ho; d.W2 = Ho; d.stride2 = 1; }   // (the previous block left the stride-2 sample only)
             } else {
                 d.w = blk.c3.w_sp3; d.bias = blk.c3.bias;
                 if (cur_is_f32) d.residual = cur32; else d.residual_sp3 = cursp;
@@ -663,6 +672,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             cur32 = need32 ? out32 : nullptr;
             if (need32) out32 = out32 == f32a ? f32b : f32a;
             if (!out_is_f32) { char* t = cursp; cursp = othersp; othersp = t; }
+            compact_in = compact ? othersp : nullptr;
             cur_is_f32 = out_is_f32;
             slot_xin = slot_o;
             H = Ho;
