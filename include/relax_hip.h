@@ -95,9 +95,11 @@ int relax_reserve(relax_handle* h, int max_images);
  * "rn_h2_early" (default 1): with "rn_h2", the stem and the 3x3 convolutions of layer1 / layer2 run f16x2 as well; 0 = bf16x6 there.
  * "att_h2" (default 1): under "gemm_precision" 3 the ViT's attention runs on fp16 planes too (csrc/attention_h2.hip: the qkv GEMM writes planes,
  * three partial products, K / V by LDS-DMA into the fragment images); 0 = the bf16x6 attention kernel on an fp32 qkv output (A/B switch).
- * "rn_fuse" (default 1): with "rn_h2_early", the layer1 blocks without a downsample branch run their 3x3 and their conv3 back to back in ONE
+ * "rn_fuse" (default 1): with "rn_h2_early", the layer1 / layer2 blocks without a downsample branch run their 3x3 and their conv3 back to back in ONE
  * launch (csrc/gemm_x6.hip, B2B: the 3x3's output tile stays in registers as the A operand of the 1x1, conv3 on f16x2 with one scale
- * per pixel row); 0 = two launches, conv3 on bf16x6 (A/B switch).  "b2b_rows" (256 or 128): rows per tile of those launches, same bits.
+ * per pixel row); 0 = two launches, conv3 on bf16x6 (A/B switch).  "b2b_rows" (256 or 128): rows per tile of layer1's such launches, same bits.
+ * "rn_c1_h2" (default 1): layer2's conv1 (1x1, fp32 rows in) on f16x2 - the rows are split into two fp16 planes in the K loop with the image's scale -;
+ * 0 = bf16x6 (A/B switch).
  * "debug_poison" (test mode, default 0): every workspace request fills the buffer with 0xFF bytes
  * first (synchronously), so a read of workspace that was not written in the same call shows up in the results. */
 int relax_set_option(relax_handle* h, const char* key, int value);
