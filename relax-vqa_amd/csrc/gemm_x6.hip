@@ -145,6 +145,7 @@ struct X6Params {
     const float* colscale3;
     const float* bias3;
     int N3;
+    const float* x2;   // B2B == 2: the second source of conv3 (the downsample branch of a block's first bottleneck folded in): fp32 rows [M][64], K = N + 64
     int sp3_sub;   // B2B: 2 = out_sp3 holds only the pixels with even (oy, ox), compacted to [Nimg][Ho/2][Wo/2] rows (what a stride-2 consumer samples); 1 = all
 };
 
@@ -173,7 +174,7 @@ constexpr int64_t kMaxRecords = 0x7ffffff0;
 // (the loop body is rotated: one "region" = barrier .. next barrier = M1(k) + M0(k+1) is one basic block, which the compiler's
 // scheduler interleaves better than any order pinned by hand)
 // X = the operand with fewer fragments per wave (double-buffered in registers), Y = the other one (two halves).
-template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false, bool B2B = false>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false, int B2B = 0>
 __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8 (B2B on 128 rows: 3 x 4)
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (it has no __amdgpu_buffer_rsrc_t and emits no stub for a body that names it)
     constexpr int NW = WM * WN;
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
     static_assert(!(H2 && AF32) || !B2B, "fp32 rows split into fp16 planes in the loop: the 1x1 form");
     static_assert(!B2B || (H2 && TAPS && (TM == 1 || TM == 2) && TN == 2 && (WN == 1 || (WN == 2 && TM == 2))),
                   "back to back: the f16x2 3x3 form on 4 x 1 waves of 32 or 64 rows x 64 columns, or on 4 x 2 waves of 64 x 64");
+    static_assert(B2B != 2 || (WN == 1 && TM == 2), "back to back with a second source: the four-wave form of 64 x 64 per wave");
     static_assert(STAGE % 1024 == 0 && A_BYTES % 1024 == 0, "stage regions are whole DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -751,7 +753,11 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         float* rowinv = reinterpret_cast<float*>(smem + B2B_STG);              // [WN][BM]: 1 / scale of every pixel row of the tile (per K half)
         unsigned* simg = reinterpret_cast<unsigned*>(smem + B2B_STG + WN * BM * 4);   // two per-image maxima of the tile
         if (tid < 2) simg[tid] = 0u;
-        u32x4 ah[TM][2 * TN], al[TM][2 * TN];
+        // B2B == 2 (the first block of layer1: conv3 + the downsample convolution in ONE contraction, K = [the 3x3's 64 channels | the block input's 64]):
+        // the lane also loads ITS pixel's row of the block input (fp32, k = 16q + 8 half + e: the natural order the downsample weights keep), the
+        // row maximum runs over both halves of K, and ONE scale per pixel row covers both - a single accumulator, no two-launch round trip
+        constexpr int KQ = 2 * TN + (B2B == 2 ? 4 : 0);      // 16-deep chunks of conv3's K
+        u32x4 ah[TM][KQ], al[TM][KQ];
 #pragma unroll
         for (int x = 0; x < TM; ++x) {
             const int m = m0 + (wm * TM + x) * 32 + c32;
@@ -771,9 +777,24 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
                         mx = fmaxf(mx, v);
                     }
                 }
+            [[maybe_unused]] f32x4 xa[4], xb[4];
+            if constexpr (B2B == 2) {
+                const float* xr = p.x2 + (int64_t)(m < p.M ? m : p.M - 1) * 64 + 8 * half;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xa[q] = *reinterpret_cast<const f32x4*>(xr + 16 * q);
+                    xb[q] = *reinterpret_cast<const f32x4*>(xr + 16 * q + 4);
+                    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(xa[q].x), fabsf(xa[q].y)), fmaxf(fabsf(xa[q].z), fabsf(xa[q].w))),
+                                         fmaxf(fmaxf(fabsf(xb[q].x), fabsf(xb[q].y)), fmaxf(fabsf(xb[q].z), fabsf(xb[q].w)))));
+                }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float sc = h2_scale_for(mx);
             if (half == 0) rowinv[wn * BM + (wm * TM + x) * 32 + c32] = 1.f / sc;       // (a power of two: exact)
+            if constexpr (B2B == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) split2_x8(xa[q] * sc, xb[q] * sc, ah[x][2 * TN + q], al[x][2 * TN + q]);
+            }
 #pragma unroll
             for (int y = 0; y < TN; ++y)
 #pragma unroll
@@ -796,7 +817,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         constexpr int RW = TM * 32 / WN;                                           // rows this wave finishes: 64, or 32 of the pair's 64
         const int rw0 = wn * RW;                                                   // ... starting at this row of the 64
         float tmax0 = 0.f, tmax1 = 0.f;
-        const int64_t w3row = (int64_t)BN * 4;
+        const int64_t w3row = (int64_t)(BN + (B2B == 2 ? 64 : 0)) * 4;       // conv3's K values x 4 bytes of planes
         // The memory operations of a wave complete in issue order (vmcnt), so the order below is the pipeline: the B fragments of pass p + 1
         // are requested BEFORE the stores of pass p (a wait for them must not wait for those stores' acknowledgements); the residual rows
         // come 32 at a time, requested while the accumulators are on their way through the LDS.  Residual, fp32 output and weights go
@@ -808,25 +829,26 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             const int64_t left = (int64_t)rows * p.N3 * 4 - wave_row0;
             return (int)(left < 0 ? 0 : (left < kMaxRecords ? left : kMaxRecords));
         };
-        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.residual)) + wave_row0, 0,
-                                                                                bytes_left(p.M), 0x00020000);
+        // (no residual - a block with a downsample branch -: a resource of zero bytes, every load answers zeros)
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.residual)) + (p.residual ? wave_row0 : 0), 0,
+                                                                                p.residual ? bytes_left(p.M) : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (p.out ? wave_row0 : 0), 0,
                                                                                 p.out ? bytes_left(p.out_rows < p.M ? p.out_rows : p.M) : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w3), 0, (int)((int64_t)p.N3 * w3row), 0x00020000);
         const int voff_row = (lr * p.N3 + lc) * 4;
         const int voff_w3 = c32 * (int)w3row + half * 16;
-        f16x8 bh[X6_B2B_PREFETCH_B ? 2 * TN : 1][2], bl[X6_B2B_PREFETCH_B ? 2 * TN : 1][2];
-        constexpr int QPRE = X6_B2B_PREFETCH_B == 2 ? TN : 2 * TN;   // chunks of the next pass requested ahead of this pass's stores (mode 2: the first half)
-        u32x4 ra[4], rb[4];
+        f16x8 bh[X6_B2B_PREFETCH_B ? KQ : 1][2], bl[X6_B2B_PREFETCH_B ? KQ : 1][2];
+        constexpr int QPRE = X6_B2B_PREFETCH_B == 2 ? KQ / 2 : KQ;   // chunks of the next pass requested ahead of this pass's stores (mode 2: the first half)
+        [[maybe_unused]] u32x4 ra[4], rb[4];
 #define X6_B2B_LOAD_BQ(pass_, q_, slot_)                                                                                \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                  \
-        const int so_ = ((pass_) * 64 + nt * 32) * (int)w3row + (wn * 2 * TN + (q_)) * 64;   /* (this wave's K half) */    \
+        const int so_ = ((pass_) * 64 + nt * 32) * (int)w3row + (wn * KQ + (q_)) * 64;   /* (this wave's K half) */        \
         bh[slot_][nt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, voff_w3, so_, 0));       \
         bl[slot_][nt] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w3, voff_w3 + 32, so_, 0));  \
     }
-#define X6_B2B_LOAD_B(pass_) _Pragma("unroll") for (int q = 0; q < 2 * TN; ++q) X6_B2B_LOAD_BQ(pass_, q, q)
+#define X6_B2B_LOAD_B(pass_) _Pragma("unroll") for (int q = 0; q < KQ; ++q) X6_B2B_LOAD_BQ(pass_, q, q)
 #define X6_B2B_LOAD_RES(pass_, it0_)                                                                                    \
-    _Pragma("unroll") for (int it = (it0_); it < (it0_) + 4; ++it) {                                                    \
+    if constexpr (B2B != 2) _Pragma("unroll") for (int it = (it0_); it < (it0_) + 4; ++it) {   /* (B2B == 2: no residual) */ \
         const int so_ = (it * 8 * p.N3 + (pass_) * 64) * 4;                                                             \
         if (X6_B2B_ABL & 2) { ra[it & 3] = (u32x4){0u, 0u, 0u, 0u}; rb[it & 3] = ra[it & 3]; continue; }                \
         ra[it & 3] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff_row, so_, 0);                                   \
@@ -850,8 +872,10 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             va = (a0 * (cs_a * ri0) + a1 * (cs_a * ri1)) + b3_a;   /* the two K halves in a fixed order */              \
             vb = (b0 * (cs_b * ri0) + b1 * (cs_b * ri1)) + b3_b;                                                        \
         }                                                                                                               \
-        va += __builtin_bit_cast(f32x4, ra[it & 3]);   /* (acc + bias) + residual: the order of the two-launch path */  \
-        vb += __builtin_bit_cast(f32x4, rb[it & 3]);                                                                    \
+        if constexpr (B2B != 2) {                                                                                       \
+            va += __builtin_bit_cast(f32x4, ra[it & 3]);   /* (acc + bias) + residual: the order of the two-launch path */ \
+            vb += __builtin_bit_cast(f32x4, rb[it & 3]);                                                                \
+        }                                                                                                               \
         va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};                           \
         vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};                           \
         if (p.gap) {                                                                                                    \
@@ -896,10 +920,10 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
 #pragma unroll
                         for (int r = 0; r < 16; ++r) c2[x][nt][r] = 0.f;
 #pragma unroll
-                for (int q = 0; q < 2 * TN; ++q) {
+                for (int q = 0; q < KQ; ++q) {
                     constexpr int slot = X6_B2B_PREFETCH_B ? -1 : 0;
                     if (!X6_B2B_PREFETCH_B) X6_B2B_LOAD_BQ(pass, q, 0);
-                    if (X6_B2B_PREFETCH_B == 2 && q == 0) { _Pragma("unroll") for (int q2 = QPRE; q2 < 2 * TN; ++q2) X6_B2B_LOAD_BQ(pass, q2, q2); }
+                    if (X6_B2B_PREFETCH_B == 2 && q == 0) { _Pragma("unroll") for (int q2 = QPRE; q2 < KQ; ++q2) X6_B2B_LOAD_BQ(pass, q2, q2); }
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1237,7 +1261,7 @@ __global__ __launch_bounds__(256) void splitk_finish_x6(const X6Params p) {
     if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lc, va, vb);
 }
 
-template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false, bool B2B = false>
+template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false, int B2B = 0>
 static int launch_x6_variant(relax_handle* h, X6Params& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     constexpr int WG_PER_CU = NT == 256 ? 2 : 1;
@@ -1321,10 +1345,12 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     const bool taps = d.KH * d.KW > 1;
     const bool b2b = d.w3 != nullptr;
     p.w3 = static_cast<const char*>(d.w3); p.colscale3 = d.colscale3; p.bias3 = d.bias3; p.N3 = d.Cout3; p.sp3_sub = d.sp3_sub == 2 ? 2 : 1;
+    p.x2 = d.x2;
+    RELAX_REQUIRE(h, !d.x2 || (b2b && d.Cout == 64 && !d.residual), "x6 conv: a second conv3 source (fp32 rows of 64 channels) goes with the 64-wide back-to-back form, without a residual");
     RELAX_REQUIRE(h, d.sp3_sub != 2 || (b2b && d.out_sp3 && d.Ho % 2 == 0 && d.Wo % 2 == 0), "x6 conv: the stride-2 plane output goes with the back-to-back form and even maps");
     RELAX_REQUIRE(h, !b2b || (d.in_h2 && taps && (d.Cout == 64 || d.Cout == 128) && d.Cout3 % 64 == 0 && d.Cout3 > 0 && d.colscale3 && d.bias3 && d.bias && d.act == 1 &&
-                              d.residual && !d.residual_sp3 && !d.in2 && (d.Ho * d.Wo) % 16 == 0 && d.Ho * d.Wo >= 256),
-                  "x6 conv: the back-to-back form needs the f16x2 3x3 onto 64 or 128 columns, ReLU, both biases, an fp32 residual and images of >= 256 pixels (a multiple of 16)");
+                              (d.residual || d.x2) && !d.residual_sp3 && !d.in2 && (d.Ho * d.Wo) % 16 == 0 && d.Ho * d.Wo >= 256),
+                  "x6 conv: the back-to-back form needs the f16x2 3x3 onto 64 or 128 columns, ReLU, both biases, an fp32 residual (or the second source) and images of >= 256 pixels (a multiple of 16)");
     RELAX_REQUIRE(h, p.M > 0 && p.N > 0 && p.K > 0, "x6 conv/gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     RELAX_REQUIRE(h, d.Cin % 16 == 0, "x6 conv/gemm: Cin=%d must be a multiple of 16", d.Cin);
     RELAX_REQUIRE(h, p.N % 64 == 0, "x6 conv/gemm: N=%d must be a multiple of 64", p.N);
@@ -1351,11 +1377,11 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     RELAX_REQUIRE(h, aligned16(d.in) && aligned16(d.w) && aligned16(d.bias) && aligned16(d.residual) && aligned16(d.residual_sp3) &&
                          aligned16(d.out) && aligned16(d.out_sp3) && aligned16(d.gap_groups) && aligned16(d.in2),
                   "x6 conv/gemm: every operand pointer must be 16-byte aligned");
-    const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * ((double)p.N * (double)p.K + (b2b ? (double)p.N * d.Cout3 : 0.0));
+    const double flops = d.flops > 0 ? d.flops : 2.0 * p.M * ((double)p.N * (double)p.K + (b2b ? (double)(p.N + (d.x2 ? 64 : 0)) * d.Cout3 : 0.0));
     // algorithmic HBM bytes: activation in (6 B per value), weights, outputs (+ residual), each touched once
     const double n_out = b2b ? d.Cout3 : p.N;    // (back to back: the outputs and the residual are the conv3's)
     const double bytes = ((d.in_f32 || d.in_h2) ? 4.0 : 6.0) * ((double)d.Nimg * d.H * d.W * d.Cin) +
-                         ((d.in_h2 || f32_h2) ? 4.0 : 6.0) * ((double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) + (b2b ? 4.0 * p.N * d.Cout3 : 0.0) +
+                         ((d.in_h2 || f32_h2) ? 4.0 : 6.0) * ((double)p.N * p.K + (d.in2 ? (double)p.M * d.Cin2 : 0.0)) + (b2b ? 4.0 * (p.N + (d.x2 ? 64 : 0)) * d.Cout3 : 0.0) + (d.x2 ? 4.0 * p.M * 64 : 0.0) +
                          (double)p.M * n_out * ((d.out ? 4.0 : 0.0) + (d.out_sp3 ? (d.sp3_sub == 2 ? 1.5 : 6.0) : 0.0) + (d.out_h2 ? 4.0 : 0.0) + (d.residual ? 4.0 : 0.0) + (d.residual_sp3 ? 6.0 : 0.0));
     int span;
     RELAX_TRY(prof_begin(h, s, (d.in_h2 || f32_h2) ? 5 : 2, flops, &span, bytes));   // (kind 5 = f16x2: three executed products per fp32 product)
@@ -1364,6 +1390,8 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     // loop on four waves, two workgroups per CU
     if (b2b && d.Cout == 128)   // ... of a 128-wide block: eight waves, conv3's K split over the two column waves
         rc = launch_x6_variant<256, 128, 4, 2, true, false, false, false, true, true>(h, p, s);
+    else if (b2b && d.x2)   // ... of a first block: conv3's K = [the 3x3's channels | the block input's]: the downsample convolution folded in
+        rc = launch_x6_variant<256, 64, 4, 1, true, false, false, false, true, 2>(h, p, s);
     else if (b2b)   // the 3x3 and the block's conv3 back to back (the 3x3's tile stays in registers)
         rc = h->gemm.b2b_rows == 256 ? launch_x6_variant<256, 64, 4, 1, true, false, false, false, true, true>(h, p, s)
                                      : launch_x6_variant<128, 64, 4, 1, true, false, false, false, true, true>(h, p, s);

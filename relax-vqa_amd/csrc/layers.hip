@@ -354,6 +354,19 @@ int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, 
     return RELAX_OK;
 }
 
+int launch_bn_relu_maxpool_f32(relax_handle* h, const float* x, const float* scale, const float* shift, float* y, int Nimg, int H, int W, int C,
+                               hipStream_t s, unsigned* amax_out, unsigned* block_ws) {
+    RELAX_REQUIRE(h, Nimg > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "bn_relu_maxpool_f32: bad shape");
+    const int64_t total = (int64_t)Nimg * (H / 2) * (W / 2) * (C / 4);
+    const int64_t per_image = (int64_t)(H / 2) * (W / 2) * (C / 4);
+    RELAX_REQUIRE(h, !amax_out || (block_ws && per_image % 256 == 0), "bn_relu_maxpool_f32: per-image maxima need whole blocks per image");
+    hipLaunchKernelGGL(bn_relu_maxpool_nhwc<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, scale, shift, y, Nimg, H, W, C,
+                       amax_out ? block_ws : nullptr);
+    if (amax_out) hipLaunchKernelGGL(image_max_of_blocks, dim3(Nimg), dim3(64), 0, s, block_ws, (int)(per_image / 256), amax_out);
+    RELAX_HIP_CHECK(h, hipGetLastError());
+    return RELAX_OK;
+}
+
 int launch_bn_relu_maxpool_sp3(relax_handle* h, const float* x, const float* scale, const float* shift, void* y_sp3,
                                int Nimg, int H, int W, int C, hipStream_t s, unsigned* amax_out, unsigned* block_ws) {
     RELAX_REQUIRE(h, Nimg > 0 && H % 2 == 0 && W % 2 == 0 && C % 16 == 0, "bn_relu_maxpool_sp3: bad shape");

@@ -110,6 +110,9 @@ struct ConvDescX6 {
     const float* colscale3;
     const float* bias3;
     int Cout3;
+    const float* x2;        // back-to-back form of a layer's FIRST block (64-wide): the block input as fp32 rows [M][64] - conv3 then contracts over
+                            // K = [the 3x3's 64 channels | these 64] with w3 = [conv3 (permuted K) | downsample (natural K)] rows of 128 and bias3 = the sum of
+                            // the two shifts; no residual
     int sp3_sub;            // back-to-back form: 2 = out_sp3 receives only the pixels with even (oy, ox), as compact [Nimg][Ho/2][Wo/2] rows - the sample the
                             // next block's stride-2 downsample branch reads (the full map travels as fp32 rows); 0 / 1 = every pixel
 };
@@ -162,6 +165,8 @@ struct Bottleneck {
     // K = [conv2 output | block input] (weights [Cout][(width + Cin) * 6 B] as split planes, bias = the sum of the two folded shifts)
     void* c3d_w_sp3 = nullptr;
     float* c3d_bias = nullptr;
+    void* c3d_w_h2p = nullptr;   // back-to-back form of a 64-wide first block: [conv3 (K permuted) | downsample] rows as fp16 planes + their inverse row scales
+    float* c3d_w_invp = nullptr;
     bool has_down = false;
     int tap = -1;  // layer-stack tap index, -1 if not tapped
 };
@@ -371,6 +376,8 @@ int launch_attention_h2(relax_handle* h, const void* qkv_planes, float s_qkv, vo
 int launch_attention_h2_op(relax_handle* h, const float* qkv, float* out, int Nimg, int heads, hipStream_t s);   // fp32 in / out (relax_op_attention)
 int launch_bn_relu_maxpool(relax_handle* h, const float* x, const float* scale, const float* shift, float* y,
                            int Nimg, int H, int W, int C, hipStream_t s);
+int launch_bn_relu_maxpool_f32(relax_handle* h, const float* x, const float* scale, const float* shift, float* y, int Nimg, int H, int W, int C,
+                               hipStream_t s, unsigned* amax_out, unsigned* block_ws);   // fp32 rows out + the per-image maxima
 int launch_bn_relu_maxpool_sp3(relax_handle* h, const float* x, const float* scale, const float* shift, void* y_sp3,
                                int Nimg, int H, int W, int C, hipStream_t s, unsigned* amax_out = nullptr, unsigned* block_ws = nullptr);
 int launch_gap_groups_finish(relax_handle* h, const float* groups, float* out, int Nimg, int HW, int C, int64_t out_stride,

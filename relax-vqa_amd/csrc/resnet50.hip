@@ -334,6 +334,42 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
         blk.c3.w_h2p = q;
         blk.c3.w_invp = inv;
     }
+    // ... and for a 64-wide FIRST block (layer1[0]: downsample without a stride, 64 input channels) [conv3 (K permuted) | downsample (natural K)] rows of
+    // 128 as fp16 planes: its back-to-back form contracts conv3 and the downsample convolution in one accumulator (gemm_x6.hip, B2B == 2)
+    for (size_t b = 0; b < kFirstH2Block && b < rn.blocks.size(); ++b) {
+        Bottleneck& blk = rn.blocks[b];
+        if (!blk.has_down || blk.c3.Cin != 64 || blk.down.Cin != 64 || blk.down.stride != 1 || blk.c2.stride != 1) continue;
+        const int Co = blk.c3.Cout;
+        float *perm = nullptr, *cat = nullptr, *inv = nullptr;
+        void* q = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&perm), sizeof(float) * (size_t)Co * 64) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&cat), sizeof(float) * (size_t)Co * 128) != hipSuccess ||
+            hipMalloc(&q, (size_t)Co * 128 * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&inv), sizeof(float) * (size_t)Co) != hipSuccess) {
+            if (perm) (void)hipFree(perm);
+            if (cat) (void)hipFree(cat);
+            if (q) (void)hipFree(q);
+            set_error(h, "resnet50: hipMalloc of the two-source back-to-back weights failed");
+            free_resnet(h);
+            return RELAX_ERR_NOMEM;
+        }
+        rn.allocs.push_back(q);
+        rn.allocs.push_back(inv);
+        rc = launch_b2b_permute_k(h, blk.c3.w, perm, Co, 64, nullptr);
+        hipError_t e = rc == RELAX_OK ? hipDeviceSynchronize() : hipErrorUnknown;
+        if (e == hipSuccess) e = hipMemcpy2D(cat, sizeof(float) * 128, perm, sizeof(float) * 64, sizeof(float) * 64, Co, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy2D(cat + 64, sizeof(float) * 128, blk.down.w, sizeof(float) * 64, sizeof(float) * 64, Co, hipMemcpyDeviceToDevice);
+        rc = e == hipSuccess ? launch_to_h2_rows(h, cat, 128, q, Co, 128, inv, nullptr) : RELAX_ERR_HIP;
+        if (rc == RELAX_OK && hipDeviceSynchronize() != hipSuccess) rc = RELAX_ERR_HIP;
+        (void)hipFree(perm);
+        (void)hipFree(cat);
+        if (rc != RELAX_OK) {
+            set_error(h, "resnet50: building the two-source back-to-back weights failed");
+            free_resnet(h);
+            return rc;
+        }
+        blk.c3d_w_h2p = q;
+        blk.c3d_w_invp = inv;
+    }
     // ... and, for the four blocks with a downsample branch, [conv3 | downsample] rows side by side
     for (Bottleneck& blk : rn.blocks) {
         if (!blk.has_down) continue;
@@ -449,6 +485,13 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
         for (size_t b = 0; b < kFirstH2Block && use_early; ++b) use_early = rn.blocks[b].c2.w_h2 != nullptr;
         int slot_xin = -1;        // (early) the slot that holds the maximum of the current block input
         if (use_early) slot_xin = next_slot++;
+        // "rn_fuse": layer1[0] back to back too, with the downsample convolution folded into its conv3 - the block input then travels as fp32 rows
+        // (4 B per value instead of 6: conv1 splits them in its K loop, the fused launch reads each pixel's row as conv3's second source)
+        const bool fuse0 = use_early && h->gemm.rn_fuse && h->gemm.fp32_rows && rn.blocks[0].c3d_w_h2p != nullptr;
+        if (fuse0)
+            RELAX_TRY(launch_bn_relu_maxpool_f32(h, bufA, rn.bn1_scale, rn.bn1_shift, bufD, N, 112, 112, 64, s, slot_amax(slot_xin),
+                                                 reinterpret_cast<unsigned*>(imgtab + 3 * kImgSlots * n)));
+        else
         RELAX_TRY(launch_bn_relu_maxpool_sp3(h, bufA, rn.bn1_scale, rn.bn1_shift, spa, N, 112, 112, 64, s,
                                              use_early ? slot_amax(slot_xin) : nullptr,
                                              reinterpret_cast<unsigned*>(imgtab + 3 * kImgSlots * n)));
@@ -461,11 +504,11 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
         // column tile, so every value is split exactly once, as the producer's epilogue would have) splits them inside its K loop
         // and its conv3 adds them as an fp32 residual - the same values bit for bit.  A layer's last block writes planes: the next
         // layer's first conv3 reads them as its second activation source.
-        const float* cur32 = nullptr;
+        const float* cur32 = fuse0 ? bufD : nullptr;   // (f32b: block 0 writes f32a, block 1 - which overwrites f32b - runs when block 0 is through)
         char* cursp = spa;
         char* othersp = spb;
         float* out32 = f32a;
-        bool cur_is_f32 = false;   // the current block input exists as fp32 rows only
+        bool cur_is_f32 = fuse0;   // the current block input exists as fp32 rows only
         const char* compact_in = nullptr;   // ... plus the planes of its stride-2 sample, compacted (what the previous block left for a downsample branch)
         int H = 56;
         for (size_t b = 0; b < rn.blocks.size(); ++b) {
@@ -479,7 +522,8 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             const bool fuse_mean = want_mean && HWo % 4 == 0;
             const bool pool_needs32 = is_last && pool && !pool_from_stack;
             // "rn_fuse" (below): conv2 and conv3 back to back in one launch
-            const bool fuse = use_early && b < kFirstH2Block && h->gemm.rn_fuse && !blk.has_down && blk.c3.w_h2p && cur_is_f32 && blk.c2.stride == 1 && H * H >= 256;
+            const bool fuse_x2 = b == 0 && fuse0;      // the first block: conv3 + downsample in the fused launch's one contraction
+            const bool fuse = fuse_x2 || (use_early && b < kFirstH2Block && h->gemm.rn_fuse && !blk.has_down && blk.c3.w_h2p && cur_is_f32 && blk.c2.stride == 1 && H * H >= 256);
             // a layer's last block in front of a downsample block: its output travelled as three bf16 planes (6 B per value: the next block's conv1 and
             // the second source of its conv3 read planes).  Back to back it leaves as fp32 rows like the others (conv1 splits in its K loop) PLUS the
             // planes of the stride-2 sample only - all the downsample branch reads -, compacted: 4 + 1.5 bytes per value instead of 6, and conv1 reads 4
@@ -601,6 +645,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                     d2.out_sp3 = nullptr;
                     d2.w3 = blk.c3.w_h2p; d2.colscale3 = blk.c3.w_invp; d2.bias3 = blk.c3.bias; d2.Cout3 = Cout;
                     d2.residual = cur32;
+                    if (fuse_x2) { d2.w3 = blk.c3d_w_h2p; d2.colscale3 = blk.c3d_w_invp; d2.bias3 = blk.c3d_bias; d2.residual = nullptr; d2.x2 = cur32; }
                     d2.out = need32 ? out32 : nullptr; d2.out_rows = rows32;
                     d2.out_sp3 = (compact || !out_is_f32) ? othersp : nullptr;
                     d2.sp3_sub = compact ? 2 : 1;
