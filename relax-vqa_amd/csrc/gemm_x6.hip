@@ -888,20 +888,18 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vb), rs_out, voff_row + 16, so_, 0);       \
         }                                                                                                               \
         if (m >= p.M) continue;                                                                                         \
-        if (p.out_sp3) {                                                                                                \
+        if (p.out_sp3 || p.out_h2 || p.amax_out) {                                                                      \
+            const int img = m / (p.Ho * p.Wo);                                                                          \
             int64_t ms_ = m;                                                                                            \
             bool keep_ = true;                                                                                          \
-            if (p.sp3_sub == 2) {   /* the stride-2 sample of the map, compacted */                                     \
-                const int img_ = m / (p.Ho * p.Wo), rem_ = m - img_ * (p.Ho * p.Wo);                                    \
+            if (p.sp3_sub == 2) {   /* the planes hold the stride-2 sample of the map only, compacted */                \
+                const int rem_ = m - img * (p.Ho * p.Wo);                                                               \
                 const int oy_ = rem_ / p.Wo, ox_ = rem_ - oy_ * p.Wo;                                                   \
                 keep_ = ((oy_ | ox_) & 1) == 0;                                                                         \
-                ms_ = ((int64_t)img_ * (p.Ho >> 1) + (oy_ >> 1)) * (p.Wo >> 1) + (ox_ >> 1);                            \
+                ms_ = ((int64_t)img * (p.Ho >> 1) + (oy_ >> 1)) * (p.Wo >> 1) + (ox_ >> 1);                             \
             }                                                                                                           \
-            if (keep_) store_sp3_x8(p.out_sp3 + ms_ * ((int64_t)p.N3 * 6), n0p + lc, va, vb);                           \
-        }                                                                                                               \
-        if (p.out_h2 || p.amax_out) {                                                                                   \
-            const int img = m / (p.Ho * p.Wo);                                                                          \
-            if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N3 * 4), n0p + lc, va, vb, p.img_out_scale[img]); \
+            if (p.out_sp3 && keep_) store_sp3_x8(p.out_sp3 + ms_ * ((int64_t)p.N3 * 6), n0p + lc, va, vb);              \
+            if (p.out_h2 && keep_) store_h2_x8(p.out_h2 + ms_ * ((int64_t)p.N3 * 4), n0p + lc, va, vb, p.img_out_scale[img]); \
             const float mx = fmaxf(fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w)), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w))); \
             if (img == img_first) tmax0 = fmaxf(tmax0, mx);      /* (a tile of 256 rows spans at most two images of >= 256 rows) */ \
             else tmax1 = fmaxf(tmax1, mx);                                                                              \
@@ -1347,7 +1345,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     p.w3 = static_cast<const char*>(d.w3); p.colscale3 = d.colscale3; p.bias3 = d.bias3; p.N3 = d.Cout3; p.sp3_sub = d.sp3_sub == 2 ? 2 : 1;
     p.x2 = d.x2;
     RELAX_REQUIRE(h, !d.x2 || (b2b && d.Cout == 64 && !d.residual), "x6 conv: a second conv3 source (fp32 rows of 64 channels) goes with the 64-wide back-to-back form, without a residual");
-    RELAX_REQUIRE(h, d.sp3_sub != 2 || (b2b && d.out_sp3 && d.Ho % 2 == 0 && d.Wo % 2 == 0), "x6 conv: the stride-2 plane output goes with the back-to-back form and even maps");
+    RELAX_REQUIRE(h, d.sp3_sub != 2 || (b2b && (d.out_sp3 || d.out_h2) && d.Ho % 2 == 0 && d.Wo % 2 == 0), "x6 conv: the stride-2 plane output goes with the back-to-back form and even maps");
     RELAX_REQUIRE(h, !b2b || (d.in_h2 && taps && (d.Cout == 64 || d.Cout == 128) && d.Cout3 % 64 == 0 && d.Cout3 > 0 && d.colscale3 && d.bias3 && d.bias && d.act == 1 &&
                               (d.residual || d.x2) && !d.residual_sp3 && !d.in2 && (d.Ho * d.Wo) % 16 == 0 && d.Ho * d.Wo >= 256),
                   "x6 conv: the back-to-back form needs the f16x2 3x3 onto 64 or 128 columns, ReLU, both biases, an fp32 residual (or the second source) and images of >= 256 pixels (a multiple of 16)");
@@ -1370,7 +1368,7 @@ int launch_conv_x6(relax_handle* h, const ConvDescX6& d, hipStream_t s) {
     const bool f32_h2 = d.in_f32 && d.img_in_scale != nullptr;   // fp32 rows split into fp16 planes in the K loop, weights as fp16 planes: three products
     RELAX_REQUIRE(h, !f32_h2 || (d.colscale && d.img_in_inv && p.K >= 256 && !d.in_h2 && p.N % 128 == 0), "x6 conv: fp32 rows on f16x2 need the weights' inverse "
                   "row scales, both per-image scale tables, K >= 256 (three products) and N %% 128 == 0");
-    RELAX_REQUIRE(h, !d.in_f32 || (!taps && !d.in2 && d.stride == 1 && p.N % 256 != 0),
+    RELAX_REQUIRE(h, !d.in_f32 || (!taps && !d.in2 && ((d.stride == 1 && p.N % 256 != 0) || f32_h2)),
                   "x6 conv/gemm: fp32 activation rows go with a 1x1 stride-1 contraction of 64 or 128 (not a multiple of 256) output columns");
     // every operand is read / written in 16-byte units (LDS-DMA pieces, f32x4 bias / residual / output accesses, plane units)
     auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };

@@ -284,7 +284,10 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
         const bool early = b < kFirstH2Block;
         for (ConvW* c : {&blk.c1, &blk.c2, &blk.c3, &blk.down}) {
             // (early blocks: the 3x3 - and conv1, whose fp32 input rows are split in the K loop under "rn_c1_h2")
-            if (!c->w || (early && ((c != &blk.c2 && c != &blk.c1) || c->Cin % 16 != 0 || c->Cout % 64 != 0 || c->Cout % 256 == 0))) continue;
+            // ... and the downsample convolution of a stride-2 first block (layer2[0]), which runs as a launch of its own in front of that block's
+            // back-to-back launch: its output is the fused conv3's fp32 residual)
+            const bool early_down = early && c == &blk.down && blk.has_down && c->stride == 2 && c->Cin % 16 == 0 && c->Cout % 128 == 0 && c->Cin >= 256;
+            if (!c->w || (early && !early_down && ((c != &blk.c2 && c != &blk.c1) || c->Cin % 16 != 0 || c->Cout % 64 != 0 || c->Cout % 256 == 0))) continue;
             const int K = c->KH * c->KW * c->Cin;
             void* q = nullptr;
             float* inv = nullptr;
@@ -307,7 +310,8 @@ int relax_load_resnet50(relax_handle* h, const float* const* tensors, const char
     // back-to-back form ("rn_fuse": gemm_x6.hip, B2B - the 3x3's transposed accumulator tile is the A operand)
     for (size_t b = 0; b < kFirstH2Block && b < rn.blocks.size(); ++b) {
         Bottleneck& blk = rn.blocks[b];
-        if (blk.has_down || (blk.c3.Cin != 64 && blk.c3.Cin != 128)) continue;        // (64-wide blocks: the four-wave form; 128-wide: eight waves)
+        // (64-wide blocks: the four-wave form; 128-wide: eight waves; a 128-wide FIRST block too - layer2[0]: its downsample branch arrives as a residual)
+        if ((blk.has_down && !(blk.c3.Cin == 128 && blk.down.stride == 2)) || (blk.c3.Cin != 64 && blk.c3.Cin != 128)) continue;
         const int K = blk.c3.Cin, Co = blk.c3.Cout;
         float* perm = nullptr;
         void* q = nullptr;
@@ -509,6 +513,8 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
         char* othersp = spb;
         float* out32 = f32a;
         bool cur_is_f32 = fuse0;   // the current block input exists as fp32 rows only
+        const char* dr_planes = nullptr;    // ... or as fp16 planes with the per-image scale of slot dr_slot (for a downsample launch of its own)
+        int dr_slot = -1, dr_slot_next = -1;
         const char* compact_in = nullptr;   // ... plus the planes of its stride-2 sample, compacted (what the previous block left for a downsample branch)
         int H = 56;
         for (size_t b = 0; b < rn.blocks.size(); ++b) {
@@ -523,13 +529,22 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             const bool pool_needs32 = is_last && pool && !pool_from_stack;
             // "rn_fuse" (below): conv2 and conv3 back to back in one launch
             const bool fuse_x2 = b == 0 && fuse0;      // the first block: conv3 + downsample in the fused launch's one contraction
-            const bool fuse = fuse_x2 || (use_early && b < kFirstH2Block && h->gemm.rn_fuse && !blk.has_down && blk.c3.w_h2p && cur_is_f32 && blk.c2.stride == 1 && H * H >= 256);
+            // layer2[0] (stride 2, 256 -> 512 downsample: too many channels for a second source in registers): the downsample convolution as a
+            // launch of its own (f16x2, the fp32 rows sampled with the stride and split in the K loop) whose fp32 output is the residual of the
+            // block's back-to-back launch (3x3 with the stride -> conv3) - instead of the 3x3 + the two-source bf16x6 conv3
+            auto down_as_residual = [&](const Bottleneck& k) {
+                return use_early && h->gemm.rn_fuse && h->gemm.rn_c1_h2 && h->gemm.fp32_rows && k.has_down && k.c2.stride == 2 && k.c3.w_h2p && k.down.w_h2 &&
+                       k.c1.w_h2 && k.c1.Cout % 128 == 0 && k.c1.Cin >= 256;
+            };
+            const bool fuse_dr = b > 0 && b < kFirstH2Block && cur_is_f32 && down_as_residual(blk) && Ho * Ho >= 256 && dr_planes != nullptr;
+            const bool fuse = fuse_x2 || fuse_dr || (use_early && b < kFirstH2Block && h->gemm.rn_fuse && !blk.has_down && blk.c3.w_h2p && cur_is_f32 && blk.c2.stride == 1 && H * H >= 256);
             // a layer's last block in front of a downsample block: its output travelled as three bf16 planes (6 B per value: the next block's conv1 and
             // the second source of its conv3 read planes).  Back to back it leaves as fp32 rows like the others (conv1 splits in its K loop) PLUS the
             // planes of the stride-2 sample only - all the downsample branch reads -, compacted: 4 + 1.5 bytes per value instead of 6, and conv1 reads 4
             const bool next_down = !is_last && rn.blocks[b + 1].has_down;
-            const bool compact = fuse && next_down && b + 1 < kFirstH2Block && h->gemm.fp32_rows && Cout <= 512 && Ho % 2 == 0 && rn.blocks[b + 1].c2.stride == 2;
-            const bool out_is_f32 = h->gemm.fp32_rows && Cout <= 512 && !is_last && (!next_down || compact);
+            const bool next_dr = next_down && b + 1 < kFirstH2Block && fuse && down_as_residual(rn.blocks[b + 1]);   // the next block reads fp32 rows only
+            const bool compact = fuse && next_down && !next_dr && b + 1 < kFirstH2Block && h->gemm.fp32_rows && Cout <= 512 && Ho % 2 == 0 && rn.blocks[b + 1].c2.stride == 2;
+            const bool out_is_f32 = h->gemm.fp32_rows && Cout <= 512 && !is_last && (!next_down || compact || next_dr);
             const bool need32 = out_is_f32 || want_export || (want_mean && !fuse_mean) || pool_needs32;
             // fp32 rows: every image for the next block, an export or the pool images behind the layer-stack ones, else the
             // layer-stack images only
@@ -604,7 +619,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             const bool pre_handover = use_h2 && b + 2 == kFirstH2Block;
             int slot_c2 = -1, slot_y = -1, slot_t1 = -1, slot_o = -1, slot_t1m = -1;
             // ("rn_fuse", `fuse` above: the 3x3's tile never leaves the CU; conv3 on f16x2 with one scale per pixel row)
-            if (handover && fuse) slot_t1m = next_slot++;   // the MEASURED maximum of conv1's output: what the hand-over scale is bounded from (below)
+            if ((handover || next_dr) && fuse) slot_t1m = next_slot++;   // the MEASURED maximum of conv1's output: what the scale of an output that leaves as fp16 planes is bounded from (below)
             if (handover) { slot_c2 = next_slot++; slot_y = next_slot++; }
             if (use_early) slot_t1 = next_slot++;
             // the maximum of this block's output: the next block's conv1 scale (early), the residual term of the hand-over block
@@ -645,10 +660,33 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                     d2.out_sp3 = nullptr;
                     d2.w3 = blk.c3.w_h2p; d2.colscale3 = blk.c3.w_invp; d2.bias3 = blk.c3.bias; d2.Cout3 = Cout;
                     d2.residual = cur32;
+                    if (fuse_dr) {
+                        // the downsample branch first: fp32 [N*Ho*Ho][Cout] into bufA (the stem's raw output: dead since the max-pool), on gemm_h3's
+                        // 1x1 form from the compact fp16 planes of the input's stride-2 sample the previous block left (its per-image scale: dr_slot)
+                        GemmDescH2 g{};
+                        g.a = dr_planes; g.w = blk.down.w_h2; g.colscale = blk.down.w_inv; g.bias = blk.down.bias; g.act = 0;
+                        g.pixels = 1; g.Nimg = N; g.H = Ho; g.W = Ho; g.Cin = blk.down.Cin; g.Ho = Ho; g.Wo = Ho;
+                        g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0;
+                        g.M = N * Ho * Ho; g.N = blk.down.Cout; g.K = blk.down.Cin;
+                        g.rows_per_img = Ho * Ho; g.img_in_inv = slot_inv(dr_slot);
+                        g.out = bufA;
+                        RELAX_TRY(launch_gemm_h2(h, g, s));
+                        d2.residual = bufA;
+                    }
+                    if (next_dr) {
+                        // this block's output leaves as fp32 rows AND as the fp16 planes of its stride-2 sample (compacted): what the next block's
+                        // downsample launch reads.  Their per-image scale: Hoelder from the measured maxima of conv1's output and of the block input
+                        // (as the hand-over block below)
+                        const int sy = next_slot++;
+                        RELAX_TRY(launch_h2_image_scales(h, slot_amax(slot_t1m), blk.c3.l1max * blk.c2.l1max, nullptr, 0.f, slot_amax(slot_xin),
+                                                         blk.c3.l1max * blk.c2.bmax + blk.c3.bmax, slot_scale(sy), slot_inv(sy), N, s));
+                        d2.out_h2 = othersp; d2.img_out_scale = slot_scale(sy); d2.sp3_sub = 2;
+                        dr_slot_next = sy;
+                    }
                     if (fuse_x2) { d2.w3 = blk.c3d_w_h2p; d2.colscale3 = blk.c3d_w_invp; d2.bias3 = blk.c3d_bias; d2.residual = nullptr; d2.x2 = cur32; }
                     d2.out = need32 ? out32 : nullptr; d2.out_rows = rows32;
                     d2.out_sp3 = (compact || !out_is_f32) ? othersp : nullptr;
-                    d2.sp3_sub = compact ? 2 : 1;
+                    d2.sp3_sub = (compact || next_dr) ? 2 : 1;
                     d2.gap_groups = fuse_mean ? gapws : nullptr; d2.gap_rows = n_ls * HWo;
                     d2.amax_out = slot_o >= 0 ? slot_amax(slot_o) : nullptr;
                     if (handover) {
@@ -718,6 +756,9 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
             if (need32) out32 = out32 == f32a ? f32b : f32a;
             if (!out_is_f32) { char* t = cursp; cursp = othersp; othersp = t; }
             compact_in = compact ? othersp : nullptr;
+            dr_planes = (fuse && next_dr) ? othersp : nullptr;
+            dr_slot = dr_slot_next;
+            dr_slot_next = -1;
             cur_is_f32 = out_is_f32;
             slot_xin = slot_o;
             H = Ho;
