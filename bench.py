@@ -583,7 +583,8 @@ KERNEL_TEXT = {
     "bf16x3": "conv_gemm_f32<..., bf16x3> (3 x v_mfma_f32_32x32x16_bf16 per fp32 product)",
     "bf16x6": "gemm_x6 + conv1_x6 (six bf16 partial products per fp32 product on v_mfma_f32_16x16x32_bf16 / 32x32x16)",
     "f16x2": "every contraction launch: gemm_h3 (f16x2: three fp16 partial products per fp32 product on v_mfma_f32_16x16x32_f16 - the ViT GEMMs, ResNet-50's "
-             "layer3 / layer4), the f16x2 kernels of ResNet-50's stem, layer1 and layer2 (v_mfma_f32_32x32x16_f16) and what is left on gemm_x6 (bf16x6, six products)"}
+             "layer3 / layer4, layer2[0]'s downsample), the f16x2 kernels of ResNet-50's stem, layer1 and layer2 (v_mfma_f32_32x32x16_f16: 3x3 + conv3 back to back, "
+             "layer2's conv1) and what is left on gemm_x6 (bf16x6, six products: layer1's three conv1 launches)"}
 FRAC_NOTE = ("frac = achieved / peak with achieved = ALGORITHMIC fp32 FLOPs (2 x MAC of the contraction) / launch time (SURVEY 8(d)); pipe_busy_frac = the 16-bit "
              "matrix-pipe FLOPs actually executed (3 per fp32 product under f16x2, 6 under bf16x6) / the same peak: how busy the pipe is, not what the kernel delivers")
 
@@ -677,9 +678,9 @@ def flow_stage_record(prof, elapsed_s, traffic_per_clip=None):
     return rec
 H2_EXECUTED = 3.0   # fp16 MFMA products per fp32 product in gemm_h3 at K >= 256 ("h2_form" 1): A[lo] B[hi], A[hi] B[lo], A[hi] B[hi]
 DTYPE_TEXT = {"f16x2": "f32 (fp32-grade split-operand arithmetic, fp32 accumulate: the whole ViT (GEMMs and attention), ResNet-50's stem, layer3 / layer4, "
-                       "the 3x3 convolutions of layer1 / layer2 and the conv3 of layer1's back-to-back blocks on fp32 operands as 2 fp16 planes x a power-of-two "
-                       "scale, 3 partial products (4 below K = 256) on the fp16 MFMA [f16x2]; the other 1x1 convolutions of ResNet-50's layer1 / layer2 (HBM-bound) "
-                       "on 3 bf16 planes, 6 partial products on the bf16 MFMA [bf16x6])",
+                       "and in layer1 / layer2 the 3x3 convolutions, every conv3 (back to back with its 3x3), the downsample convolutions and layer2's conv1 on fp32 operands "
+                       "as 2 fp16 planes x a power-of-two scale, 3 partial products (4 below K = 256) on the fp16 MFMA [f16x2]; the three conv1 (1x1) launches of "
+                       "layer1 (HBM-bound) on 3 bf16 planes, 6 partial products on the bf16 MFMA [bf16x6])",
               "fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into two bf16 terms, fp32 accumulate; reduced precision)",
               "bf16x6": "f32 (fp32 operands as 3 bf16 planes, 6 partial products on the bf16 MFMA, fp32 accumulate: fp32-grade)"}
 
