@@ -771,6 +771,7 @@ static int resnet_forward(relax_handle* h, const uint8_t* frags, int N, int n_ls
                 if (want_export) RELAX_TRY(launch_nhwc_to_nchw(h, cur32, taps_nchw[blk.tap], N, HWo, Cout, s));
             }
         }
+        RELAX_REQUIRE(h, next_slot <= (int)kImgSlots, "resnet50: %d per-image scale slots used, %d reserved", next_slot, (int)kImgSlots);
         return pool_tail(cur32, avg6, gapws);
     }
     auto emit_tap = [&](int tap, const float* act) -> int {
