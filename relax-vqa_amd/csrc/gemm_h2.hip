@@ -43,6 +43,9 @@
 #include "gelu.h"
 
 // Phase-stamp hooks of the diagnostic build: empty in the product (tools/abl/gemm_h2_stamps.hip defines them and #includes this file).
+#ifndef H3_EP_FETCH_AHEAD
+#define H3_EP_FETCH_AHEAD 0
+#endif
 #ifndef H2_STAMP
 #define H2_STAMP(i_)
 #define H2_STAMPS_BEFORE_LAUNCH(h_, p_, units_)
@@ -511,6 +514,17 @@ __global__ __launch_bounds__(512, 2) void gemm_h2(const H2Params p) {
 constexpr int H3_STAGE = (H2_BM + H2_BN) * 128;   // 64 KB
 constexpr int H3_NSTG = 2;
 
+// the maximum over the 16 lanes of a DPP row, in every lane of the row (quad swaps, then the two mirrors)
+__device__ inline float dpp_row_max(float v) {
+#define H3_DPP_MAX(CTRL_) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL_, 0xf, 0xf, true)))
+    H3_DPP_MAX(0xB1);    // quad_perm [1, 0, 3, 2]
+    H3_DPP_MAX(0x4E);    // quad_perm [2, 3, 0, 1]
+    H3_DPP_MAX(0x141);   // row_half_mirror
+    H3_DPP_MAX(0x140);   // row_mirror
+#undef H3_DPP_MAX
+    return v;
+}
+
 // PERIMG: the per-image features of the convolution launches (per-image scales, plane residual, fused means, maxima, out_rows): the
 // plain GEMMs of the ViT keep the lean epilogue
 template <bool FOUR, bool TAPS = false, bool PERIMG = false>
@@ -785,49 +799,86 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     const bool interior = m0 + BM <= p.M;   // workgroup-uniform
     // per-image maxima of this tile, behind the staging area (which takes the first EP_ROWS * LDC * 4 = 66.5 KB of the stages)
     unsigned* simg = reinterpret_cast<unsigned*>(smem + 96 * 1024);
-    const int img_first = p.rows_per_img > 0 ? m0 / p.rows_per_img : 0;
+    // row -> image without a division per row: the tile's first image and its row offset inside that image are workgroup-uniform, the
+    // quotient of the small remainder comes from a float product and one correction step either way (exact: the operands are < 2^24)
+    const int rpi = p.rows_per_img;
+    const int img_first = rpi > 0 ? m0 / rpi : 0;
+    const int row_first = m0 - img_first * rpi;
+    const float rpi_inv = rpi > 0 ? 1.f / (float)rpi : 0.f;
+    auto img_of_row = [&](int trow) -> int {
+        const int x = row_first + trow;
+        int q = (int)((float)x * rpi_inv);
+        q -= (q * rpi > x) ? 1 : 0;
+        q += ((q + 1) * rpi <= x) ? 1 : 0;
+        return img_first + q;
+    };
     const bool lds_amax = PERIMG && p.amax_out && slice < 0 && p.rows_per_img >= 18;   // at most 16 images under the tile's 256 rows
     if (lds_amax && tid < 16) simg[tid] = 0u;   // (ordered before the first use by the barrier of the first pass)
+    // Addresses: the fp32 matrices and the plane matrices have the same row pitch (4 N bytes) and a 256-column tile starts 4 n0 bytes into
+    // the row in both, so ONE workgroup-uniform byte offset places the tile in all of them (64-bit, scalar registers); a thread adds a
+    // 32-bit offset - its row inside the tile, its 8 columns as fp32 (ofs_f, second group ofs_fb further) or as plane units (ofs_p) - and
+    // the row step of a pass is uniform again: loads and stores take the scalar-base form, one VALU add per row instead of a 64-bit
+    // multiply per access
+    const int64_t tile_ofs = ((int64_t)m0 * p.N + n0) * 4;
+    const unsigned row_pitch = (unsigned)p.N * 4u;
+    const unsigned ofs_f = (unsigned)lr0 * row_pitch + (unsigned)lcA * 4u;
+    const unsigned ofs_p = (unsigned)lr0 * row_pitch + (unsigned)h2_offset(lcA);
+    const unsigned ofs_fb = (unsigned)(lcB - lcA) * 4u;
+    const char* tile_res = reinterpret_cast<const char*>(p.residual) + tile_ofs;
+    const char* tile_res_h2 = p.residual_h2 + tile_ofs;
+    char* tile_out = reinterpret_cast<char*>(p.out) + tile_ofs;
+    char* tile_out_h2 = p.out_h2 + tile_ofs;
+    // What a pass needs from memory for its rows - residual, scales - is fetched by H3_EP_FETCH at the head of the pass (a plane residual
+    // stays RAW in ra / rb - hi plane, lo plane - and is decoded where it is consumed).  H3_EP_FETCH_AHEAD = 1 (convolution form) fetches
+    // pass 0 here and pass p + 1 from inside the row loop of pass p, into the registers the row has just consumed, so that the fetch would
+    // be in flight under the rest of the pass: measured SLOWER (epilogue of layer4's conv3 98.7 k -> 117.8 k cycles per tile) - the form
+    // needs 256 registers and spills 7 pointers, and every scratch reload in the row loop is an s_waitcnt vmcnt(0) that waits for the
+    // fetch it follows.  Off.
+    f32x4 ra[EP_ITERS], rb[EP_ITERS];
+    float rs[EP_ITERS], os[EP_ITERS], rri[EP_ITERS];
+    int im[EP_ITERS];
+#define H3_EP_FETCH(P_, IT_)                                                                                                     \
+    {                                                                                                                            \
+        const int trow_ = (P_) * EP_ROWS + (IT_) * EP_STEP + lr0;                                                                \
+        const int m_ = m0 + trow_;                                                                                               \
+        const unsigned row_ofs_ = (unsigned)(((P_) * EP_ROWS + (IT_) * EP_STEP) * row_pitch);                                    \
+        ra[IT_] = zero4;                                                                                                         \
+        rb[IT_] = zero4;                                                                                                         \
+        rs[IT_] = 1.f;                                                                                                           \
+        os[IT_] = p.out_scale;                                                                                                   \
+        rri[IT_] = 1.f;                                                                                                          \
+        im[IT_] = 0;                                                                                                             \
+        if (slice < 0 && (interior || m_ < p.M)) {                                                                               \
+            if (p.residual) {                                                                                                    \
+                const char* r_ = tile_res + (size_t)(unsigned)(row_ofs_ + ofs_f);                                                \
+                ra[IT_] = *reinterpret_cast<const f32x4*>(r_);                                                                   \
+                rb[IT_] = *reinterpret_cast<const f32x4*>(r_ + ofs_fb);                                                          \
+            }                                                                                                                    \
+            if (p.rowscale) rs[IT_] = p.rowscale[m_];                                                                            \
+            if (PERIMG && rpi > 0) { /* per-image scales: the row's image */                                                     \
+                im[IT_] = img_of_row(trow_);                                                                                     \
+                if (p.img_in_inv) rs[IT_] = p.img_in_inv[im[IT_]];                                                               \
+                if (p.img_out_scale) os[IT_] = p.img_out_scale[im[IT_]];                                                         \
+            }                                                                                                                    \
+            if (PERIMG && p.residual_h2) { /* the residual as fp16 planes (planes: lcB = lcA + 4): hi unit, lo unit */           \
+                const char* r_ = tile_res_h2 + (size_t)(unsigned)(row_ofs_ + ofs_p);                                             \
+                ra[IT_] = __builtin_bit_cast(f32x4, *reinterpret_cast<const h2_u32x4*>(r_));                                     \
+                rb[IT_] = __builtin_bit_cast(f32x4, *reinterpret_cast<const h2_u32x4*>(r_ + 32));                                \
+                rri[IT_] = p.img_res_inv[im[IT_]];                                                                               \
+            }                                                                                                                    \
+        }                                                                                                                        \
+    }
+    constexpr bool EP_AHEAD = PERIMG && H3_EP_FETCH_AHEAD;
+    if constexpr (EP_AHEAD) {
+#pragma unroll
+        for (int it = 0; it < EP_ITERS; ++it) H3_EP_FETCH(0, it);
+    }
 #pragma unroll
     for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
         if (pass > 0) __syncthreads();
-        f32x4 ra[EP_ITERS], rb[EP_ITERS];
-        float rs[EP_ITERS], os[EP_ITERS];
-        int im[EP_ITERS];
+        if constexpr (!EP_AHEAD) {
 #pragma unroll
-        for (int it = 0; it < EP_ITERS; ++it) {
-            const int m = m0 + pass * EP_ROWS + it * EP_STEP + lr0;
-            ra[it] = zero4;
-            rb[it] = zero4;
-            rs[it] = 1.f;
-            os[it] = p.out_scale;
-            im[it] = 0;
-            if (slice < 0 && (interior || m < p.M)) {
-                if (p.residual) {
-                    const float* r = p.residual + (int64_t)m * p.N + n0;
-                    ra[it] = *reinterpret_cast<const f32x4*>(r + lcA);
-                    rb[it] = *reinterpret_cast<const f32x4*>(r + lcB);
-                }
-                if (p.rowscale) rs[it] = p.rowscale[m];
-                if (PERIMG && p.rows_per_img > 0) {   // per-image scales: the row's image
-                    im[it] = m / p.rows_per_img;
-                    if (p.img_in_inv) rs[it] = p.img_in_inv[im[it]];
-                    if (p.img_out_scale) os[it] = p.img_out_scale[im[it]];
-                }
-                if (PERIMG && p.residual_h2) {   // the residual as fp16 planes: (hi + lo) / scale is the stored 22-bit value, exactly (planes: lcB = lcA + 4)
-                    const char* r = p.residual_h2 + (int64_t)m * ((int64_t)p.N * 4) + h2_offset(n0 + lcA);
-                    const h2_u32x4 hi = *reinterpret_cast<const h2_u32x4*>(r), lo = *reinterpret_cast<const h2_u32x4*>(r + 32);
-                    const float ri = p.img_res_inv[im[it]];
-#define H2_LO16(u_) ((float)__builtin_bit_cast(_Float16, (unsigned short)((u_) & 0xffffu)))
-#define H2_HI16(u_) ((float)__builtin_bit_cast(_Float16, (unsigned short)((u_) >> 16)))
-                    ra[it] = (f32x4){H2_LO16(hi.x) + H2_LO16(lo.x), H2_HI16(hi.x) + H2_HI16(lo.x), H2_LO16(hi.y) + H2_LO16(lo.y),
-                                     H2_HI16(hi.y) + H2_HI16(lo.y)} * ri;
-                    rb[it] = (f32x4){H2_LO16(hi.z) + H2_LO16(lo.z), H2_HI16(hi.z) + H2_HI16(lo.z), H2_LO16(hi.w) + H2_LO16(lo.w),
-                                     H2_HI16(hi.w) + H2_HI16(lo.w)} * ri;
-#undef H2_LO16
-#undef H2_HI16
-                }
-            }
+            for (int it = 0; it < EP_ITERS; ++it) H3_EP_FETCH(pass, it);
         }
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
@@ -845,6 +896,26 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
             const int lr = it * EP_STEP + lr0;
             const int trow = pass * EP_ROWS + lr;
             const int m = m0 + trow;
+            // this row's operands leave the fetch registers (a plane residual is decoded: (hi + lo) / scale is the stored 22-bit value,
+            // exactly)
+            f32x4 xa = ra[it], xb = rb[it];
+            const float rs_it = rs[it], os_it = os[it];
+            const int im_it = im[it];
+            if (PERIMG && p.residual_h2) {
+                const h2_u32x4 hi = __builtin_bit_cast(h2_u32x4, xa), lo = __builtin_bit_cast(h2_u32x4, xb);
+                const float ri = rri[it];
+#define H2_LO16(u_) ((float)__builtin_bit_cast(_Float16, (unsigned short)((u_) & 0xffffu)))
+#define H2_HI16(u_) ((float)__builtin_bit_cast(_Float16, (unsigned short)((u_) >> 16)))
+                xa = (f32x4){H2_LO16(hi.x) + H2_LO16(lo.x), H2_HI16(hi.x) + H2_HI16(lo.x), H2_LO16(hi.y) + H2_LO16(lo.y),
+                             H2_HI16(hi.y) + H2_HI16(lo.y)} * ri;
+                xb = (f32x4){H2_LO16(hi.z) + H2_LO16(lo.z), H2_HI16(hi.z) + H2_HI16(lo.z), H2_LO16(hi.w) + H2_LO16(lo.w),
+                             H2_HI16(hi.w) + H2_HI16(lo.w)} * ri;
+#undef H2_LO16
+#undef H2_HI16
+            }
+            if constexpr (EP_AHEAD) {
+                if (pass + 1 < BM / EP_ROWS) H3_EP_FETCH(pass + 1, it);
+            }
             if (!interior && m >= p.M) continue;
             f32x4 va = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lcA);
             f32x4 vb = *reinterpret_cast<const f32x4*>(stg + lr * LDC + lcB);
@@ -855,11 +926,11 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                 continue;
             }
             // powers of two: exact.  Then (acc + bias) + residual, the same order on every path
-            va = va * (cs_a * rs[it]) + bias_a;
-            vb = vb * (cs_b * rs[it]) + bias_b;
+            va = va * (cs_a * rs_it) + bias_a;
+            vb = vb * (cs_b * rs_it) + bias_b;
             if (p.residual || (PERIMG && p.residual_h2)) {
-                va += ra[it];
-                vb += rb[it];
+                va += xa;
+                vb += xb;
             }
             if (p.act == 1) {
                 va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};
@@ -868,27 +939,34 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                 va = gelu_erf4(va);
                 vb = gelu_erf4(vb);
             }
-            const int64_t o = (int64_t)m * p.N + n0;
+            const unsigned row_ofs = (unsigned)((pass * EP_ROWS + it * EP_STEP) * row_pitch);
             if (p.out && (!PERIMG || m < p.out_rows)) {
-                *reinterpret_cast<f32x4*>(p.out + o + lcA) = va;
-                *reinterpret_cast<f32x4*>(p.out + o + lcB) = vb;
+                char* o = tile_out + (size_t)(unsigned)(row_ofs + ofs_f);
+                *reinterpret_cast<f32x4*>(o) = va;
+                *reinterpret_cast<f32x4*>(o + ofs_fb) = vb;
             }
             if (PERIMG && p.gap) {   // the finished values go back to the staging rows for the group sums below
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcA) = va;
                 *reinterpret_cast<f32x4*>(stg + lr * LDC + lcB) = vb;
             }
-            if (p.out_h2 && !H3_ABL_NO_OUT_H2(TAPS, p)) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, os[it]);   // (planes: lcB = lcA + 4)
+            if (p.out_h2 && !H3_ABL_NO_OUT_H2(TAPS, p)) {   // (planes: lcB = lcA + 4)
+                h2_u32x4 hi, lo;
+                split2_x8(va * os_it, vb * os_it, hi, lo);
+                char* o = tile_out_h2 + (size_t)(unsigned)(row_ofs + ofs_p);
+                *reinterpret_cast<h2_u32x4*>(o) = hi;
+                *reinterpret_cast<h2_u32x4*>(o + 32) = lo;
+            }
             if (PERIMG && p.amax_out) {
-                // the largest output of this row segment (outputs are >= 0: these launches end in a ReLU), over the 32 lanes that share
-                // the row, into the image's slot: integer max of the bits = float max, order-free, so the maximum - and every scale
-                // derived from it - is the same whatever batch the image travels in.  Collected per tile in LDS first (a tile spans a few
-                // images): one global atomic per image and tile instead of one per row segment
+                // the largest output of this row segment (outputs are >= 0: these launches end in a ReLU) into the image's slot: integer
+                // max of the bits = float max, order-free, so the maximum - and every scale derived from it - is the same whatever batch
+                // the image travels in.  The 32 lanes that share the row are two DPP rows: four DPP steps leave the maximum of 16 lanes
+                // in each of them (no LDS round trips), and the first lane of either row posts it.  Collected per tile in LDS first (a
+                // tile spans a few images): one global atomic per image and tile instead of one per row segment
                 float mx = fmaxf(fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w)), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)));
-#pragma unroll
-                for (int o = 16; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-                if ((tid & 31) == 0) {
-                    if (lds_amax) atomicMax(simg + (im[it] - img_first), __float_as_uint(mx));
-                    else atomicMax(p.amax_out + im[it], __float_as_uint(mx));
+                mx = dpp_row_max(mx);
+                if ((tid & 15) == 0) {
+                    if (lds_amax) atomicMax(simg + (im_it - img_first), __float_as_uint(mx));
+                    else atomicMax(p.amax_out + im_it, __float_as_uint(mx));
                 }
             }
         }
@@ -909,6 +987,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
             }
         }
     }
+#undef H3_EP_FETCH
     if (lds_amax) {
         __syncthreads();
         if (tid < 16 && simg[tid] != 0u) atomicMax(p.amax_out + img_first + tid, simg[tid]);
