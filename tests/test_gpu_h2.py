@@ -164,6 +164,8 @@ from relax_vqa_amd.engine import pack_conv_weight  # noqa: E402
 CONVS = [  # Nimg, H, Cin, Cout, k, stride, pad
     (2, 14, 256, 256, 3, 1, 1), (5, 7, 512, 512, 3, 1, 1), (2, 7, 2048, 512, 1, 1, 0), (3, 28, 256, 512, 1, 2, 0), (7, 7, 512, 2048, 1, 1, 0),
     (2, 14, 1024, 256, 1, 1, 0), (3, 14, 512, 512, 3, 2, 1), (40, 14, 256, 256, 3, 1, 1), (3, 30, 32, 256, 3, 2, 1),
+    # small images: a 256-row tile spans 4 / 11 / 16 images of very different magnitude (the epilogue finds a row's image without a division)
+    (33, 9, 64, 256, 1, 1, 0), (50, 5, 64, 256, 3, 1, 1), (70, 4, 64, 256, 1, 1, 0),
     # the four-wave f16x2 form of gemm_x6.hip (64 / 128 output columns, K x K, K >= 256): the 3x3 convolutions of layer1 / layer2
     (2, 56, 64, 64, 3, 1, 1), (3, 28, 128, 128, 3, 1, 1), (2, 56, 128, 128, 3, 2, 1), (5, 9, 64, 64, 3, 1, 1), (2, 14, 32, 64, 3, 1, 1),
     (37, 7, 64, 128, 3, 1, 1), (2, 12, 16, 64, 5, 2, 2),
