@@ -831,9 +831,11 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     // What a pass needs from memory for its rows - residual, scales - is fetched by H3_EP_FETCH at the head of the pass (a plane residual
     // stays RAW in ra / rb - hi plane, lo plane - and is decoded where it is consumed).  H3_EP_FETCH_AHEAD = 1 (convolution form) fetches
     // pass 0 here and pass p + 1 from inside the row loop of pass p, into the registers the row has just consumed, so that the fetch would
-    // be in flight under the rest of the pass: measured SLOWER (epilogue of layer4's conv3 98.7 k -> 117.8 k cycles per tile) - the form
-    // needs 256 registers and spills 7 pointers, and every scratch reload in the row loop is an s_waitcnt vmcnt(0) that waits for the
-    // fetch it follows.  Off.
+    // be in flight under the rest of the pass: measured twice, never faster - with per-access 64-bit addresses the form needed 256
+    // registers and spilled 7 pointers, and every scratch reload in the row loop is an s_waitcnt vmcnt(0) that waits for the fetch it
+    // follows (epilogue of layer4's conv3 98.7 k -> 117.8 k cycles per tile); with the scalar-base addresses above 4 spills remain, outside
+    // the row loop, and a ResNet-50 pass takes the same 36.5 ms either way (that epilogue 76 k -> 86 k by the stamps): the wait for the
+    // residual rows is not what bounds these epilogues.  Off (tools/build_ablations.sh h3ahead, tools/r06_h3ahead.sh).
     f32x4 ra[EP_ITERS], rb[EP_ITERS];
     float rs[EP_ITERS], os[EP_ITERS], rri[EP_ITERS];
     int im[EP_ITERS];
