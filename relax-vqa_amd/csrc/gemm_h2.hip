@@ -567,6 +567,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     }
     const int m0 = tm * BM;
     const int n0 = tn * BN;
+#ifdef H3_STAGGER   // (diagnostic, tools/build_ablations.sh h3stagger:<cycles>) the workgroups of the FIRST round start (blockIdx & 3) x H3_STAGGER cycles
+    if (PERIMG && !TAPS && blockIdx.x < 256 && (blockIdx.x & 3)) {   // apart, so that the CUs do not reach their epilogues together
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), wait = (unsigned long long)(blockIdx.x & 3) * (H3_STAGGER);
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     H2_STAMP(0);
 
     // ---- DMA descriptors.  A piece = 1 KiB = 16 rows x 64 B of one image; the images hold 32 pieces each (activation rows: 0 .. 15,
@@ -770,6 +776,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
 #undef H3_ISSUE_ADVANCE
     H2_STAMP(2);
     __syncthreads();   // no DMA is in flight and every fragment is in registers: the stages become the epilogue staging
+    H2_STAMP(7);
 
     // ---- epilogue, staged through LDS in 64-row passes (C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r); a
     // thread owns two groups of 4 columns: adjacent (8 consecutive columns = whole 16-byte plane units) when planes leave, half a
@@ -882,6 +889,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
 #pragma unroll
             for (int it = 0; it < EP_ITERS; ++it) H3_EP_FETCH(pass, it);
         }
+        if (pass == 0) H2_STAMP(4);   // (diagnostic builds: the phases of the first pass)
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
             const int rb0 = wm * 128 + x * 16;
@@ -893,6 +901,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
             }
         }
         __syncthreads();
+        if (pass == 0) H2_STAMP(5);
 #pragma unroll
         for (int it = 0; it < EP_ITERS; ++it) {
             const int lr = it * EP_STEP + lr0;
@@ -972,6 +981,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
                 }
             }
         }
+        if (pass == 0) H2_STAMP(6);
         if (PERIMG && p.gap && slice < 0) {
             // fused spatial mean, stage 1: sums over the aligned 4-row groups of this pass, rows added in order.  Images start at multiples
             // of 4 rows (the launcher checks Ho*Wo % 4 == 0): a group never spans two images and the grouping - hence every bit - does

@@ -23,17 +23,21 @@ static int h2_report_stamps(relax_handle* h, const Params& p, int units, hipStre
     RELAX_HIP_CHECK(h, hipStreamSynchronize(s));
     std::vector<unsigned long long> hs(8 * (size_t)units);
     RELAX_HIP_CHECK(h, hipMemcpy(hs.data(), p.stamps, hs.size() * sizeof(hs[0]), hipMemcpyDeviceToHost));
-    double d[3] = {0, 0, 0};
+    double d[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int u = 0; u < p.full_tiles; ++u) {
         const unsigned long long* t = &hs[8 * (size_t)u];
         d[0] += (double)(t[1] - t[0]);
         d[1] += (double)(t[2] - t[1]);
         d[2] += (double)(t[3] - t[2]);
+        d[3] += (double)(t[4] - t[2]);   // first epilogue pass (gemm_h3): what the pass needs from memory requested,
+        d[4] += (double)(t[5] - t[4]);   // accumulators staged + barrier,
+        d[5] += (double)(t[6] - t[5]);   // rows finished
+        d[6] += (double)(t[7] - t[2]);   // the barrier behind the K loop
     }
     const double n = p.full_tiles > 0 ? p.full_tiles : 1;
     fprintf(stderr, "h2 %dx%dx%d act %d res %d h2out %d: cycles per tile: prologue %.0f, K loop %.0f (%d steps, %.0f per step of 16 k), "
-            "epilogue %.0f\n", p.M, p.N, p.K, p.act, p.residual != nullptr, p.out_h2 != nullptr, d[0] / n, d[1] / n,
-            p.K / 16, d[1] / n / (p.K / 16), d[2] / n);
+            "epilogue %.0f (barrier behind the loop %.0f; first pass: fetch issued %.0f after the loop, staged %.0f, rows %.0f)\n", p.M, p.N, p.K, p.act, p.residual != nullptr, p.out_h2 != nullptr,
+            d[0] / n, d[1] / n, p.K / 16, d[1] / n / (p.K / 16), d[2] / n, d[6] / n, d[3] / n, d[4] / n, d[5] / n);
     return RELAX_OK;
 }
 }  // namespace relax

@@ -38,6 +38,7 @@ for n in "$@"; do
     h3b2b) $CC -I. -DH3_B2B_BOUND -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_b2b.o; link gemm_h2.o /tmp/gemm_h2_b2b.o h3b2b ;;
     h3ahead) $CC -I. -DH3_EP_FETCH_AHEAD=1 -c gemm_h2.hip -o /tmp/gemm_h2_ahead.o; link gemm_h2.o /tmp/gemm_h2_ahead.o h3ahead ;;
     h3ahead_stamps) $CC -I. -DH3_EP_FETCH_AHEAD=1 -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_ahead_st.o; link gemm_h2.o /tmp/gemm_h2_ahead_st.o h3ahead_stamps ;;
+    h3stagger:*) $CC -I. -DH3_STAGGER=${n#h3stagger:} -c gemm_h2.hip -o /tmp/gemm_h2_stg.o; link gemm_h2.o /tmp/gemm_h2_stg.o h3stagger${n#h3stagger:} ;;
     h2l2hit) $CC -I. -DH3_L2HIT -c ../../tools/abl/gemm_h2_stamps.hip -o /tmp/gemm_h2_l2hit.o; link gemm_h2.o /tmp/gemm_h2_l2hit.o h2l2hit ;;
     flowstamps) $FLOWCC -I. -c ../../tools/abl/flow_stamps.hip -o /tmp/flow_stamps.o; link flow.o /tmp/flow_stamps.o flowstamps ;;
     a6stamps) $CC -I. -c ../../tools/abl/attention_x6_stamps.hip -o /tmp/attention_x6_stamps.o; link attention_x6.o /tmp/attention_x6_stamps.o a6stamps ;;
