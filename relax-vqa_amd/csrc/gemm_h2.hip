@@ -794,15 +794,14 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     const int lcB = planes ? lcA + 4 : lcA + BN / 2;
     const int lr0 = tid / C8;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 bias_a = zero4, bias_b = zero4, cs_a = zero4, cs_b = zero4;
-    if (slice < 0) {
-        cs_a = *reinterpret_cast<const f32x4*>(p.colscale + n0 + lcA);
-        cs_b = *reinterpret_cast<const f32x4*>(p.colscale + n0 + lcB);
-        if (p.bias) {
-            bias_a = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcA);
-            bias_b = *reinterpret_cast<const f32x4*>(p.bias + n0 + lcB);
-        }
-    }
+    // Column scales and bias: UNCONDITIONAL loads (a K slice loads and ignores them; no bias = a buffer resource of zero bytes, whose loads
+    // answer zeros).  Loaded under `if (p.bias)` the value is a phi with the zero default, which the compiler resolved by a register copy
+    // BEHIND the load - an s_waitcnt on the load's latency at the head of every tile's epilogue, long before the first use.
+    const f32x4 cs_a = *reinterpret_cast<const f32x4*>(p.colscale + n0 + lcA);
+    const f32x4 cs_b = *reinterpret_cast<const f32x4*>(p.colscale + n0 + lcB);
+    const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    const f32x4 bias_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, (n0 + lcA) * 4, 0, 0));
+    const f32x4 bias_b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, (n0 + lcB) * 4, 0, 0));
     const bool interior = m0 + BM <= p.M;   // workgroup-uniform
     // per-image maxima of this tile, behind the staging area (which takes the first EP_ROWS * LDC * 4 = 66.5 KB of the stages)
     unsigned* simg = reinterpret_cast<unsigned*>(smem + 96 * 1024);
@@ -831,8 +830,16 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
     const unsigned ofs_f = (unsigned)lr0 * row_pitch + (unsigned)lcA * 4u;
     const unsigned ofs_p = (unsigned)lr0 * row_pitch + (unsigned)h2_offset(lcA);
     const unsigned ofs_fb = (unsigned)(lcB - lcA) * 4u;
-    const char* tile_res = reinterpret_cast<const char*>(p.residual) + tile_ofs;
-    const char* tile_res_h2 = p.residual_h2 + tile_ofs;
+    // The residual - fp32 rows or, convolution form, planes - through ONE buffer resource that starts at the tile and ends with the matrix
+    // (rows beyond M answer zeros; no residual, or a K slice: a resource of zero bytes): the loads are unconditional.  Loaded under
+    // `if (p.residual)` the rows were phis with their zero defaults, and the compiler resolved one of them by a register copy BEHIND the
+    // load: an s_waitcnt on the first load of every row before the next row's loads went out - the fetch of a pass was four latencies long.
+    const bool res_planes = PERIMG && p.residual_h2 != nullptr;   // workgroup-uniform
+    const char* res_ptr = res_planes ? p.residual_h2 : reinterpret_cast<const char*>(p.residual);
+    const int64_t res_left = (int64_t)p.M * p.N * 4 - tile_ofs;
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(res_ptr) + (res_ptr ? tile_ofs : 0), 0, (res_ptr && slice < 0) ? (int)(res_left < kH2MaxRecords ? res_left : kH2MaxRecords) : 0, 0x00020000);
+    const unsigned ofs_r = res_planes ? ofs_p : ofs_f, ofs_rb = res_planes ? 32u : ofs_fb;
     char* tile_out = reinterpret_cast<char*>(p.out) + tile_ofs;
     char* tile_out_h2 = p.out_h2 + tile_ofs;
     // What a pass needs from memory for its rows - residual, scales - is fetched by H3_EP_FETCH at the head of the pass (a plane residual
@@ -851,30 +858,20 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
         const int trow_ = (P_) * EP_ROWS + (IT_) * EP_STEP + lr0;                                                                \
         const int m_ = m0 + trow_;                                                                                               \
         const unsigned row_ofs_ = (unsigned)(((P_) * EP_ROWS + (IT_) * EP_STEP) * row_pitch);                                    \
-        ra[IT_] = zero4;                                                                                                         \
-        rb[IT_] = zero4;                                                                                                         \
+        ra[IT_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, row_ofs_ + ofs_r, 0, 0));              \
+        rb[IT_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, row_ofs_ + ofs_r + ofs_rb, 0, 0));     \
         rs[IT_] = 1.f;                                                                                                           \
         os[IT_] = p.out_scale;                                                                                                   \
         rri[IT_] = 1.f;                                                                                                          \
         im[IT_] = 0;                                                                                                             \
         if (slice < 0 && (interior || m_ < p.M)) {                                                                               \
-            if (p.residual) {                                                                                                    \
-                const char* r_ = tile_res + (size_t)(unsigned)(row_ofs_ + ofs_f);                                                \
-                ra[IT_] = *reinterpret_cast<const f32x4*>(r_);                                                                   \
-                rb[IT_] = *reinterpret_cast<const f32x4*>(r_ + ofs_fb);                                                          \
-            }                                                                                                                    \
             if (p.rowscale) rs[IT_] = p.rowscale[m_];                                                                            \
             if (PERIMG && rpi > 0) { /* per-image scales: the row's image */                                                     \
                 im[IT_] = img_of_row(trow_);                                                                                     \
                 if (p.img_in_inv) rs[IT_] = p.img_in_inv[im[IT_]];                                                               \
                 if (p.img_out_scale) os[IT_] = p.img_out_scale[im[IT_]];                                                         \
             }                                                                                                                    \
-            if (PERIMG && p.residual_h2) { /* the residual as fp16 planes (planes: lcB = lcA + 4): hi unit, lo unit */           \
-                const char* r_ = tile_res_h2 + (size_t)(unsigned)(row_ofs_ + ofs_p);                                             \
-                ra[IT_] = __builtin_bit_cast(f32x4, *reinterpret_cast<const h2_u32x4*>(r_));                                     \
-                rb[IT_] = __builtin_bit_cast(f32x4, *reinterpret_cast<const h2_u32x4*>(r_ + 32));                                \
-                rri[IT_] = p.img_res_inv[im[IT_]];                                                                               \
-            }                                                                                                                    \
+            if (res_planes) rri[IT_] = p.img_res_inv[im[IT_]]; /* (planes: ra = the hi unit, rb = the lo unit, lcB = lcA + 4) */ \
         }                                                                                                                        \
     }
     constexpr bool EP_AHEAD = PERIMG && H3_EP_FETCH_AHEAD;
@@ -902,6 +899,18 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
         }
         __syncthreads();
         if (pass == 0) H2_STAMP(5);
+        if constexpr (!EP_AHEAD) {
+            // Everything the pass fetched has to be in its registers HERE, before the first store of the row loop: the empty statement reads
+            // and redefines the registers, so the compiler waits for the loads now (they went out before the staging and the barrier) and
+            // for nothing later.  Left alone it waits in front of each row for that row's loads with a count that must hold on every
+            // path through the loop's (uniform) branches - the one without stores - and on the real path that count also covers the
+            // stores of the rows before: every row waited for the write acknowledgements of the previous one.
+#pragma unroll
+            for (int it = 0; it < EP_ITERS; ++it) {
+                asm volatile("" : "+v"(ra[it]), "+v"(rb[it]), "+v"(rs[it]));
+                if constexpr (PERIMG) asm volatile("" : "+v"(os[it]), "+v"(rri[it]));
+            }
+        }
 #pragma unroll
         for (int it = 0; it < EP_ITERS; ++it) {
             const int lr = it * EP_STEP + lr0;
@@ -912,7 +921,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
             f32x4 xa = ra[it], xb = rb[it];
             const float rs_it = rs[it], os_it = os[it];
             const int im_it = im[it];
-            if (PERIMG && p.residual_h2) {
+            if (res_planes) {
                 const h2_u32x4 hi = __builtin_bit_cast(h2_u32x4, xa), lo = __builtin_bit_cast(h2_u32x4, xb);
                 const float ri = rri[it];
 #define H2_LO16(u_) ((float)__builtin_bit_cast(_Float16, (unsigned short)((u_) & 0xffffu)))
@@ -939,7 +948,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h3(const H2Params p) {
             // powers of two: exact.  Then (acc + bias) + residual, the same order on every path
             va = va * (cs_a * rs_it) + bias_a;
             vb = vb * (cs_b * rs_it) + bias_b;
-            if (p.residual || (PERIMG && p.residual_h2)) {
+            if (res_ptr) {
                 va += xa;
                 vb += xb;
             }
