@@ -68,6 +68,9 @@
 // X6_B2B_PREFETCH_B (same bits: conv3's B fragments requested per K chunk right before their MFMAs - 0, 2.07 ms per launch of layer1 -, a whole
 // pass ahead - 1: 16 spilled registers, 2.21 ms -, or half a pass ahead of this pass's stores - 2: 14 spilled, 2.17 ms), X6_H2_STAGES (same bits:
 // LDS stages of the f16x2 3x3 loop)
+#ifndef X6_B2B_RSETS
+#define X6_B2B_RSETS 0   // residual register sets of the back-to-back tail: 0 = a whole pass (default), 4 = the rows in two halves (the old form)
+#endif
 #ifndef X6_B2B_PREFETCH_B
 #define X6_B2B_PREFETCH_B 0
 #endif
@@ -839,7 +842,11 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         const int voff_w3 = c32 * (int)w3row + half * 16;
         f16x8 bh[X6_B2B_PREFETCH_B ? KQ : 1][2], bl[X6_B2B_PREFETCH_B ? KQ : 1][2];
         constexpr int QPRE = X6_B2B_PREFETCH_B == 2 ? KQ / 2 : KQ;   // chunks of the next pass requested ahead of this pass's stores (mode 2: the first half)
-        [[maybe_unused]] u32x4 ra[4], rb[4];
+        // residual rows of a whole pass (RW / 8 lane-rows: 8 register sets on the 64-wide tiles): ALL of them are requested before the pass's
+        // first store.  With four sets the second half was requested behind the stores of the first, and a wait for those loads is a wait
+        // for every older operation of the wave - the write acknowledgements of the pass's first 32 rows (X6_B2B_RSETS=4: the old form)
+        constexpr int RSETS = (X6_B2B_RSETS) ? (X6_B2B_RSETS) : RW / 8;
+        [[maybe_unused]] u32x4 ra[RSETS], rb[RSETS];
 #define X6_B2B_LOAD_BQ(pass_, q_, slot_)                                                                                \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                  \
         const int so_ = ((pass_) * 64 + nt * 32) * (int)w3row + (wn * KQ + (q_)) * 64;   /* (this wave's K half) */        \
@@ -850,9 +857,9 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
 #define X6_B2B_LOAD_RES(pass_, it0_)                                                                                    \
     if constexpr (B2B != 2) _Pragma("unroll") for (int it = (it0_); it < (it0_) + 4; ++it) {   /* (B2B == 2: no residual) */ \
         const int so_ = (it * 8 * p.N3 + (pass_) * 64) * 4;                                                             \
-        if (X6_B2B_ABL & 2) { ra[it & 3] = (u32x4){0u, 0u, 0u, 0u}; rb[it & 3] = ra[it & 3]; continue; }                \
-        ra[it & 3] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff_row, so_, 0);                                   \
-        rb[it & 3] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff_row + 16, so_, 0);                              \
+        if (X6_B2B_ABL & 2) { ra[it % RSETS] = (u32x4){0u, 0u, 0u, 0u}; rb[it % RSETS] = ra[it % RSETS]; continue; }                \
+        ra[it % RSETS] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff_row, so_, 0);                                   \
+        rb[it % RSETS] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, voff_row + 16, so_, 0);                              \
     }
 #define X6_B2B_ROWS(it0_)                                                                                               \
     _Pragma("unroll") for (int it = (it0_); it < (it0_) + 4; ++it) {                                                    \
@@ -873,8 +880,8 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             vb = (b0 * (cs_b * ri0) + b1 * (cs_b * ri1)) + b3_b;                                                        \
         }                                                                                                               \
         if constexpr (B2B != 2) {                                                                                       \
-            va += __builtin_bit_cast(f32x4, ra[it & 3]);   /* (acc + bias) + residual: the order of the two-launch path */ \
-            vb += __builtin_bit_cast(f32x4, rb[it & 3]);                                                                \
+            va += __builtin_bit_cast(f32x4, ra[it % RSETS]);   /* (acc + bias) + residual: the order of the two-launch path */ \
+            vb += __builtin_bit_cast(f32x4, rb[it % RSETS]);                                                                \
         }                                                                                                               \
         va = (f32x4){fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f)};                           \
         vb = (f32x4){fmaxf(vb.x, 0.f), fmaxf(vb.y, 0.f), fmaxf(vb.z, 0.f), fmaxf(vb.w, 0.f)};                           \
@@ -942,12 +949,13 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             const f32x4 b3_a = *reinterpret_cast<const f32x4*>(p.bias3 + n0p + lc), b3_b = *reinterpret_cast<const f32x4*>(p.bias3 + n0p + lc + 4);
             if (X6_B2B_PREFETCH_B && pass + 1 < npass) { _Pragma("unroll") for (int q = 0; q < QPRE; ++q) X6_B2B_LOAD_BQ(pass + 1, q, q); }
             X6_B2B_LOAD_RES(pass, 0);
+            if constexpr (RW == 64 && RSETS == 8) X6_B2B_LOAD_RES(pass, 4);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's stores have reached the LDS before its loads ...
             if constexpr (WN == 1) __builtin_amdgcn_wave_barrier();
             else __builtin_amdgcn_s_barrier();                   // ... and (WN == 2) the partner's partial tile is there too
             X6_B2B_ROWS(0);
             if constexpr (RW == 64) {
-                X6_B2B_LOAD_RES(pass, 4);
+                if constexpr (RSETS != 8) X6_B2B_LOAD_RES(pass, 4);
                 X6_B2B_ROWS(4);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
