@@ -177,6 +177,12 @@ constexpr int64_t kMaxRecords = 0x7ffffff0;
 // (the loop body is rotated: one "region" = barrier .. next barrier = M1(k) + M0(k+1) is one basic block, which the compiler's
 // scheduler interleaves better than any order pinned by hand)
 // X = the operand with fewer fragments per wave (double-buffered in registers), Y = the other one (two halves).
+// a float at a workgroup-uniform address, read through the constant address space: s_load_dword into a scalar register (memory that no
+// launch in flight writes: tables an earlier launch left)
+__device__ inline float x6_uniform_load(const float* q) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<uintptr_t>(q));
+}
+
 template <int BM, int BN, int WM, int WN, bool TAPS, bool M16 = false, bool DUAL = false, bool AF32 = false, bool H2 = false, int B2B = 0>
 __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm_x6(const X6Params p) {   // 2 waves per SIMD: 2 x 4 waves or 1 x 8 (B2B on 128 rows: 3 x 4)
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (it has no __amdgpu_buffer_rsrc_t and emits no stub for a body that names it)
@@ -1034,8 +1040,21 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
     // global atomic per row segment - 1.6 M per launch of layer2's conv3, hundreds per address - cost 1.7 ms of a 1.1 ms launch)
     static_assert(EP_ROWS * LDC * 4 + 64 <= 2 * STAGE + 1024, "no room for the per-image maxima behind the staging rows");
     unsigned* simg = reinterpret_cast<unsigned*>(smem + EP_ROWS * LDC * 4);
-    const int img_first = p.amax_out ? m0 / (p.Ho * p.Wo) : 0;
+    const bool per_img = (H2 || p.out_h2 != nullptr || p.amax_out != nullptr) && p.Ho * p.Wo > 0;   // workgroup-uniform
+    const int img_first = per_img ? m0 / (p.Ho * p.Wo) : 0;
     const bool lds_amax = p.amax_out && slice < 0 && p.Ho * p.Wo >= 18;   // at most 16 images under the tile's 256 rows
+    // The per-image scalars of the rows (1 / input scale, output scale).  Images of at least BM rows (every launch of the ResNet engine): the
+    // tile's TWO images' values are loaded here, once, and a row selects.  (Loaded per row inside the row loop, each load sat behind the
+    // stores of the rows before it, and the wait for a load is a wait for every older operation of the wave: one write acknowledgement
+    // per row.)  The loads are unconditional - a launch without the table reads the first word of the weights and ignores it - so that no
+    // value is a phi with a default that the compiler may resolve by a copy behind the load.
+    const bool two_sc = per_img && p.Ho * p.Wo >= BM;
+    const int img_second = per_img && (int64_t)(img_first + 1) * (p.Ho * p.Wo) < p.M ? img_first + 1 : img_first;
+    const float* inv_tab = H2 ? p.img_in_inv : reinterpret_cast<const float*>(p.w);
+    const float* osc_tab = p.out_h2 ? p.img_out_scale : reinterpret_cast<const float*>(p.w);
+    // (uniform addresses read through the constant address space: scalar loads into scalar registers - the tables were written by earlier launches)
+    const float inv0 = x6_uniform_load(inv_tab + (H2 && two_sc ? img_first : 0)), inv1 = x6_uniform_load(inv_tab + (H2 && two_sc ? img_second : 0));
+    const float osc0 = x6_uniform_load(osc_tab + (p.out_h2 && two_sc ? img_first : 0)), osc1 = x6_uniform_load(osc_tab + (p.out_h2 && two_sc ? img_second : 0));
     if (lds_amax && tid < 16) simg[tid] = 0u;   // (ordered before the first use by the barrier of the first pass)
     // images of at least BM rows (layer1 / layer2): a tile spans at most TWO images - a thread keeps one running maximum for each in
     // registers and the workgroup reduces them once, after the last pass (no shuffles or LDS atomics per row segment)
@@ -1121,8 +1140,9 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
                 *reinterpret_cast<f32x4*>(o + lcB) = vb;
                 continue;
             }
+            const int img = per_img ? m / (p.Ho * p.Wo) : 0;
             if (H2) {   // powers of two: exact
-                const float rs = p.img_in_inv[m / (p.Ho * p.Wo)];
+                const float rs = two_sc ? (img == img_first ? inv0 : inv1) : p.img_in_inv[img];
                 va = va * (cs_a * rs);
                 vb = vb * (cs_b * rs);
             }
@@ -1146,8 +1166,8 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             }
             if (p.out_sp3) store_sp3_x8(p.out_sp3 + (int64_t)m * ((int64_t)p.N * 6), n0 + lcA, va, vb);   // (planes: lcB = lcA + 4)
             if (p.out_h2 || p.amax_out) {   // hand-over to the f16x2 layers: fp16 planes with the image's scale, the image's maximum
-                const int img = m / (p.Ho * p.Wo);
-                if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb, p.img_out_scale[img]);
+                if (p.out_h2) store_h2_x8(p.out_h2 + (int64_t)m * ((int64_t)p.N * 4), n0 + lcA, va, vb,
+                                          two_sc ? (img == img_first ? osc0 : osc1) : p.img_out_scale[img]);
                 if (p.amax_out) {   // outputs are >= 0 (ReLU): integer max of the bits = float max, order-free; per tile in LDS first
                     float mx = fmaxf(fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w)), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)));
                     if (two_img) {
