@@ -68,6 +68,10 @@
 // X6_B2B_PREFETCH_B (same bits: conv3's B fragments requested per K chunk right before their MFMAs - 0, 2.07 ms per launch of layer1 -, a whole
 // pass ahead - 1: 16 spilled registers, 2.21 ms -, or half a pass ahead of this pass's stores - 2: 14 spilled, 2.17 ms), X6_H2_STAGES (same bits:
 // LDS stages of the f16x2 3x3 loop)
+#ifndef X6_B2B_RES_EARLY
+#define X6_B2B_RES_EARLY 0   // 1: the residual rows of a pass requested AHEAD of its MFMA phase (128-wide tiles; the 64-wide ones have no registers for it).  Measured slower,
+                             // layer2's blocks 1.50 -> 1.55 ms: memory operations return in order, so the first wait for a weight fragment of the phase now waits for the residual rows
+#endif
 #ifndef X6_B2B_RSETS
 #define X6_B2B_RSETS 0   // residual register sets of the back-to-back tail: 0 = a whole pass (default), 4 = the rows in two halves (the old form)
 #endif
@@ -853,6 +857,7 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         // for every older operation of the wave - the write acknowledgements of the pass's first 32 rows (X6_B2B_RSETS=4: the old form)
         constexpr int RSETS = (X6_B2B_RSETS) ? (X6_B2B_RSETS) : RW / 8;
         [[maybe_unused]] u32x4 ra[RSETS], rb[RSETS];
+        constexpr bool RES_EARLY = (X6_B2B_RES_EARLY) && WN == 2;   // (the 64-wide tiles have no registers for it: 120 bytes of scratch per lane)
 #define X6_B2B_LOAD_BQ(pass_, q_, slot_)                                                                                \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                  \
         const int so_ = ((pass_) * 64 + nt * 32) * (int)w3row + (wn * KQ + (q_)) * 64;   /* (this wave's K half) */        \
@@ -922,6 +927,10 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
         if (X6_B2B_PREFETCH_B) { _Pragma("unroll") for (int q = 0; q < QPRE; ++q) X6_B2B_LOAD_BQ(0, q, q); }
         for (int pass = 0; pass < npass; ++pass) {
             const int n0p = pass * 64;
+            if constexpr (RES_EARLY) {   // the pass's residual rows requested ahead of its MFMA phase: they land under it
+                X6_B2B_LOAD_RES(pass, 0);
+                if constexpr (RW == 64 && RSETS == 8) X6_B2B_LOAD_RES(pass, 4);
+            }
             {
                 floatx16 c2[TM][2];
 #pragma unroll
@@ -954,8 +963,10 @@ __global__ __launch_bounds__(WM * WN * 64, (B2B && BM == 128) ? 3 : 2) void gemm
             const f32x4 cs_a = *reinterpret_cast<const f32x4*>(p.colscale3 + n0p + lc), cs_b = *reinterpret_cast<const f32x4*>(p.colscale3 + n0p + lc + 4);
             const f32x4 b3_a = *reinterpret_cast<const f32x4*>(p.bias3 + n0p + lc), b3_b = *reinterpret_cast<const f32x4*>(p.bias3 + n0p + lc + 4);
             if (X6_B2B_PREFETCH_B && pass + 1 < npass) { _Pragma("unroll") for (int q = 0; q < QPRE; ++q) X6_B2B_LOAD_BQ(pass + 1, q, q); }
-            X6_B2B_LOAD_RES(pass, 0);
-            if constexpr (RW == 64 && RSETS == 8) X6_B2B_LOAD_RES(pass, 4);
+            if constexpr (!RES_EARLY) {
+                X6_B2B_LOAD_RES(pass, 0);
+                if constexpr (RW == 64 && RSETS == 8) X6_B2B_LOAD_RES(pass, 4);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's stores have reached the LDS before its loads ...
             if constexpr (WN == 1) __builtin_amdgcn_wave_barrier();
             else __builtin_amdgcn_s_barrier();                   // ... and (WN == 2) the partner's partial tile is there too
