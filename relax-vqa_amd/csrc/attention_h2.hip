@@ -228,8 +228,14 @@ __global__ __launch_bounds__(AH_THREADS) void attention_h2(const char* __restric
 #undef AH_TR
         // oacc[dt][r] = O(query li, d = dt*32 + (r&3) + 8*(r>>2) + 4*half) * (s 2^14): runs of 4 consecutive d; the lane^32 partner holds the
         // runs in between: after swapping two runs per tile each lane owns two units of 8 consecutive d (as attention_x6)
+        // The planes leave through a buffer resource that covers the item's image exactly: the padding queries (rows >= 197) are out of its
+        // range and their stores are dropped - no branch around the stores, so every wave issues all eight of them and the waits below can be
+        // COUNTED: the eight youngest memory operations of the wave are these stores, everything older - the next item's K rows (DMA) and query
+        // planes - has landed when vmcnt <= 8.  (With `if (q < 197)` around them the count had to be 0: every item ended by waiting for the
+        // write acknowledgements of its own output.)
         const int q = wave * 32 + li;
-        const int64_t orow = (int64_t)(item / heads) * AH_NTOK + q;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_h2 + (int64_t)(item / heads) * AH_NTOK * ((int64_t)dim * 4), 0,
+                                                                                AH_NTOK * dim * 4, 0x00020000);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             float own[16], got[8];
@@ -239,24 +245,26 @@ __global__ __launch_bounds__(AH_THREADS) void attention_h2(const char* __restric
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) got[4 * u + j] = __shfl_xor(half ? own[8 * u + j] : own[8 * u + 4 + j], 32);
-            if (q < AH_NTOK) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    ah_f32x4 lo4, hi4;
-                    if (half == 0) {
-                        lo4 = (ah_f32x4){own[8 * u], own[8 * u + 1], own[8 * u + 2], own[8 * u + 3]};
-                        hi4 = (ah_f32x4){got[4 * u], got[4 * u + 1], got[4 * u + 2], got[4 * u + 3]};
-                    } else {
-                        lo4 = (ah_f32x4){got[4 * u], got[4 * u + 1], got[4 * u + 2], got[4 * u + 3]};
-                        hi4 = (ah_f32x4){own[8 * u + 4], own[8 * u + 5], own[8 * u + 6], own[8 * u + 7]};
-                    }
-                    const int d0 = (item % heads) * 64 + dt * 32 + 16 * u + 8 * half;
-                    store_h2_x8(out_h2 + orow * ((int64_t)dim * 4), d0, lo4, hi4, 1.f);   // (the output scale is folded into inv)
+            for (int u = 0; u < 2; ++u) {
+                ah_f32x4 lo4, hi4;
+                if (half == 0) {
+                    lo4 = (ah_f32x4){own[8 * u], own[8 * u + 1], own[8 * u + 2], own[8 * u + 3]};
+                    hi4 = (ah_f32x4){got[4 * u], got[4 * u + 1], got[4 * u + 2], got[4 * u + 3]};
+                } else {
+                    lo4 = (ah_f32x4){got[4 * u], got[4 * u + 1], got[4 * u + 2], got[4 * u + 3]};
+                    hi4 = (ah_f32x4){own[8 * u + 4], own[8 * u + 5], own[8 * u + 6], own[8 * u + 7]};
                 }
+                const int d0 = (item % heads) * 64 + dt * 32 + 16 * u + 8 * half;
+                h2_u32x4 ph, pl;
+                split2_x8(lo4, hi4, ph, pl);                                           // (the output scale is folded into inv)
+                const int vo = q * (dim * 4) + (int)h2_offset(d0);
+                __builtin_amdgcn_raw_buffer_store_b128(ph, rs_out, vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(pl, rs_out, vo + 32, 0, 0);
             }
         }
         if (next >= total_items) break;
-        AH_WAIT_DMA();
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the next item's K rows and query planes have landed (the 8 stores above may still be in flight)
         __syncthreads();          // every wave is done with V, and the next K rows have landed
         item = next;
     }
